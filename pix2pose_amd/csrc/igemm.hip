@@ -1,0 +1,267 @@
+// Implicit-GEMM NHWC convolution for gfx950 (CDNA4) on the fp32 matrix cores.
+//
+//   v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles/instr/SIMD,
+//   157 TFLOP/s chip peak.  The Pix2Pose parity bar (XYZ within 1e-3 abs through ~30 layers)
+//   is why the arithmetic is fp32 and not bf16 (DESIGN.md "Precision").
+//
+// One kernel serves every dense contraction of the generator graphs
+// (reference pix2pose_model/ae_model.py:70-150,175-240; resnet50_mod.py:40-118):
+//   * Conv2D 1x1 / 3x3 / 5x5, stride 1 or 2, TF 'SAME' or 'valid'  (tap table dy/dx)
+//   * Conv2DTranspose 5x5/2 as four sub-pixel phase convolutions    (os = 2, oy/ox = phase)
+//   * Dense layers as 1-tap convolutions over a 1x1 grid            (optionally split-K)
+//   * skip concatenation as a two-segment channel gather (no copy), channel slices by stride
+//   * folded BatchNorm scale/shift, residual add, ReLU / LeakyReLU, or the tanh/sigmoid heads
+//     in the epilogue.
+//
+// Tiling: 256 threads = 4 wave64; workgroup tile BM x BN (128x128 / 128x64 / 128x32), K-step 32.
+// Both operands are staged K-contiguous in LDS (row stride 36 floats => conflict-free
+// ds_read_b128: 16 rows x 4 banks cover all 64 banks).  A lane's b128 holds 4 consecutive k;
+// lanes 0-31 take k..k+3 and lanes 32-63 take k+4..k+7, so the j-th element of every lane
+// forms one 32x32x2 MFMA step (the k-permutation is the same for A and B, which is all a
+// contraction needs).  Global->LDS is register-staged (the padded LDS image rules out
+// global_load_lds) and double-buffered: one barrier per K-step, loads for step k+1 are
+// issued before the 64 (128x128 tile) MFMAs of step k.
+#include "kernels.h"
+
+namespace p2p {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDS_LD = IGEMM_BK + 4;  // padded row stride (floats)
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p)
+{
+    constexpr int BM = WGM * TM * 32;
+    constexpr int BN = WGN * TN * 32;
+    constexpr int A_PASSES = BM / 32;
+    constexpr int B_PASSES = BN / 32;
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+    __shared__ int row_base[BM];   // n*Hin*Win, or -1 for rows past M
+    __shared__ int row_yx[BM];     // (iy0 << 16) | ix0
+    __shared__ int row_out[BM];    // output pixel index, or -1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 31, lk = lane >> 5;
+
+    // ---- XCD-aware tile mapping: workgroup b runs on XCD b%8; give each XCD a contiguous
+    //      run of tiles (n-tile fastest) so A rows and the weight panel are shared in its L2.
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = t % tiles_n;
+    const int tile_m = t / tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int HgWg = p.Hg * p.Wg;
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int base = -1, yx = 0, op = -1;
+        if (m < p.M) {
+            const int n = m / HgWg;
+            const int rem = m - n * HgWg;
+            const int gy = rem / p.Wg;
+            const int gx = rem - gy * p.Wg;
+            base = n * p.Hin * p.Win;
+            yx = ((gy * p.in_stride) << 16) | (gx * p.in_stride);
+            op = (n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox;
+        }
+        row_base[r] = base;
+        row_yx[r] = yx;
+        row_out[r] = op;
+    }
+    __syncthreads();
+
+    // ---- loader state: thread handles rows (tid>>3)+32*j, 16-byte column segment (tid&7)
+    const int lrow = tid >> 3;
+    const int lcol = (tid & 7) * 4;
+    int a_base[A_PASSES], a_yx[A_PASSES];
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) {
+        a_base[j] = row_base[lrow + 32 * j];
+        a_yx[j] = row_yx[lrow + 32 * j];
+    }
+    const float* wrow = p.w + (size_t)(n0 + lrow) * p.K + lcol;
+
+    // ---- split-K range
+    const int ks_per = (p.ksteps + p.ksplit - 1) / p.ksplit;
+    const int ks0 = blockIdx.y * ks_per;
+    const int ks1 = min(p.ksteps, ks0 + ks_per);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[A_PASSES], rb[B_PASSES];
+
+    auto gload = [&](int ks) {
+        const int tap = ks / p.chunks_per_tap;
+        const int chunk = ks - tap * p.chunks_per_tap;
+        const int s = chunk >= p.seg0_chunks;
+        const IgemmSeg sg = p.seg[s];
+        const int c = (s ? chunk - p.seg0_chunks : chunk) * IGEMM_BK + sg.coff + lcol;
+        const int dy = p.dy[tap], dx = p.dx[tap];
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            const int iy = (a_yx[j] >> 16) + dy;
+            const int ix = (a_yx[j] & 0xffff) + dx;
+            const bool ok = a_base[j] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(sg.ptr + (size_t)(a_base[j] + iy * p.Win + ix) * sg.cstride + c);
+            ra[j] = v;
+        }
+        const float* wp = wrow + (size_t)ks * IGEMM_BK;
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j)
+            rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * j) * p.K);
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * LDS_LD;
+        float* Bs = As + BM * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j)
+            *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_LD + lcol) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j)
+            *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_LD + lcol) = rb[j];
+    };
+
+    if (ks0 < ks1) {
+        gload(ks0);
+        lstore(0);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const bool more = ks + 1 < ks1;
+        if (more) gload(ks + 1);
+
+        const float* As = smem + cur * (BM + BN) * LDS_LD + (wm * TM * 32 + li) * LDS_LD + lk * 4;
+        const float* Bs = smem + cur * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + lk * 4;
+#pragma unroll
+        for (int kk = 0; kk < IGEMM_BK; kk += 8) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + li;
+        const bool cok = col < p.Cout;
+        if (p.ksplit > 1) {
+            float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (cok && m < p.M) part[(size_t)m * p.Cout + col] = acc[i][j][r];
+                }
+            continue;
+        }
+        const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
+        const float sh = (cok && p.shift) ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int op = row_out[row];
+                if (!cok || op < 0) continue;
+                float v = fmaf(acc[i][j][r], sc, sh);
+                if (p.mode == EPI_HEAD) {
+                    // col = phase*4 + ch; phase = py*2 + px; ch 0..2 -> tanh (XYZ), ch 3 -> sigmoid (error)
+                    const int ch = col & 3, ph = col >> 2;
+                    const size_t o = (size_t)(op + (ph >> 1) * p.Wout + (ph & 1)) * 4 + ch;
+                    p.out[o] = ch < 3 ? tanhf(v) : 1.f / (1.f + __expf(-v));
+                } else {
+                    if (p.residual) v += p.residual[(size_t)op * p.res_cstride + col];
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : v * p.alpha;
+                    p.out[(size_t)op * p.out_cstride + p.out_coff + col] = v;
+                }
+            }
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+static hipError_t launch_cfg(const IgemmParams& p, hipStream_t s)
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+    dim3 grid(tiles, p.ksplit > 1 ? p.ksplit : 1);
+    hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s)
+{
+    switch (cfg) {
+    case 0: return launch_cfg<2, 2, 2, 2>(p, s);   // 128 x 128
+    case 1: return launch_cfg<2, 2, 2, 1>(p, s);   // 128 x 64
+    case 2: return launch_cfg<4, 1, 1, 1>(p, s);   // 128 x 32
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int M, int Cout,
+                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                     int act, float alpha, float* __restrict__ out)
+{
+    const size_t total = (size_t)M * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < ksplit; ++z) s += partial[(size_t)z * total + i];
+        const int c = (int)(i % Cout);
+        float v = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_LEAKY) v = v > 0.f ? v : v * alpha;
+        out[i] = v;
+    }
+}
+
+hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cout, const float* scale,
+                                const float* shift, int act, float alpha, float* out, hipStream_t s)
+{
+    const size_t total = (size_t)M * Cout;
+    const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, ksplit, M, Cout, scale,
+                       shift, act, alpha, out);
+    return hipGetLastError();
+}
+
+}  // namespace p2p

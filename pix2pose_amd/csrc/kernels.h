@@ -1,0 +1,73 @@
+// Internal launch interface between the host-side model code and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace p2p {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+enum EpiMode { EPI_NORMAL = 0, EPI_HEAD = 1 };
+
+constexpr int IGEMM_MAX_TAPS = 25;
+constexpr int IGEMM_BK = 32;          // K-step (floats); every channel segment is a multiple of it
+
+// One channel segment of the (virtually concatenated) NHWC input: channels
+// [coff, coff+C) of a tensor whose pixel stride is `cstride` floats.
+struct IgemmSeg {
+    const float* ptr;
+    int C;
+    int cstride;
+    int coff;
+};
+
+// Implicit-GEMM convolution  D[m, co] = sum_{tap, ci} X[pix(m) + tap][ci] * W[co][tap*Cin + ci]
+//   m enumerates (n, gy, gx) over an Hg x Wg grid; input pixel = (gy*in_stride + dy, gx*in_stride + dx)
+//   output pixel = (gy*os + oy, gx*os + ox) of an Hout x Wout image (os=2 for transposed-conv phases).
+struct IgemmParams {
+    IgemmSeg seg[2];
+    int seg0_chunks;       // seg[0].C / 32
+    int chunks_per_tap;    // (seg[0].C + seg[1].C) / 32
+    int N, Hin, Win;
+    int Hg, Wg, M;
+    int in_stride;
+    int ntaps;
+    int8_t dy[IGEMM_MAX_TAPS + 3];
+    int8_t dx[IGEMM_MAX_TAPS + 3];
+    const float* w;        // [Cout_pad][K], K = ntaps * Cin_total, rows padded to a multiple of 128
+    int K;
+    int Cout;
+    int ksteps;            // K / 32
+    int ksplit;            // gridDim.y; >1 => raw partial sums go to `partial`
+    float* partial;        // [ksplit][M][Cout]
+    const float* scale;    // per-cout (folded BatchNorm), may be null => 1
+    const float* shift;    // per-cout (bias / folded BN shift)
+    const float* residual; // optional, indexed [out_pixel * res_cstride + co]
+    int res_cstride;
+    int act;
+    float alpha;
+    float* out;
+    int Hout, Wout, os, oy, ox;
+    int out_cstride, out_coff;
+    int mode;
+};
+
+// tile configurations (BM x BN): 0 = 128x128, 1 = 128x64, 2 = 128x32
+hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s);
+
+// out[m][co] = act(sum_z partial[z][m][co] * scale + shift)
+hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cout, const float* scale,
+                                const float* shift, int act, float alpha, float* out, hipStream_t s);
+
+// First-layer direct convolution, Cin = 3 (conv1 7x7/2 of the ResNet front, conv1_x 5x5/2 of
+// the paper encoder), fused scale/shift + activation.  w_packed: [kh*kw*3][Cout].
+hipError_t launch_conv_first(const float* x, int N, int H, int W, const float* w_packed, int KH,
+                             int stride, int pad, int Cout, const float* scale, const float* shift,
+                             int act, float alpha, float* out, int Ho, int Wo, hipStream_t s);
+
+// MaxPooling2D 3x3 stride 2, TF 'SAME' (pad 0 before / 1 after), NHWC, C % 4 == 0.
+hipError_t launch_maxpool3s2(const float* x, int N, int H, int W, int C, float* out, hipStream_t s);
+
+// [n,128,128,4] -> xyz [n,128,128,3], prob [n,128,128,1]
+hipError_t launch_split_xyzp(const float* xyzp, int64_t npix, float* xyz, float* prob, hipStream_t s);
+
+}  // namespace p2p

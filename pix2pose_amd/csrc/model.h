@@ -1,0 +1,54 @@
+// Host-side objects behind the opaque handles of include/p2p_mi355.h.
+#pragma once
+#include <algorithm>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/p2p_mi355.h"
+#include "kernels.h"
+
+namespace p2p {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+// One packed dense contraction (device pointers).
+struct ConvLayer {
+    float* w = nullptr;       // [Cout_pad][K]  (conv_first: [K][Cout])
+    float* scale = nullptr;   // folded BatchNorm scale per cout
+    float* shift = nullptr;   // bias / folded BatchNorm shift per cout
+    int K = 0, Cout = 0, ntaps = 0;
+    int8_t dy[IGEMM_MAX_TAPS + 3] = {0};
+    int8_t dx[IGEMM_MAX_TAPS + 3] = {0};
+};
+
+struct Model {
+    int backbone = 0;
+    int device = 0;
+    std::map<std::string, ConvLayer> L;
+    ~Model();
+};
+
+struct Pipeline;   // est_pose workspaces (pipeline.hip)
+
+struct Ctx {
+    int device = 0;
+    int max_batch = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::string, float*> act;    // activation workspace, sized for max_batch inputs
+    float* x_stage = nullptr;
+    float* xyzp_stage = nullptr;
+    float* xyz_stage = nullptr;
+    float* prob_stage = nullptr;
+    Pipeline* pipe = nullptr;
+    int ensure_workspace();
+    void free_pipeline();
+    ~Ctx();
+};
+
+int forward_chunk(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp_dev);
+int forward_async(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp_dev);
+
+}  // namespace p2p

@@ -1,0 +1,671 @@
+// Host side of the generator forward pass: weight packing (Keras layouts -> MFMA implicit-GEMM
+// panels, BatchNorm folded into scale/shift), activation workspace, layer sequencing, and the
+// C ABI of include/p2p_mi355.h for the network call.
+//
+// Reference graphs: pix2pose_model/ae_model.py:70-150 (paper), :175-240 (resnet50),
+// pix2pose_model/resnet50_mod.py:40-118,200-213.  Call sites replaced: recognition.py:21-26
+// (construction + load_weights) and recognition.py:84,129 (generator_train.predict).
+#include "model.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace p2p {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return P2P_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+constexpr double BN_EPS = 1e-3;     // Keras BatchNormalization default
+constexpr float LEAKY = 0.3f;       // keras.layers.LeakyReLU() default
+
+// ------------------------------------------------------------------------------------------
+// weight lookup / packing (host)
+// ------------------------------------------------------------------------------------------
+struct TensorMap {
+    std::unordered_map<std::string, std::pair<const float*, int64_t>> m;
+    const float* get(const std::string& name, int64_t numel) const
+    {
+        auto it = m.find(name);
+        if (it == m.end()) {
+            set_error("weight tensor '%s' missing", name.c_str());
+            return nullptr;
+        }
+        if (it->second.second != numel) {
+            set_error("weight tensor '%s' has %lld elements, expected %lld", name.c_str(),
+                      (long long)it->second.second, (long long)numel);
+            return nullptr;
+        }
+        return it->second.first;
+    }
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static int upload(const std::vector<float>& h, float** d)
+{
+    HIP_TRY(hipMalloc((void**)d, h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return P2P_OK;
+}
+
+// scale = gamma / sqrt(var + eps); shift = (bias - mean) * scale + beta  (per output channel)
+static int fold_bn(const TensorMap& T, const std::string& name, int C, bool has_bn, std::vector<float>& scale,
+                   std::vector<float>& shift)
+{
+    const float* bias = T.get(name + ".bias", C);
+    if (!bias) return P2P_ERR_WEIGHTS;
+    if (!has_bn) {
+        for (int c = 0; c < C; ++c) { scale.push_back(1.f); shift.push_back(bias[c]); }
+        return P2P_OK;
+    }
+    const float* g = T.get(name + ".gamma", C);
+    const float* b = T.get(name + ".beta", C);
+    const float* mu = T.get(name + ".mean", C);
+    const float* var = T.get(name + ".var", C);
+    if (!g || !b || !mu || !var) return P2P_ERR_WEIGHTS;
+    for (int c = 0; c < C; ++c) {
+        const double s = (double)g[c] / std::sqrt((double)var[c] + BN_EPS);
+        scale.push_back((float)s);
+        shift.push_back((float)(((double)bias[c] - (double)mu[c]) * s + (double)b[c]));
+    }
+    return P2P_OK;
+}
+
+static int finish_layer(ConvLayer& L, const std::vector<float>& w, const std::vector<float>& scale,
+                        const std::vector<float>& shift)
+{
+    int rc;
+    if ((rc = upload(w, &L.w))) return rc;
+    if ((rc = upload(scale, &L.scale))) return rc;
+    if ((rc = upload(shift, &L.shift))) return rc;
+    return P2P_OK;
+}
+
+// Conv2D kernels (kh,kw,Cin,Cout) of `names` (concatenated along Cout: parallel branches on one
+// input, e.g. conv4_1 || conv4_2) -> W[Cout_pad][kh*kw*Cin], tap t = kh*KW+kw at (kh-pad, kw-pad).
+static int pack_conv(const TensorMap& T, const std::vector<std::string>& names, int KH, int Cin, int cout_each,
+                     int pad, bool bn, ConvLayer& L)
+{
+    const int nb = (int)names.size();
+    L.Cout = cout_each * nb;
+    L.ntaps = KH * KH;
+    L.K = L.ntaps * Cin;
+    if (L.ntaps > IGEMM_MAX_TAPS || Cin % IGEMM_BK) {
+        set_error("pack_conv(%s): unsupported shape", names[0].c_str());
+        return P2P_ERR_INVALID_ARG;
+    }
+    std::vector<float> w((size_t)round_up(L.Cout, 128) * L.K, 0.f), scale, shift;
+    for (int b = 0; b < nb; ++b) {
+        const float* k = T.get(names[b] + ".kernel", (int64_t)KH * KH * Cin * cout_each);
+        if (!k) return P2P_ERR_WEIGHTS;
+        for (int t = 0; t < L.ntaps; ++t)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int co = 0; co < cout_each; ++co)
+                    w[(size_t)(b * cout_each + co) * L.K + (size_t)t * Cin + ci] = k[((size_t)t * Cin + ci) * cout_each + co];
+        int rc = fold_bn(T, names[b], cout_each, bn, scale, shift);
+        if (rc) return rc;
+    }
+    for (int kh = 0; kh < KH; ++kh)
+        for (int kw = 0; kw < KH; ++kw) {
+            L.dy[kh * KH + kw] = (int8_t)(kh - pad);
+            L.dx[kh * KH + kw] = (int8_t)(kw - pad);
+        }
+    return finish_layer(L, w, scale, shift);
+}
+
+// First-layer (Cin=3) direct-conv panel: [kh*kw*3][Cout] (branches concatenated along Cout).
+static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& names, int KH, int cout_each,
+                           ConvLayer& L)
+{
+    const int nb = (int)names.size();
+    L.Cout = cout_each * nb;
+    L.K = KH * KH * 3;
+    std::vector<float> w((size_t)L.K * L.Cout), scale, shift;
+    for (int b = 0; b < nb; ++b) {
+        const float* k = T.get(names[b] + ".kernel", (int64_t)L.K * cout_each);
+        if (!k) return P2P_ERR_WEIGHTS;
+        for (int r = 0; r < L.K; ++r)
+            for (int co = 0; co < cout_each; ++co) w[(size_t)r * L.Cout + b * cout_each + co] = k[(size_t)r * cout_each + co];
+        int rc = fold_bn(T, names[b], cout_each, true, scale, shift);
+        if (rc) return rc;
+    }
+    return finish_layer(L, w, scale, shift);
+}
+
+// Conv2DTranspose 5x5 stride 2 'SAME' (kernel (kh,kw,Cout,Cin)); y[o] = sum x[i] w[k] with
+// o = 2i + k - 1.  Output phase (py,px): o = 2m+p uses k = p+1-2d at i = m+d,
+//   p=0: (d,k) in {(0,1), (-1,3)};  p=1: (d,k) in {(+1,0), (0,2), (-1,4)}   (SURVEY 8a-N5).
+static int pack_deconv_phase(const TensorMap& T, const std::string& name, int Cin, int Cout, int py, int px,
+                             ConvLayer& L, bool with_epilogue)
+{
+    const float* k = T.get(name + ".kernel", (int64_t)25 * Cin * Cout);
+    if (!k) return P2P_ERR_WEIGHTS;
+    L.Cout = Cout;
+    L.ntaps = 0;
+    int khs[3], kws[3], nkh = 0, nkw = 0;
+    for (int d = 1; d >= -1; --d) {
+        const int kh = py + 1 - 2 * d;
+        if (kh >= 0 && kh < 5) khs[nkh++] = kh;
+        const int kw = px + 1 - 2 * d;
+        if (kw >= 0 && kw < 5) kws[nkw++] = kw;
+    }
+    L.K = nkh * nkw * Cin;
+    std::vector<float> w((size_t)round_up(Cout, 128) * L.K, 0.f);
+    for (int a = 0; a < nkh; ++a)
+        for (int b = 0; b < nkw; ++b) {
+            const int kh = khs[a], kw = kws[b], t = L.ntaps++;
+            L.dy[t] = (int8_t)((py + 1 - kh) / 2);
+            L.dx[t] = (int8_t)((px + 1 - kw) / 2);
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                    w[(size_t)co * L.K + (size_t)t * Cin + ci] = k[(((size_t)kh * 5 + kw) * Cout + co) * Cin + ci];
+        }
+    int rc = upload(w, &L.w);
+    if (rc) return rc;
+    if (with_epilogue) {
+        std::vector<float> scale, shift;
+        if ((rc = fold_bn(T, name, Cout, true, scale, shift))) return rc;
+        if ((rc = upload(scale, &L.scale))) return rc;
+        if ((rc = upload(shift, &L.shift))) return rc;
+    }
+    return P2P_OK;
+}
+
+// Both heads (Conv2DTranspose 128->3 tanh, 128->1 sigmoid; ae_model.py:233-236) as ONE 3x3-tap
+// convolution over the 64x64 input grid with 16 "channels" = 4 output phases x (x,y,z,prob);
+// taps a phase does not use are zero (25 of 36 tap-phase pairs are live).
+static int pack_heads(const TensorMap& T, ConvLayer& L)
+{
+    const int Cin = 128;
+    const float* kx = T.get("head_xyz.kernel", (int64_t)25 * 3 * Cin);
+    const float* kp = T.get("head_prob.kernel", (int64_t)25 * 1 * Cin);
+    const float* bx = T.get("head_xyz.bias", 3);
+    const float* bp = T.get("head_prob.bias", 1);
+    if (!kx || !kp || !bx || !bp) return P2P_ERR_WEIGHTS;
+    L.Cout = 16;
+    L.ntaps = 9;
+    L.K = 9 * Cin;
+    std::vector<float> w((size_t)128 * L.K, 0.f), scale(16, 1.f), shift(16);
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int t = (dy + 1) * 3 + (dx + 1);
+            L.dy[t] = (int8_t)dy;
+            L.dx[t] = (int8_t)dx;
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px) {
+                    const int kh = py + 1 - 2 * dy, kw = px + 1 - 2 * dx;
+                    if (kh < 0 || kh > 4 || kw < 0 || kw > 4) continue;
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const int j = (py * 2 + px) * 4 + ch;
+                        for (int ci = 0; ci < Cin; ++ci)
+                            w[(size_t)j * L.K + (size_t)t * Cin + ci] =
+                                ch < 3 ? kx[(((size_t)kh * 5 + kw) * 3 + ch) * Cin + ci] : kp[((size_t)kh * 5 + kw) * Cin + ci];
+                    }
+                }
+        }
+    for (int j = 0; j < 16; ++j) shift[j] = (j & 3) < 3 ? bx[j & 3] : bp[0];
+    return finish_layer(L, w, scale, shift);
+}
+
+// Dense kernel (in,out) -> W[out_pad][in]; bias in shift.
+static int pack_dense(const TensorMap& T, const std::string& name, int In, int Out, ConvLayer& L)
+{
+    const float* k = T.get(name + ".kernel", (int64_t)In * Out);
+    if (!k) return P2P_ERR_WEIGHTS;
+    L.Cout = Out;
+    L.ntaps = 1;
+    L.K = In;
+    L.dy[0] = L.dx[0] = 0;
+    std::vector<float> w((size_t)round_up(Out, 128) * In, 0.f), scale, shift;
+    for (int i = 0; i < In; ++i)
+        for (int o = 0; o < Out; ++o) w[(size_t)o * In + i] = k[(size_t)i * Out + o];
+    int rc = fold_bn(T, name, Out, false, scale, shift);
+    if (rc) return rc;
+    return finish_layer(L, w, scale, shift);
+}
+
+static void free_layer(ConvLayer& L)
+{
+    if (L.w) hipFree(L.w);
+    if (L.scale) hipFree(L.scale);
+    if (L.shift) hipFree(L.shift);
+    L.w = L.scale = L.shift = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// model construction
+// ------------------------------------------------------------------------------------------
+static int build_decoder(const TensorMap& T, Model& M, int skip3, int skip2, int skip1)
+{
+    int rc;
+    if ((rc = pack_dense(T, "dense_enc", 32768, 256, M.L["dense_enc"]))) return rc;
+    if ((rc = pack_dense(T, "dense_dec", 256, 16384, M.L["dense_dec"]))) return rc;
+    const struct { const char* n; int cin, cout; } ups[3] = {{"up1", 256, 256}, {"up2", 256, 128}, {"up3", 256, 64}};
+    for (const auto& u : ups)
+        for (int ph = 0; ph < 4; ++ph) {
+            ConvLayer& L = M.L[std::string(u.n) + "_p" + std::to_string(ph)];
+            if ((rc = pack_deconv_phase(T, u.n, u.cin, u.cout, ph >> 1, ph & 1, L, true))) return rc;
+        }
+    if ((rc = pack_conv(T, {"deconv1"}, 5, 256 + skip3, 256, 2, true, M.L["deconv1"]))) return rc;
+    if ((rc = pack_conv(T, {"deconv2"}, 5, 128 + skip2, 256, 2, true, M.L["deconv2"]))) return rc;
+    if ((rc = pack_conv(T, {"deconv3"}, 5, 64 + skip1, 128, 2, true, M.L["deconv3"]))) return rc;
+    return pack_heads(T, M.L["heads"]);
+}
+
+static int build_model(const TensorMap& T, Model& M)
+{
+    int rc;
+    if (M.backbone == P2P_BACKBONE_RESNET50) {
+        if ((rc = pack_conv_first(T, {"conv1"}, 7, 64, M.L["conv1"]))) return rc;
+        const struct { const char* n; int cin, f1, f3; bool sc; } blocks[7] = {
+            {"res2a", 64, 64, 256, true},    {"res2b", 256, 64, 256, false},  {"res2c", 256, 64, 256, false},
+            {"res3a", 256, 128, 512, true},  {"res3b", 512, 128, 512, false}, {"res3c", 512, 128, 512, false},
+            {"res3d", 512, 128, 512, false}};
+        for (const auto& b : blocks) {
+            const std::string n = b.n;
+            if ((rc = pack_conv(T, {n + "_2a"}, 1, b.cin, b.f1, 0, true, M.L[n + "_2a"]))) return rc;
+            if ((rc = pack_conv(T, {n + "_2b"}, 3, b.f1, b.f1, 1, true, M.L[n + "_2b"]))) return rc;
+            if ((rc = pack_conv(T, {n + "_2c"}, 1, b.f1, b.f3, 0, true, M.L[n + "_2c"]))) return rc;
+            if (b.sc && (rc = pack_conv(T, {n + "_1"}, 1, b.cin, b.f3, 0, true, M.L[n + "_1"]))) return rc;
+        }
+        if ((rc = pack_conv(T, {"conv4_1", "conv4_2"}, 5, 512, 256, 1, true, M.L["conv4"]))) return rc;
+        return build_decoder(T, M, 128, 128, 32);
+    }
+    if (M.backbone == P2P_BACKBONE_PAPER) {
+        if ((rc = pack_conv_first(T, {"conv1_1", "conv1_2"}, 5, 64, M.L["conv1"]))) return rc;
+        if ((rc = pack_conv(T, {"conv2_1", "conv2_2"}, 5, 128, 128, 1, true, M.L["conv2"]))) return rc;
+        if ((rc = pack_conv(T, {"conv3_1", "conv3_2"}, 5, 256, 128, 1, true, M.L["conv3"]))) return rc;
+        if ((rc = pack_conv(T, {"conv4_1", "conv4_2"}, 5, 256, 256, 1, true, M.L["conv4"]))) return rc;
+        return build_decoder(T, M, 128, 128, 64);
+    }
+    set_error("unknown backbone %d", M.backbone);
+    return P2P_ERR_INVALID_ARG;
+}
+
+// ------------------------------------------------------------------------------------------
+// activation workspace
+// ------------------------------------------------------------------------------------------
+static const struct { const char* name; size_t per_sample; } kBuffers[] = {
+    // shared
+    {"f4", 8 * 8 * 512}, {"enc", 256}, {"dd", 8 * 8 * 256}, {"u1", 16 * 16 * 256}, {"c1", 16 * 16 * 256},
+    {"u2", 32 * 32 * 128}, {"c2", 32 * 32 * 256}, {"u3", 64 * 64 * 64}, {"c3", 64 * 64 * 128},
+    {"part", 32 * 256},
+    // front (resnet50 sizes dominate the paper ones)
+    {"f1", 64 * 64 * 128}, {"p1", 32 * 32 * 64}, {"t_a", 32 * 32 * 64}, {"t_b", 32 * 32 * 64},
+    {"sc", 32 * 32 * 256}, {"o_a", 32 * 32 * 256}, {"o_b", 32 * 32 * 256}, {"f2", 32 * 32 * 256},
+    {"f3", 16 * 16 * 512},
+};
+
+int Ctx::ensure_workspace()
+{
+    if (!act.empty()) return P2P_OK;
+    for (const auto& b : kBuffers) {
+        float* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, b.per_sample * (size_t)max_batch * sizeof(float)));
+        act[b.name] = d;
+    }
+    HIP_TRY(hipMalloc((void**)&x_stage, (size_t)max_batch * 128 * 128 * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&xyzp_stage, (size_t)max_batch * 128 * 128 * 4 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&xyz_stage, (size_t)max_batch * 128 * 128 * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&prob_stage, (size_t)max_batch * 128 * 128 * sizeof(float)));
+    return P2P_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// layer launch helpers
+// ------------------------------------------------------------------------------------------
+struct Src {
+    const float* ptr; int C; int cstride; int coff;
+};
+
+struct ConvCall {
+    Src s0{nullptr, 0, 0, 0}, s1{nullptr, 0, 0, 0};
+    int N = 0, Hin = 0, Win = 0, Hg = 0, Wg = 0, in_stride = 1;
+    float* out = nullptr;
+    int Hout = 0, Wout = 0, os = 1, oy = 0, ox = 0, out_cstride = 0, out_coff = 0;
+    int act = ACT_NONE;
+    const float* residual = nullptr;
+    int res_cstride = 0;
+    int mode = EPI_NORMAL;
+    int ksplit = 1;
+    float* partial = nullptr;
+};
+
+static int run_conv(hipStream_t st, const ConvLayer& L, const ConvCall& c)
+{
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.seg[0] = {c.s0.ptr, c.s0.C, c.s0.cstride, c.s0.coff};
+    p.seg[1] = {c.s1.ptr, c.s1.C, c.s1.cstride, c.s1.coff};
+    const int cin = c.s0.C + c.s1.C;
+    if (c.s0.C % IGEMM_BK || c.s1.C % IGEMM_BK || cin * L.ntaps != L.K) {
+        set_error("run_conv: channel segments (%d+%d) x %d taps do not match packed K=%d", c.s0.C, c.s1.C, L.ntaps, L.K);
+        return P2P_ERR_INVALID_ARG;
+    }
+    p.seg0_chunks = c.s0.C / IGEMM_BK;
+    p.chunks_per_tap = cin / IGEMM_BK;
+    p.N = c.N; p.Hin = c.Hin; p.Win = c.Win; p.Hg = c.Hg; p.Wg = c.Wg;
+    p.M = c.N * c.Hg * c.Wg;
+    p.in_stride = c.in_stride;
+    p.ntaps = L.ntaps;
+    memcpy(p.dy, L.dy, sizeof(L.dy));
+    memcpy(p.dx, L.dx, sizeof(L.dx));
+    p.w = L.w; p.K = L.K; p.Cout = L.Cout;
+    p.ksteps = L.K / IGEMM_BK;
+    p.ksplit = c.ksplit; p.partial = c.partial;
+    p.scale = L.scale; p.shift = L.shift;
+    p.residual = c.residual; p.res_cstride = c.res_cstride;
+    p.act = c.act; p.alpha = LEAKY;
+    p.out = c.out; p.Hout = c.Hout; p.Wout = c.Wout; p.os = c.os; p.oy = c.oy; p.ox = c.ox;
+    p.out_cstride = c.out_cstride; p.out_coff = c.out_coff;
+    p.mode = c.mode;
+    const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? 1 : 2);
+    HIP_TRY(launch_igemm(p, cfg, st));
+    return P2P_OK;
+}
+
+// stride-1/2 Conv2D on a full tensor `in` [N,H,W,C] -> out [N,H/s,W/s,Cout]
+static int conv_layer(hipStream_t st, const ConvLayer& L, const float* in, int N, int H, int W, int C, int stride,
+                      float* out, int act, const float* residual = nullptr)
+{
+    ConvCall c;
+    c.s0 = {in, C, C, 0};
+    c.N = N; c.Hin = H; c.Win = W; c.Hg = H / stride; c.Wg = W / stride; c.in_stride = stride;
+    c.out = out; c.Hout = c.Hg; c.Wout = c.Wg; c.out_cstride = L.Cout;
+    c.act = act; c.residual = residual; c.res_cstride = L.Cout;
+    return run_conv(st, L, c);
+}
+
+// 5x5 stride-1 'SAME' conv over the concatenation [a (Ca ch) || b[..., :Cb] (pixel stride cb_stride)]
+static int concat_conv(hipStream_t st, const ConvLayer& L, const float* a, int Ca, const float* b, int Cb,
+                       int cb_stride, int cb_off, int N, int H, float* out)
+{
+    ConvCall c;
+    c.s0 = {a, Ca, Ca, 0};
+    c.s1 = {b, Cb, cb_stride, cb_off};
+    c.N = N; c.Hin = H; c.Win = H; c.Hg = H; c.Wg = H;
+    c.out = out; c.Hout = H; c.Wout = H; c.out_cstride = L.Cout;
+    c.act = ACT_LEAKY;
+    return run_conv(st, L, c);
+}
+
+// Conv2DTranspose 5x5/2 + BN + LeakyReLU as four phase convolutions
+static int deconv_layer(hipStream_t st, const Model& M, const char* name, const float* in, int N, int H, int C,
+                        float* out)
+{
+    for (int ph = 0; ph < 4; ++ph) {
+        const ConvLayer& L = M.L.at(std::string(name) + "_p" + std::to_string(ph));
+        ConvCall c;
+        c.s0 = {in, C, C, 0};
+        c.N = N; c.Hin = H; c.Win = H; c.Hg = H; c.Wg = H;
+        c.out = out; c.Hout = 2 * H; c.Wout = 2 * H; c.os = 2; c.oy = ph >> 1; c.ox = ph & 1;
+        c.out_cstride = L.Cout;
+        c.act = ACT_LEAKY;
+        int rc = run_conv(st, L, c);
+        if (rc) return rc;
+    }
+    return P2P_OK;
+}
+
+static int res_block(hipStream_t st, const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H,
+                     int Cin, int f1, int stride, bool shortcut, float* out)
+{
+    int rc;
+    const int Ho = H / stride;
+    float* ta = X.act["t_a"];
+    float* tb = X.act["t_b"];
+    if ((rc = conv_layer(st, M.L.at(n + "_2a"), in, N, H, H, Cin, stride, ta, ACT_RELU))) return rc;
+    if ((rc = conv_layer(st, M.L.at(n + "_2b"), ta, N, Ho, Ho, f1, 1, tb, ACT_RELU))) return rc;
+    const float* res = in;
+    if (shortcut) {
+        if ((rc = conv_layer(st, M.L.at(n + "_1"), in, N, H, H, Cin, stride, X.act["sc"], ACT_NONE))) return rc;
+        res = X.act["sc"];
+    }
+    return conv_layer(st, M.L.at(n + "_2c"), tb, N, Ho, Ho, f1, 1, out, ACT_RELU, res);
+}
+
+// x_dev [n,128,128,3] -> xyzp_dev [n,128,128,4]; n <= ctx.max_batch
+int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
+{
+    int rc;
+    hipStream_t st = X.stream;
+    auto& A = X.act;
+    const float *s1, *s2, *s3;      // skip tensors and their pixel strides / channel offsets
+    int s1_stride, s1_off, s1_C, s2_stride, s2_off, s3_stride, s3_off;
+    if (M.backbone == P2P_BACKBONE_RESNET50) {
+        const ConvLayer& c1 = M.L.at("conv1");
+        HIP_TRY(launch_conv_first(x, n, 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift, ACT_RELU, LEAKY, A["f1"], 64, 64, st));
+        HIP_TRY(launch_maxpool3s2(A["f1"], n, 64, 64, 64, A["p1"], st));
+        if ((rc = res_block(st, M, X, "res2a", A["p1"], n, 32, 64, 64, 1, true, A["o_a"]))) return rc;
+        if ((rc = res_block(st, M, X, "res2b", A["o_a"], n, 32, 256, 64, 1, false, A["o_b"]))) return rc;
+        if ((rc = res_block(st, M, X, "res2c", A["o_b"], n, 32, 256, 64, 1, false, A["f2"]))) return rc;
+        if ((rc = res_block(st, M, X, "res3a", A["f2"], n, 32, 256, 128, 2, true, A["o_a"]))) return rc;
+        if ((rc = res_block(st, M, X, "res3b", A["o_a"], n, 16, 512, 128, 1, false, A["o_b"]))) return rc;
+        if ((rc = res_block(st, M, X, "res3c", A["o_b"], n, 16, 512, 128, 1, false, A["o_a"]))) return rc;
+        if ((rc = res_block(st, M, X, "res3d", A["o_a"], n, 16, 512, 128, 1, false, A["f3"]))) return rc;
+        if ((rc = conv_layer(st, M.L.at("conv4"), A["f3"], n, 16, 16, 512, 2, A["f4"], ACT_LEAKY))) return rc;
+        // ae_model.py:186-188: f1[..., :32], f2[..., :128], f3[..., :128]
+        s1 = A["f1"]; s1_stride = 64; s1_off = 0; s1_C = 32;
+        s2 = A["f2"]; s2_stride = 256; s2_off = 0;
+        s3 = A["f3"]; s3_stride = 512; s3_off = 0;
+    } else {
+        // ae_model.py:74-106: each level = two parallel 5x5/2 convs concatenated [_1 || _2];
+        // the skip is the _2 half, i.e. the upper channels of the merged output.
+        const ConvLayer& c1 = M.L.at("conv1");
+        HIP_TRY(launch_conv_first(x, n, 128, 128, c1.w, 5, 2, 1, 128, c1.scale, c1.shift, ACT_LEAKY, LEAKY, A["f1"], 64, 64, st));
+        if ((rc = conv_layer(st, M.L.at("conv2"), A["f1"], n, 64, 64, 128, 2, A["f2"], ACT_LEAKY))) return rc;
+        if ((rc = conv_layer(st, M.L.at("conv3"), A["f2"], n, 32, 32, 256, 2, A["f3"], ACT_LEAKY))) return rc;
+        if ((rc = conv_layer(st, M.L.at("conv4"), A["f3"], n, 16, 16, 256, 2, A["f4"], ACT_LEAKY))) return rc;
+        s1 = A["f1"]; s1_stride = 128; s1_off = 64; s1_C = 64;
+        s2 = A["f2"]; s2_stride = 256; s2_off = 128;
+        s3 = A["f3"]; s3_stride = 256; s3_off = 128;
+    }
+    // Flatten (HWC order) + Dense(256): split-K GEMM over K = 32768, then bias in the reduce
+    {
+        const ConvLayer& L = M.L.at("dense_enc");
+        ConvCall c;
+        c.s0 = {A["f4"], 32768, 32768, 0};
+        c.N = n; c.Hin = c.Win = c.Hg = c.Wg = 1;
+        c.out = A["enc"]; c.Hout = c.Wout = 1; c.out_cstride = 256;
+        c.ksplit = 32; c.partial = A["part"];
+        if ((rc = run_conv(st, L, c))) return rc;
+        HIP_TRY(launch_splitk_reduce(A["part"], 32, n, 256, L.scale, L.shift, ACT_NONE, LEAKY, A["enc"], st));
+    }
+    {
+        const ConvLayer& L = M.L.at("dense_dec");     // Dense(8*8*256) + Reshape((8,8,-1))
+        ConvCall c;
+        c.s0 = {A["enc"], 256, 256, 0};
+        c.N = n; c.Hin = c.Win = c.Hg = c.Wg = 1;
+        c.out = A["dd"]; c.Hout = c.Wout = 1; c.out_cstride = 16384;
+        if ((rc = run_conv(st, L, c))) return rc;
+    }
+    if ((rc = deconv_layer(st, M, "up1", A["dd"], n, 8, 256, A["u1"]))) return rc;
+    if ((rc = concat_conv(st, M.L.at("deconv1"), A["u1"], 256, s3, 128, s3_stride, s3_off, n, 16, A["c1"]))) return rc;
+    if ((rc = deconv_layer(st, M, "up2", A["c1"], n, 16, 256, A["u2"]))) return rc;
+    if ((rc = concat_conv(st, M.L.at("deconv2"), A["u2"], 128, s2, 128, s2_stride, s2_off, n, 32, A["c2"]))) return rc;
+    if ((rc = deconv_layer(st, M, "up3", A["c2"], n, 32, 256, A["u3"]))) return rc;
+    if ((rc = concat_conv(st, M.L.at("deconv3"), A["u3"], 64, s1, s1_C, s1_stride, s1_off, n, 64, A["c3"]))) return rc;
+    {
+        ConvCall c;
+        c.s0 = {A["c3"], 128, 128, 0};
+        c.N = n; c.Hin = c.Win = c.Hg = c.Wg = 64;
+        c.out = xyzp; c.Hout = c.Wout = 128; c.os = 2; c.out_cstride = 4;
+        c.mode = EPI_HEAD;
+        if ((rc = run_conv(st, M.L.at("heads"), c))) return rc;
+    }
+    return P2P_OK;
+}
+
+int forward_async(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp_dev)
+{
+    int rc = X.ensure_workspace();
+    if (rc) return rc;
+    for (int i = 0; i < n; i += X.max_batch) {
+        const int c = std::min(X.max_batch, n - i);
+        rc = forward_chunk(X, M, x_dev + (size_t)i * 128 * 128 * 3, c, xyzp_dev + (size_t)i * 128 * 128 * 4);
+        if (rc) return rc;
+    }
+    return P2P_OK;
+}
+
+Model::~Model()
+{
+    for (auto& kv : L) free_layer(kv.second);
+}
+
+Ctx::~Ctx()
+{
+    for (auto& kv : act) hipFree(kv.second);
+    if (x_stage) hipFree(x_stage);
+    if (xyzp_stage) hipFree(xyzp_stage);
+    if (xyz_stage) hipFree(xyz_stage);
+    if (prob_stage) hipFree(prob_stage);
+    free_pipeline();
+    if (stream) hipStreamDestroy(stream);
+}
+
+}  // namespace p2p
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace p2p;
+
+extern "C" {
+
+int p2p_abi_version(void) { return P2P_ABI_VERSION; }
+const char* p2p_last_error(void) { return get_error(); }
+
+int p2p_device_count(int* count)
+{
+    if (!count) { set_error("p2p_device_count: null argument"); return P2P_ERR_INVALID_ARG; }
+    HIP_TRY(hipGetDeviceCount(count));
+    return P2P_OK;
+}
+
+int p2p_ctx_create(int device, int max_batch, p2p_ctx** out)
+{
+    if (!out || max_batch < 1) { set_error("p2p_ctx_create: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { set_error("p2p_ctx_create: device %d out of range (%d devices)", device, n); return P2P_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    Ctx* c = new Ctx();
+    c->device = device;
+    c->max_batch = max_batch;
+    hipError_t e = hipStreamCreate(&c->stream);
+    if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return P2P_ERR_HIP; }
+    *out = reinterpret_cast<p2p_ctx*>(c);
+    return P2P_OK;
+}
+
+void p2p_ctx_destroy(p2p_ctx* ctx)
+{
+    if (!ctx) return;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    delete c;
+}
+
+int p2p_ctx_synchronize(p2p_ctx* ctx)
+{
+    if (!ctx) { set_error("null ctx"); return P2P_ERR_INVALID_ARG; }
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<Ctx*>(ctx)->stream));
+    return P2P_OK;
+}
+
+void* p2p_ctx_stream(p2p_ctx* ctx) { return ctx ? (void*)reinterpret_cast<Ctx*>(ctx)->stream : nullptr; }
+
+int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone, p2p_model** out)
+{
+    if (!ctx || !tensors || !out || n_tensors <= 0) { set_error("p2p_model_create: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (backbone != P2P_BACKBONE_PAPER && backbone != P2P_BACKBONE_RESNET50) {
+        // the reference silently leaves generator_train undefined here (recognition.py:21-26)
+        set_error("p2p_model_create: unknown backbone %d", backbone);
+        return P2P_ERR_INVALID_ARG;
+    }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    TensorMap T;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || !tensors[i].data) { set_error("p2p_model_create: tensor %d is null", i); return P2P_ERR_INVALID_ARG; }
+        T.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
+    }
+    Model* m = new Model();
+    m->backbone = backbone;
+    m->device = c->device;
+    int rc = build_model(T, *m);
+    if (rc) { delete m; return rc; }
+    *out = reinterpret_cast<p2p_model*>(m);
+    return P2P_OK;
+}
+
+void p2p_model_destroy(p2p_model* model)
+{
+    if (!model) return;
+    Model* m = reinterpret_cast<Model*>(model);
+    hipSetDevice(m->device);
+    delete m;
+}
+
+int p2p_forward_async(p2p_ctx* ctx, const p2p_model* model, const float* x_dev, int n, float* xyzp_dev)
+{
+    if (!ctx || !model || !x_dev || !xyzp_dev || n < 0) { set_error("p2p_forward_async: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    return forward_async(*c, *reinterpret_cast<const Model*>(model), x_dev, n, xyzp_dev);
+}
+
+int p2p_predict(p2p_ctx* ctx, const p2p_model* model, const float* x, int n, float* xyz, float* prob, int mem)
+{
+    if (!ctx || !model || n < 0 || (n > 0 && (!x || !xyz || !prob))) { set_error("p2p_predict: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    if (mem != P2P_MEM_HOST && mem != P2P_MEM_DEVICE) { set_error("p2p_predict: bad mem flag %d", mem); return P2P_ERR_INVALID_ARG; }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    const Model& m = *reinterpret_cast<const Model*>(model);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->ensure_workspace();
+    if (rc) return rc;
+    const size_t px = 128 * 128;
+    for (int i = 0; i < n; i += c->max_batch) {
+        const int k = std::min(c->max_batch, n - i);
+        const float* xin = x + (size_t)i * px * 3;
+        if (mem == P2P_MEM_HOST) {
+            HIP_TRY(hipMemcpyAsync(c->x_stage, xin, (size_t)k * px * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            xin = c->x_stage;
+        }
+        if ((rc = forward_chunk(*c, m, xin, k, c->xyzp_stage))) return rc;
+        float* oxyz = mem == P2P_MEM_HOST ? c->xyz_stage : xyz + (size_t)i * px * 3;
+        float* oprob = mem == P2P_MEM_HOST ? c->prob_stage : prob + (size_t)i * px;
+        HIP_TRY(launch_split_xyzp(c->xyzp_stage, (int64_t)k * px, oxyz, oprob, c->stream));
+        if (mem == P2P_MEM_HOST) {
+            HIP_TRY(hipMemcpyAsync(xyz + (size_t)i * px * 3, oxyz, (size_t)k * px * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(prob + (size_t)i * px, oprob, (size_t)k * px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return P2P_OK;
+}
+
+}  // extern "C"
