@@ -1,5 +1,7 @@
 """Quick timing of the generator forward pass on one GPU (development aid, not bench.py)."""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 
 import numpy as np
