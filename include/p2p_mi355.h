@@ -79,6 +79,112 @@ int p2p_predict(p2p_ctx* ctx, const p2p_model* model, const float* x, int n, flo
 int p2p_forward_async(p2p_ctx* ctx, const p2p_model* model, const float* x_dev, int n,
                       float* xyzp_dev);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Pose estimation: replaces `pix2pose.est_pose(rgb, bbox)` (reference recognition.py:70-193,
+ * crop geometry get_boxes :28-69, pnp_ransac :195-224) for a whole batch of detections.
+ * ---------------------------------------------------------------------------------------- */
+#define P2P_MAX_OUTLIER_TH 8
+
+typedef enum { P2P_IMG_U8 = 0, P2P_IMG_F32 = 1 } p2p_img_dtype;
+
+/* One H x W x 3 interleaved RGB frame (`rgb` of est_pose; uint8, or float32 as the ICP script
+ * passes, reference tools/5_evaluation_bop_icp3d.py:369-370). */
+typedef struct {
+    const void* data;
+    int height, width;
+    int dtype; /* p2p_img_dtype */
+    int mem;   /* p2p_mem */
+} p2p_image;
+
+/* Per-object state of a reference `pix2pose` instance (recognition.py:10-26): the generator
+ * network plus obj_param = [x_scale,y_scale,z_scale,x_ct,y_ct,z_ct] (tools/bop_io.py:33-42),
+ * th_outlier (1..8 values, evaluated in order), th_inlier, box_size. */
+typedef struct {
+    const p2p_model* model;
+    double obj_scale[3];
+    double obj_ct[3];
+    int n_outlier_th;
+    double outlier_th[P2P_MAX_OUTLIER_TH];
+    double inlier_th;
+    double box_size;
+} p2p_object;
+
+/* One 2D detection: which frame, which object, bbox = [v_min,u_min,v_max,u_max] (ints, as the
+ * detectors hand them over, tools/5_evaluation_bop_basic.py:289-304) and the camera matrix the
+ * caller would have assigned to `.camK` before the call (:302). */
+typedef struct {
+    int image;
+    int object;
+    int bbox[4];
+    double camK[9];
+} p2p_detection;
+
+/* est_pose status: the reference signals failure in-band with -1 sentinels (recognition.py:79,
+ * 127,191); the shim maps any status != 0 back to those sentinels. */
+typedef enum {
+    P2P_POSE_OK = 0,
+    P2P_POSE_CROP_TOO_SMALL = 1,   /* recognition.py:78-79  */
+    P2P_POSE_NO_CANDIDATE = 2,     /* recognition.py:125-127 */
+    P2P_POSE_PNP_FAILED = 3        /* recognition.py:189-191 */
+} p2p_pose_status;
+
+typedef struct {
+    double R[9];          /* rot_pred, row-major                           (recognition.py:223) */
+    double t[3];          /* tra_pred, mm                                                       */
+    double frac_inlier;   /* max_inlier / n_init_mask                      (recognition.py:193) */
+    int n_inliers;        /* len(inliers) of the selected candidate                             */
+    int n_init_mask;      /* stage-1 non-gray pixel count                  (recognition.py:90)  */
+    int status;           /* p2p_pose_status                                                    */
+    int best_slot;        /* index into outlier_th of the selected candidate, -1 if none        */
+    int bbox_t[4];        /* [v1,v2,u1,u2] as returned by the reference (box of the LAST candidate) */
+    int n_candidates;     /* stage-2 candidates that were built                                 */
+    int ransac_iters;     /* RANSAC iterations run for the selected candidate                   */
+} p2p_pose;
+
+/* Optional knobs; zero-initialise for the reference behaviour. */
+typedef struct {
+    /* PnP-RANSAC constants hard-coded at recognition.py:216-217 / OpenCV defaults. 0 => default */
+    int ransac_iterations;      /* 100  */
+    double reprojection_error;  /* 5.0  */
+    double confidence;          /* 0.99 */
+    /* TEST / BENCH ONLY: replace the decoder outputs after each generator pass (device
+     * pointers).  inject1: [n_det,128,128,4]; inject2: [n_det,n_outlier_th_max,128,128,4].
+     * The generator still runs (and is timed); its output is then overwritten.  No trained
+     * weights exist offline, so synthetic scenes drive the PnP stage this way. */
+    const float* inject1;
+    const float* inject2;
+    int inject_slots;           /* second dimension of inject2 */
+    /* optional per-detection outputs, host pointers (may be null):
+     * valid_mask [n_det][mask_stride] bytes (H*W of the detection's frame used),
+     * img_pred   [n_det][pred_stride] bytes (crop h*w*3 used) */
+    unsigned char* valid_mask;
+    int64_t mask_stride;
+    unsigned char* img_pred;
+    int64_t pred_stride;
+    /* optional debug taps (host pointers, may be null): stage-1 inputs [n_det,128,128,3] and
+     * stage-2 inputs [n_det,K,128,128,3], K = max n_outlier_th over the objects in the batch */
+    float* dbg_x1;
+    float* dbg_x2;
+    int* dbg_boxes2;            /* [n_det][12] stage-2 get_boxes result */
+    int* dbg_cand;              /* [n_det][K][4]: valid, n_non_gray, n_corr, n_inliers */
+} p2p_est_pose_opts;
+
+/* Blocking.  poses[i] corresponds to dets[i]. */
+int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images,
+                       int n_images, const p2p_detection* dets, int n_dets, p2p_pose* poses,
+                       const p2p_est_pose_opts* opts);
+
+/* Replaces `cv2.solvePnPRansac(obj, img, camK, None, flags=EPNP, reprojectionError, iterationsCount)`
+ * + `cv2.Rodrigues` (reference recognition.py:216-223) for a batch of independent problems.
+ * Problem p owns points [offsets[p], offsets[p+1]) of obj_pts [N,3] (mm, double) and img_pts
+ * [N,2] (pixels, double); camK [n_problems][9].  Host pointers.  ok[p]=0 reproduces cv2 returning
+ * inliers=None.  inlier_mask (may be null) is [N] bytes.  info[p] = {n_inliers, iterations, best_iter}. */
+int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts, const double* img_pts,
+                         const int* offsets, int n_problems, int iterations, double reprojection_error,
+                         double confidence, double* R, double* t, int* info, int* ok,
+                         unsigned char* inlier_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,281 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+CPU (numpy) restatement of ``pix2pose.est_pose`` / ``get_boxes`` / ``pnp_ransac``
+(reference pix2pose_model/recognition.py:28-69, :70-193, :195-224), including the behavioural
+quirks listed in SURVEY.md section 8a-Q.  Third-party pieces are replaced by restatements:
+
+  * ``skimage.transform.resize(order=1)``  -> :func:`resize_bilinear` (half-pixel
+    centres, per-tap border handling 'reflect' / 'constant'+cval, no anti-aliasing -- the
+    scikit-image version is unpinned in the reference; anti_aliasing was off by default until 0.15)
+  * ``cv2.solvePnPRansac`` / ``cv2.Rodrigues`` -> oracle/pnp_oracle.c
+  * ``generator_train.predict``            -> any callable (oracle/ae_oracle.forward, or injected
+    decoder outputs for the synthetic PnP scenes)
+
+PARITY UNPINNED: none of keras / cv2 / skimage is installable here and the reference has no
+tests; this file follows the reference source line by line (cited below) and the published
+semantics of those libraries.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import pnp_oracle
+
+
+# --------------------------------------------------------------------------------------
+# skimage.transform.resize(order=1) restatement
+# --------------------------------------------------------------------------------------
+def _map_reflect(i, n):
+    """numpy-pad 'reflect' (edge sample not repeated), any integer index -> [0, n)."""
+    if n == 1:
+        return np.zeros_like(i)
+    p = 2 * (n - 1)
+    i = np.mod(i, p)
+    return np.where(i >= n, p - i, i)
+
+
+def resize_bilinear(img, out_shape, mode, cval=0.0):
+    """img [H,W] or [H,W,C] (bool/float) -> float64 [oh,ow(,C)].
+    src = dst*scale + (0.5*scale - 0.5), scale = in/out; taps floor/ceil; out-of-range taps are
+    reflected ('reflect') or replaced by cval ('constant')."""
+    a = np.asarray(img)
+    a = a.astype(np.float64)
+    h, w = a.shape[:2]
+    oh, ow = out_shape
+
+    def axis(n_in, n_out):
+        s = n_in / n_out
+        src = np.arange(n_out, dtype=np.float64) * s + (0.5 * s - 0.5)
+        lo = np.floor(src)
+        hi = np.ceil(src)
+        return lo.astype(np.int64), hi.astype(np.int64), src - lo
+
+    r0, r1, dr = axis(h, oh)
+    c0, c1, dc = axis(w, ow)
+
+    def tap(ri, ci):
+        if mode == "reflect":
+            return a[_map_reflect(ri, h)][:, _map_reflect(ci, w)]
+        ok_r = (ri >= 0) & (ri < h)
+        ok_c = (ci >= 0) & (ci < w)
+        v = a[np.clip(ri, 0, h - 1)][:, np.clip(ci, 0, w - 1)]
+        ok = ok_r[:, None] & ok_c[None, :]
+        if a.ndim == 3:
+            ok = ok[..., None]
+        return np.where(ok, v, cval)
+
+    if a.ndim == 3:
+        dcb = dc[None, :, None]
+        drb = dr[:, None, None]
+    else:
+        dcb = dc[None, :]
+        drb = dr[:, None]
+    top = (1 - dcb) * tap(r0, c0) + dcb * tap(r0, c1)
+    bot = (1 - dcb) * tap(r1, c0) + dcb * tap(r1, c1)
+    return (1 - drb) * top + drb * bot
+
+
+# --------------------------------------------------------------------------------------
+# crop geometry  (recognition.py:28-69)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Boxes:
+    v1_ori: int
+    v2_ori: int
+    u1_ori: int
+    u2_ori: int
+    v1: int
+    v2: int
+    u1: int
+    u2: int
+    vv1: int
+    vv2: int
+    uu1: int
+    uu2: int
+
+    def as_list(self):
+        return [self.v1_ori, self.v2_ori, self.u1_ori, self.u2_ori, self.v1, self.v2, self.u1, self.u2,
+                self.vv1, self.vv2, self.uu1, self.uu2]
+
+
+def get_boxes(bbox, v_max, u_max, box_size=1.5, ct=None, max_w=9999) -> Boxes:
+    """Square crop of side 2*int(w/2), w = min(max_w, box_size*max(width,height)), centred on the
+    bbox centre (or ``ct``), clipped to the image; plus paste offsets into a zero canvas."""
+    if ct is None:                                           # :29-31
+        ct_v = int((bbox[0] + bbox[2]) / 2)
+        ct_u = int((bbox[1] + bbox[3]) / 2)
+    else:                                                    # :32-34
+        ct_v, ct_u = ct[0], ct[1]
+    width = bbox[3] - bbox[1]                                # :36-37
+    height = bbox[2] - bbox[0]
+    w = min(max_w, max(width * box_size, height * box_size))  # :38
+    half = int(w / 2)
+    v1o, v2o = ct_v - half, ct_v + half                      # :40-43
+    u1o, u2o = ct_u - half, ct_u + half
+    v1, v2, u1, u2 = v1o, v2o, u1o, u2o
+    sv0 = su0 = sv1 = su1 = 0
+    if v1o < 0:                                              # :53-55
+        sv0 = abs(v1o); v1 = 0
+    if v2o > v_max:                                          # :56-58
+        sv1 = -abs(v2o - v_max); v2 = v_max
+    if u1o < 0:                                              # :59-61
+        su0 = abs(u1o); u1 = 0
+    if u2o > u_max:                                          # :62-64
+        su1 = -abs(u2o - u_max); u2 = u_max
+    return Boxes(int(v1o), int(v2o), int(u1o), int(u2o), int(v1), int(v2), int(u1), int(u2),
+                 int(sv0), int(sv1 + (v2o - v1o)), int(su0), int(su1 + (u2o - u1o)))   # :65-69
+
+
+# --------------------------------------------------------------------------------------
+# PnP front end  (recognition.py:195-224)
+# --------------------------------------------------------------------------------------
+def correspondences(rgb_aug, img_prob_ori, non_zero, v1, v2, u1, u2, obj_scale, obj_ct, th_i):
+    """u8 XYZ canvas -> (obj_pts [n,3] mm, img_pts [n,2] (u,v), valid_mask)  (:196-213)."""
+    xyz = np.copy(rgb_aug[v1:v2, u1:u2]).astype(np.float64)
+    xyz = xyz / 255
+    xyz = xyz * 2 - 1
+    for k in range(3):
+        xyz[:, :, k] = xyz[:, :, k] * obj_scale[k] + obj_ct[k]
+    valid = np.logical_and(non_zero, img_prob_ori < th_i)
+    vs, us = np.where(valid == 1)                     # row-major order
+    obj_pts = xyz[vs, us]
+    img_pts = np.stack((us + u1, vs + v1), axis=1).astype(np.float64)
+    return obj_pts, img_pts, valid
+
+
+def pnp_ransac(rgb_aug, img_prob_ori, non_zero, v1, v2, u1, u2, camK, obj_scale, obj_ct, th_i):
+    obj_pts, img_pts, valid = correspondences(rgb_aug, img_prob_ori, non_zero, v1, v2, u1, u2, obj_scale, obj_ct, th_i)
+    if len(obj_pts) < 6:                              # :214-215
+        return np.eye(3), np.array([0, 0, 0]), valid, -1, None
+    ok, R, t, inl, meta = pnp_oracle.solve_pnp_ransac(obj_pts, img_pts, camK, iterations=100, reproj_err=5.0)
+    if not ok:                                        # :218-219 (inliers is None)
+        return np.eye(3), np.array([0, 0, 0]), -1, -1, meta
+    return R, t, valid, len(inl), meta                # :220-224
+
+
+# --------------------------------------------------------------------------------------
+# est_pose  (recognition.py:70-193)
+# --------------------------------------------------------------------------------------
+def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th_inlier=0.1, box_size=1.5,
+             debug=None):
+    """Returns the reference's 6-tuple.  ``predict(x[N,128,128,3]) -> [decode, prob]``.
+    ``debug`` (dict) receives intermediates for stage-wise parity tests."""
+    camK = np.asarray(camK, np.float64).reshape(3, 3)
+    obj_scale, obj_ct = np.asarray(obj_param[:3], float), np.asarray(obj_param[3:], float)
+    H, W = rgb.shape[0], rgb.shape[1]
+    dbg = debug if debug is not None else {}
+
+    b1 = get_boxes(bbox, H, W, box_size)                                             # :71
+    cx_o = (bbox[3] + bbox[1]) / 2                                                   # :72-73
+    cy_o = (bbox[2] + bbox[0]) / 2
+    w_stage_1 = b1.v2_ori - b1.v1_ori                                                # :74
+    side = b1.v2_ori - b1.v1_ori
+    base = np.zeros((side, b1.u2_ori - b1.u1_ori, 3))                               # :75
+    crop = (np.copy(rgb[b1.v1:b1.v2, b1.u1:b1.u2]).astype(np.float32) - [128, 128, 128]) / 128     # :76-77
+    fail_box = np.array([b1.v1, b1.v2, b1.u1, b1.u2], int)
+    if base.shape[0] < 5 or base.shape[1] < 5 or crop.shape[0] < 5 or crop.shape[1] < 5:   # :78-79
+        return np.zeros((1)), -1, -1, -1, -1, fail_box
+    base[b1.vv1:b1.vv2, b1.uu1:b1.uu2] = crop                                        # :81
+    x1 = resize_bilinear(base, (128, 128), "reflect")                                # :82
+    dbg["x1"] = x1.astype(np.float32)
+    decode, prob = predict(np.expand_dims(x1, 0), stage=1)                           # :84
+    decode = np.array(decode, np.float32)
+    img_pred = np.clip((decode[0] + 1) / 2, 0, 1)                                    # :85-87
+    non_gray = np.linalg.norm(decode[0], axis=2) > 0.3                               # :89
+    n_init_mask = int(np.sum(non_gray))                                              # :90
+    dbg["n_init_mask"] = n_init_mask
+    dbg["decode1"], dbg["prob1"] = decode[0], np.array(prob[0, :, :, 0], np.float32)
+
+    inputs, boxes, slots = [], [], []
+    for slot, th_o in enumerate(th_outlier):                                         # :93
+        keep = np.logical_and(non_gray, prob[0, :, :, 0] < th_o)                     # :94-95
+        if np.sum(keep) < 10:                                                        # :96-97
+            continue
+        vs, us = np.where(non_gray)                                                  # :98
+        if len(vs) == 0:
+            continue
+        bb = np.array([vs.min(), us.min(), vs.max(), us.max()])                      # :101 (of non_gray, not keep)
+        bb = bb * np.array([side / 128, (b1.u2_ori - b1.u1_ori) / 128] * 2)          # :102
+        keep_ori = resize_bilinear(keep, (side, b1.u2_ori - b1.u1_ori), "constant", 0) > 0.9       # :103
+        keep_ori = keep_ori[b1.vv1:b1.vv2, b1.uu1:b1.uu2]                            # :104
+        bg_full = np.ones((H, W), bool)                                              # :105-106
+        bg_full[b1.v1:b1.v2, b1.u1:b1.u2] = np.invert(keep_ori)
+        cx_m = int((np.mean(us) - (127 / 2)) + cx_o)                                 # :108 (quirk: 128-res offset)
+        cy_m = int((np.mean(vs) - (127 / 2)) + cy_o)                                 # :109
+        b2 = get_boxes(bb, H, W, box_size, ct=np.array([cy_m, cx_m]), max_w=w_stage_1)   # :110
+        base2 = np.zeros((b2.v2_ori - b2.v1_ori, b2.u2_ori - b2.u1_ori, 3))          # :113
+        crop2 = (np.copy(rgb[b2.v1:b2.v2, b2.u1:b2.u2]) - [128, 128, 128]) / 128     # :114-115
+        if crop2.shape[0] > 0 and crop2.shape[1] > 0:
+            crop2[bg_full[b2.v1:b2.v2, b2.u1:b2.u2]] = 0                             # :116
+        tgt = base2[b2.vv1:b2.vv2, b2.uu1:b2.uu2]
+        if (base2.shape[0] < 5 or base2.shape[1] < 5 or crop2.shape[0] < 5 or crop2.shape[1] < 5
+                or tgt.shape[0] == 0 or tgt.shape[1] == 0):                          # :117-119
+            continue
+        # NOTE the reference appends to box_refined (:111) BEFORE this `continue`, which would
+        # mis-align boxes and inputs afterwards; we keep them aligned (the misaligned case needs
+        # a <5 px re-crop and does not occur for boxes that passed the stage-1 check).
+        base2[b2.vv1:b2.vv2, b2.uu1:b2.uu2] = crop2                                  # :120
+        inputs.append(resize_bilinear(base2, (128, 128), "reflect"))                 # :121-122
+        boxes.append(b2)
+        slots.append(slot)
+    dbg["slots"] = slots
+    dbg["boxes2"] = [b.as_list() for b in boxes]
+    if len(inputs) <= 0:                                                             # :125-127
+        return img_pred, -1, -1, -1, -1, fail_box
+    dbg["x2"] = np.array(inputs, np.float32)
+
+    decode, prob = predict(np.array(inputs), stage=2, slots=slots)                   # :129
+    decode = np.array(decode, np.float32)
+    prob = np.array(prob, np.float32)
+    max_inlier, min_dist = -1, 9999999                                               # :130-131
+    rot_pred = tra_pred = valid_mask_full = img_pred_f = None
+    dbg["cands"] = []
+    last = b1
+    for c in range(len(inputs)):                                                     # :132
+        b = boxes[c]
+        last = b
+        side2, wid2 = b.v2_ori - b.v1_ori, b.u2_ori - b.u1_ori
+        prob_ori = resize_bilinear(prob[c, :, :, 0], (side2, wid2), "constant", 1)   # :134
+        prob_ori = prob_ori[b.vv1:b.vv2, b.uu1:b.uu2]                                # :135
+        gray = np.linalg.norm(decode[c], axis=2) < 0.3                               # :137
+        ng = np.invert(gray)                                                         # :138
+        decode[c, gray, :] = 0                                                       # :139
+        pred = np.clip((decode[c] + 1) / 2, 0, 1)                                    # :141-143
+        pred_ori = resize_bilinear(pred, (side2, wid2), "constant", 0.5) * 255       # :144
+        ng = resize_bilinear(ng.astype(float), (side2, wid2), "constant", 0) > 0.9   # :146
+        ng = ng[b.vv1:b.vv2, b.uu1:b.uu2]                                            # :147
+        n_non_gray = int(np.sum(ng))                                                 # :148
+        cd = {"slot": slots[c], "n_non_gray": n_non_gray}
+        dbg["cands"].append(cd)
+        if n_non_gray < 10:                                                          # :149-150
+            continue
+        pred_ori = pred_ori[b.vv1:b.vv2, b.uu1:b.uu2]                                # :151
+        canvas = np.zeros((H, W, 3), np.uint8)                                       # :152
+        canvas[b.v1:b.v2, b.u1:b.u2] = pred_ori                                      # :153-154 (float -> u8 truncation)
+        R_c, t_c, valid, n_inl, meta = pnp_ransac(canvas, prob_ori, ng, b.v1, b.v2, b.u1, b.u2, camK,
+                                                  obj_scale, obj_ct, th_inlier)      # :156
+        ng_full = np.zeros((H, W), bool)                                             # :159-162
+        ng_full[b.v1:b.v2, b.u1:b.u2] = ng
+        fv, fu = np.where(ng_full)
+        ct_pt = np.array([np.mean(fv), np.mean(fu)])
+        if t_c[2] == 0:                                                              # :163-164
+            dist = 99999
+        else:                                                                        # :165-168
+            pu = camK[0, 0] * t_c[0] / t_c[2] + camK[0, 2]
+            pv = camK[1, 1] * t_c[1] / t_c[2] + camK[1, 2]
+            dist = ((pv - ct_pt[0]) ** 2 + (pu - ct_pt[1]) ** 2) / (n_inl + 1E-6)
+        cd.update(R=np.array(R_c, float), t=np.array(t_c, float), n_inliers=n_inl, dist=float(dist), meta=meta,
+                  n_valid=int(np.sum(valid)) if not isinstance(valid, int) else -1)
+        if dist < min_dist:                                                          # :170-178
+            rot_pred, tra_pred, max_inlier, min_dist = R_c, t_c, n_inl, dist
+            valid_mask_full = np.zeros((H, W), bool)
+            valid_mask_full[b.v1:b.v2, b.u1:b.u2] = valid      # valid == -1 (int) broadcasts to True, as in the reference
+            img_pred_f = pred_ori
+            dbg["best"] = c
+    last_box = np.array([last.v1, last.v2, last.u1, last.u2], int)   # :133 overwrites v1.. -> box of the LAST candidate
+    if max_inlier == -1:                                                             # :189-191
+        return img_pred, -1, -1, -1, -1, last_box
+    return (img_pred_f.astype(np.uint8), valid_mask_full, np.array(rot_pred, float), np.array(tra_pred, float),
+            max_inlier / n_init_mask, last_box)                                      # :193

@@ -725,7 +725,13 @@ int p2po_solve_pnp_ransac(const double* K, const double* obj, const double* img,
         info[1] = iter;
         ok = max_good > 0;
     }
-    if (ok) {
+    if (ok && n == model_points) {
+        /* npoints == model_points: solvePnPRansac returns the direct solvePnP result */
+        p2po_rodrigues_v2r(best_rvec, R);
+        t[0] = best_tvec[0]; t[1] = best_tvec[1]; t[2] = best_tvec[2];
+        memcpy(inlier_mask, best_mask, n);
+        info[0] = n;
+    } else if (ok) {
         /* re-solve EPnP on all inliers (points keep their float32 rounding, promoted to double) */
         double* oi = (double*)malloc(sizeof(double) * 3 * max_good);
         double* ii = (double*)malloc(sizeof(double) * 2 * max_good);

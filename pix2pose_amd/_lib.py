@@ -23,6 +23,37 @@ class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
 
 
+MAX_TH = 8
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("height", C.c_int), ("width", C.c_int), ("dtype", C.c_int), ("mem", C.c_int)]
+
+
+class Object(C.Structure):
+    _fields_ = [("model", C.c_void_p), ("obj_scale", C.c_double * 3), ("obj_ct", C.c_double * 3),
+                ("n_outlier_th", C.c_int), ("outlier_th", C.c_double * MAX_TH), ("inlier_th", C.c_double),
+                ("box_size", C.c_double)]
+
+
+class Detection(C.Structure):
+    _fields_ = [("image", C.c_int), ("object", C.c_int), ("bbox", C.c_int * 4), ("camK", C.c_double * 9)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("frac_inlier", C.c_double), ("n_inliers", C.c_int),
+                ("n_init_mask", C.c_int), ("status", C.c_int), ("best_slot", C.c_int), ("bbox_t", C.c_int * 4),
+                ("n_candidates", C.c_int), ("ransac_iters", C.c_int)]
+
+
+class EstPoseOpts(C.Structure):
+    _fields_ = [("ransac_iterations", C.c_int), ("reprojection_error", C.c_double), ("confidence", C.c_double),
+                ("inject1", C.c_void_p), ("inject2", C.c_void_p), ("inject_slots", C.c_int),
+                ("valid_mask", C.c_void_p), ("mask_stride", C.c_int64), ("img_pred", C.c_void_p),
+                ("pred_stride", C.c_int64), ("dbg_x1", C.c_void_p), ("dbg_x2", C.c_void_p),
+                ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -56,6 +87,11 @@ def lib():
     L.p2p_model_destroy.restype = None
     L.p2p_predict.argtypes = [vp, vp, vp, ci, vp, vp, ci]
     L.p2p_forward_async.argtypes = [vp, vp, vp, ci, vp]
+    L.p2p_est_pose_batch.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,
+                                     C.POINTER(Pose), C.POINTER(EstPoseOpts)]
+    dp = C.POINTER(C.c_double)
+    L.p2p_pnp_ransac_batch.argtypes = [vp, dp, dp, dp, C.POINTER(ci), ci, ci, C.c_double, C.c_double, dp, dp,
+                                       C.POINTER(ci), C.POINTER(ci), vp]
     _lib = L
     return L
 

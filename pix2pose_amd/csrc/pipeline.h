@@ -1,0 +1,88 @@
+// Device-side records of the est_pose pipeline (crop -> generator -> masks -> re-crop ->
+// generator -> correspondences -> PnP-RANSAC -> selection).  Reference: recognition.py:28-224.
+#pragma once
+#include "model.h"
+
+namespace p2p {
+
+constexpr int MAX_TH = P2P_MAX_OUTLIER_TH;
+
+// get_boxes() result (recognition.py:28-69)
+struct Boxes {
+    int v1_ori, v2_ori, u1_ori, u2_ori;   // unclipped square
+    int v1, v2, u1, u2;                   // clipped to the frame
+    int vv1, vv2, uu1, uu2;               // paste window inside the square canvas
+};
+
+// Per-detection constants, filled on the host.
+struct DetInfo {
+    const void* img;        // device pointer to the frame
+    int H, W;
+    int img_f32;            // 0: uint8, 1: float32
+    int obj;
+    int n_th;
+    float th_o[MAX_TH];     // prob < th_o is evaluated in float32 (prob is a float32 array)
+    double th_i;            // img_prob_ori < th_i is evaluated in float64
+    double box_size;
+    double cx_o, cy_o;      // (bbox[3]+bbox[1])/2, (bbox[2]+bbox[0])/2   recognition.py:72-73
+    double K[9];
+    double obj_scale[3], obj_ct[3];
+    Boxes b1;
+    int ok1;                // 0 => recognition.py:78-79 early return
+    long long corr_off;     // float offset of this detection's correspondence storage
+    int corr_cap;           // points per candidate (stage-1 side squared)
+};
+
+// Stage-1 reductions + stage-2 geometry, written by the device.
+struct Stage1 {
+    int n_init_mask;
+    int bb[4];              // min v, min u, max v, max u of non_gray
+    long long sum_v, sum_u;
+    int keep_cnt[MAX_TH];
+    int valid2[MAX_TH];     // candidate built for threshold slot k
+    int n_cand;
+    Boxes b2;               // all candidates of a detection share it (quirk)
+};
+
+// Per-candidate reductions written by the correspondence kernel.
+struct CandStat {
+    int n_non_gray;
+    int n_corr;
+    long long sum_v, sum_u; // of non_gray pixels, frame coordinates
+};
+
+struct PnpProblem {
+    const float* pts;       // SoA: X[cap] Y[cap] Z[cap] U[cap] V[cap] (float32, as OpenCV stores them)
+    int cap;
+    int n;
+    double K[9];
+    unsigned char* mask;    // optional inlier mask [n]
+};
+
+struct PnpResult {
+    double R[9];
+    double t[3];
+    int n_inliers;          // -1 on failure (recognition.py:215,219)
+    int iters;
+    int best_iter;
+    int ok;
+};
+
+hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_problems, int iterations,
+                             double reproj_err, double confidence, int min_points, hipStream_t s);
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Pipeline {
+    DevBuf det, s1, cand, probs, results, poses, x1, y1, x2, y2, corr, images, mask, pred;
+    ~Pipeline();
+};
+
+}  // namespace p2p

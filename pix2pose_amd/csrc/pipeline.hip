@@ -1,4 +1,810 @@
-#include "model.h"
+// est_pose as a batched device pipeline (gfx950).  Replaces, for n detections at once,
+// pix2pose.est_pose (reference pix2pose_model/recognition.py:70-193), get_boxes (:28-69) and the
+// correspondence building of pnp_ransac (:195-213); the PnP-RANSAC solve itself is pnp.hip.
+//
+// Everything between the two generator passes stays on the device: no host round trip decides the
+// stage-2 geometry.  The many O(H*W) temporaries and the 16 skimage.resize calls per detection of
+// the reference collapse into per-pixel gathers: every resized map is evaluated on the fly from
+// the 128x128 network output with skimage's bilinear rule (half-pixel centres,
+// floor/ceil taps, 'reflect' or 'constant'+cval borders, no anti-aliasing), in float64 like the
+// reference, with FMA contraction off so thresholds (>0.9, <th, uint8 truncation) see the same
+// values as the numpy formulation.
+#include "pipeline.h"
+
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#pragma clang fp contract(off)
+
 namespace p2p {
-void Ctx::free_pipeline() {}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return P2P_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return P2P_OK;
+    release();
+    const size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return P2P_ERR_HIP;
+    }
+    cap = want;
+    return P2P_OK;
 }
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+Pipeline::~Pipeline()
+{
+    for (DevBuf* b : {&det, &s1, &cand, &probs, &results, &poses, &x1, &y1, &x2, &y2, &corr, &images, &mask, &pred}) b->release();
+}
+void Ctx::free_pipeline()
+{
+    delete pipe;
+    pipe = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry (host + device): recognition.py:28-69
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline Boxes get_boxes(const double bbox[4], int v_max, int u_max, double box_size, bool has_ct,
+                                           int ct_v, int ct_u, double max_w)
+{
+    if (!has_ct) {
+        ct_v = (int)((bbox[0] + bbox[2]) / 2);
+        ct_u = (int)((bbox[1] + bbox[3]) / 2);
+    }
+    const double width = bbox[3] - bbox[1], height = bbox[2] - bbox[0];
+    const double wa = width * box_size, wb = height * box_size;
+    double w = wa > wb ? wa : wb;
+    if (max_w < w) w = max_w;
+    const int half = (int)(w / 2);
+    Boxes b;
+    b.v1_ori = ct_v - half; b.v2_ori = ct_v + half;
+    b.u1_ori = ct_u - half; b.u2_ori = ct_u + half;
+    b.v1 = b.v1_ori; b.v2 = b.v2_ori; b.u1 = b.u1_ori; b.u2 = b.u2_ori;
+    int sv0 = 0, su0 = 0, sv1 = 0, su1 = 0;
+    if (b.v1_ori < 0) { sv0 = -b.v1_ori; b.v1 = 0; }
+    if (b.v2_ori > v_max) { sv1 = -(b.v2_ori - v_max); b.v2 = v_max; }
+    if (b.u1_ori < 0) { su0 = -b.u1_ori; b.u1 = 0; }
+    if (b.u2_ori > u_max) { su1 = -(b.u2_ori - u_max); b.u2 = u_max; }
+    b.vv1 = sv0; b.vv2 = sv1 + (b.v2_ori - b.v1_ori);
+    b.uu1 = su0; b.uu2 = su1 + (b.u2_ori - b.u1_ori);
+    return b;
+}
+
+// crop usable?  (recognition.py:78-79 / :117-119; boxes the reference would crash on -- entirely
+// outside the frame, where numpy's negative slice indices wrap -- are rejected as well)
+__host__ __device__ inline bool boxes_ok(const Boxes& b, int H, int W)
+{
+    const int side_v = b.v2_ori - b.v1_ori, side_u = b.u2_ori - b.u1_ori;
+    if (side_v < 5 || side_u < 5) return false;
+    if (b.v2 - b.v1 < 5 || b.u2 - b.u1 < 5) return false;
+    if (b.v2 <= 0 || b.u2 <= 0 || b.v1 >= H || b.u1 >= W) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// skimage-style bilinear sampling helpers
+// ------------------------------------------------------------------------------------------
+struct Tap {
+    int i0, i1;
+    double d;
+};
+
+__device__ inline Tap axis_tap(int o, int n_in, int n_out)
+{
+    const double s = (double)n_in / (double)n_out;
+    const double src = (double)o * s + (0.5 * s - 0.5);
+    const double lo = floor(src);
+    Tap t;
+    t.i0 = (int)lo;
+    t.i1 = (int)ceil(src);
+    t.d = src - lo;
+    return t;
+}
+
+__device__ inline int reflect_idx(int i, int n)   // numpy-pad 'reflect' (edge sample not repeated)
+{
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - i : i;
+}
+
+__device__ inline double lerp2(double tl, double tr, double bl, double br, double dr, double dc)
+{
+    const double top = (1 - dc) * tl + dc * tr;
+    const double bot = (1 - dc) * bl + dc * br;
+    return (1 - dr) * top + dr * bot;
+}
+
+// (pixel - 128) / 128 of frame pixel (y, x), channel ch
+__device__ inline double frame_px(const DetInfo& D, int y, int x, int ch)
+{
+    const size_t o = ((size_t)y * D.W + x) * 3 + ch;
+    const double p = D.img_f32 ? (double)reinterpret_cast<const float*>(D.img)[o]
+                               : (double)reinterpret_cast<const unsigned char*>(D.img)[o];
+    return (p - 128.0) / 128.0;
+}
+
+__device__ inline bool non_gray_at(const float* y4)   // np.linalg.norm(decode, axis=2) > 0.3 in float32
+{
+    const float s = (y4[0] * y4[0] + y4[1] * y4[1]) + y4[2] * y4[2];
+    return sqrtf(s) > 0.3f;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: stage-1 network inputs  (recognition.py:75-82)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stage1_input_kernel(const DetInfo* __restrict__ dets, float* __restrict__ x1)
+{
+    const int d = blockIdx.x >> 6;
+    const int pix = ((blockIdx.x & 63) << 8) | threadIdx.x;
+    const int oy = pix >> 7, ox = pix & 127;
+    const DetInfo& D = dets[d];
+    float* out = x1 + ((size_t)d * 16384 + pix) * 3;
+    if (!D.ok1) { out[0] = out[1] = out[2] = 0.f; return; }
+    const Boxes& b = D.b1;
+    const int S = b.v2_ori - b.v1_ori, Sw = b.u2_ori - b.u1_ori;
+    const Tap tr = axis_tap(oy, S, 128), tc = axis_tap(ox, Sw, 128);
+    const int r[2] = {reflect_idx(tr.i0, S), reflect_idx(tr.i1, S)};
+    const int c[2] = {reflect_idx(tc.i0, Sw), reflect_idx(tc.i1, Sw)};
+    for (int ch = 0; ch < 3; ++ch) {
+        double v[2][2];
+        for (int a = 0; a < 2; ++a)
+            for (int e = 0; e < 2; ++e) {
+                const bool in = r[a] >= b.vv1 && r[a] < b.vv2 && c[e] >= b.uu1 && c[e] < b.uu2;
+                v[a][e] = in ? frame_px(D, b.v1 + r[a] - b.vv1, b.u1 + c[e] - b.uu1, ch) : 0.0;
+            }
+        out[ch] = (float)lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: stage-1 reductions + stage-2 geometry  (recognition.py:89-110)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stage1_stats_kernel(const DetInfo* __restrict__ dets, const float* __restrict__ y1,
+                                                           Stage1* __restrict__ s1)
+{
+    __shared__ int s_n, s_minv, s_minu, s_maxv, s_maxu, s_sv, s_su;
+    __shared__ int s_keep[MAX_TH];
+    const int d = blockIdx.x, tid = threadIdx.x;
+    const DetInfo& D = dets[d];
+    if (tid == 0) { s_n = 0; s_minv = s_minu = 1 << 30; s_maxv = s_maxu = -1; s_sv = s_su = 0; }
+    if (tid < MAX_TH) s_keep[tid] = 0;
+    __syncthreads();
+    int n = 0, minv = 1 << 30, minu = 1 << 30, maxv = -1, maxu = -1, sv = 0, su = 0;
+    int keep[MAX_TH];
+#pragma unroll
+    for (int k = 0; k < MAX_TH; ++k) keep[k] = 0;
+    const float* y = y1 + (size_t)d * 16384 * 4;
+    for (int p = tid; p < 16384; p += 256) {
+        const float4 q = reinterpret_cast<const float4*>(y)[p];
+        const float v4[4] = {q.x, q.y, q.z, q.w};
+        if (!non_gray_at(v4)) continue;
+        const int v = p >> 7, u = p & 127;
+        ++n; sv += v; su += u;
+        minv = min(minv, v); maxv = max(maxv, v); minu = min(minu, u); maxu = max(maxu, u);
+#pragma unroll
+        for (int k = 0; k < MAX_TH; ++k)
+            if (k < D.n_th && q.w < D.th_o[k]) ++keep[k];
+    }
+    atomicAdd(&s_n, n); atomicAdd(&s_sv, sv); atomicAdd(&s_su, su);
+    atomicMin(&s_minv, minv); atomicMin(&s_minu, minu); atomicMax(&s_maxv, maxv); atomicMax(&s_maxu, maxu);
+#pragma unroll
+    for (int k = 0; k < MAX_TH; ++k)
+        if (keep[k]) atomicAdd(&s_keep[k], keep[k]);
+    __syncthreads();
+    if (tid != 0) return;
+    Stage1 o;
+    memset(&o, 0, sizeof(o));
+    o.n_init_mask = s_n;
+    o.bb[0] = s_minv; o.bb[1] = s_minu; o.bb[2] = s_maxv; o.bb[3] = s_maxu;
+    o.sum_v = s_sv; o.sum_u = s_su;
+    o.b2 = D.b1;
+    bool any = false;
+    if (D.ok1 && s_n > 0) {
+        const Boxes& b = D.b1;
+        const double sy = (double)(b.v2_ori - b.v1_ori) / 128, sx = (double)(b.u2_ori - b.u1_ori) / 128;
+        const double bb[4] = {s_minv * sy, s_minu * sx, s_maxv * sy, s_maxu * sx};          // :101-102
+        const double mean_u = (double)s_su / (double)s_n, mean_v = (double)s_sv / (double)s_n;
+        const int cx_m = (int)((mean_u - (127.0 / 2)) + D.cx_o);                            // :108
+        const int cy_m = (int)((mean_v - (127.0 / 2)) + D.cy_o);                            // :109
+        const Boxes b2 = get_boxes(bb, D.H, D.W, D.box_size, true, cy_m, cx_m, (double)(b.v2_ori - b.v1_ori));   // :110
+        const bool geo_ok = boxes_ok(b2, D.H, D.W);
+        for (int k = 0; k < D.n_th; ++k) {
+            o.keep_cnt[k] = s_keep[k];
+            o.valid2[k] = (s_keep[k] >= 10 && geo_ok) ? 1 : 0;                             // :96-97, :117-119
+            if (o.valid2[k]) { any = true; ++o.n_cand; }
+        }
+        if (any) o.b2 = b2;
+    }
+    s1[d] = o;
+}
+
+// resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square
+__device__ inline bool keep_ori_at(const float* y1d, float th, int r, int c, int S, int Sw)
+{
+    const Tap tr = axis_tap(r, 128, S), tc = axis_tap(c, 128, Sw);
+    double v[2][2];
+    const int ri[2] = {tr.i0, tr.i1}, cj[2] = {tc.i0, tc.i1};
+    for (int a = 0; a < 2; ++a)
+        for (int e = 0; e < 2; ++e) {
+            double k = 0.0;
+            if (ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
+                const float* q = y1d + ((size_t)ri[a] * 128 + cj[e]) * 4;
+                k = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
+            }
+            v[a][e] = k;
+        }
+    return lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d) > 0.9;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: stage-2 network inputs  (recognition.py:103-121)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
+                                                           const float* __restrict__ y1, int K, float* __restrict__ x2)
+{
+    const int cand = blockIdx.x >> 6;
+    const int d = cand / K, slot = cand - d * K;
+    const int pix = ((blockIdx.x & 63) << 8) | threadIdx.x;
+    const int oy = pix >> 7, ox = pix & 127;
+    const DetInfo& D = dets[d];
+    const Stage1& S = s1[d];
+    float* out = x2 + ((size_t)cand * 16384 + pix) * 3;
+    if (slot >= D.n_th || !S.valid2[slot]) { out[0] = out[1] = out[2] = 0.f; return; }
+    const Boxes& b1 = D.b1;
+    const Boxes& b = S.b2;
+    const int S1 = b1.v2_ori - b1.v1_ori, S1w = b1.u2_ori - b1.u1_ori;
+    const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
+    const Tap tr = axis_tap(oy, S2, 128), tc = axis_tap(ox, S2w, 128);
+    const int r[2] = {reflect_idx(tr.i0, S2), reflect_idx(tr.i1, S2)};
+    const int c[2] = {reflect_idx(tc.i0, S2w), reflect_idx(tc.i1, S2w)};
+    const float* y1d = y1 + (size_t)d * 16384 * 4;
+    const float th = D.th_o[slot];
+    bool fg[2][2];
+    int fy[2], fx[2];
+    for (int a = 0; a < 2; ++a) {
+        fy[a] = b.v1 + r[a] - b.vv1;
+        fx[a] = b.u1 + c[a] - b.uu1;
+    }
+    for (int a = 0; a < 2; ++a)
+        for (int e = 0; e < 2; ++e) {
+            const bool in = r[a] >= b.vv1 && r[a] < b.vv2 && c[e] >= b.uu1 && c[e] < b.uu2;
+            bool f = false;
+            if (in) {
+                const int y = fy[a], x = fx[e];
+                // bg_full: True outside the stage-1 clipped crop, ~keep_ori inside   (:105-106)
+                if (y >= b1.v1 && y < b1.v2 && x >= b1.u1 && x < b1.u2) f = keep_ori_at(y1d, th, y - b1.v1_ori, x - b1.u1_ori, S1, S1w);
+            }
+            fg[a][e] = f;
+        }
+    for (int ch = 0; ch < 3; ++ch) {
+        double v[2][2];
+        for (int a = 0; a < 2; ++a)
+            for (int e = 0; e < 2; ++e) v[a][e] = fg[a][e] ? frame_px(D, fy[a], fx[e], ch) : 0.0;
+        out[ch] = (float)lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-pixel evaluation of one candidate at crop resolution  (recognition.py:134-154, 196-204)
+// ------------------------------------------------------------------------------------------
+struct CandPixel {
+    bool non_gray;
+    bool valid;
+    unsigned char q[3];
+};
+
+__device__ inline CandPixel cand_pixel(const float* y2c, int r, int c, int S2, int S2w, double th_i)
+{
+    const Tap tr = axis_tap(r, 128, S2), tc = axis_tap(c, 128, S2w);
+    const int ri[2] = {tr.i0, tr.i1}, cj[2] = {tc.i0, tc.i1};
+    double prob[2][2], ng[2][2], pred[3][2][2];
+    for (int a = 0; a < 2; ++a)
+        for (int e = 0; e < 2; ++e) {
+            if (ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
+                const float* q = y2c + ((size_t)ri[a] * 128 + cj[e]) * 4;
+                const float s = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+                const bool gray = sqrtf(s) < 0.3f;                                  // :137
+                prob[a][e] = (double)q[3];
+                ng[a][e] = gray ? 0.0 : 1.0;
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float dq = gray ? 0.f : q[ch];                            // :139
+                    float ip = (dq + 1.0f) / 2.0f;                                  // :141 (float32)
+                    ip = ip > 1.f ? 1.f : (ip < 0.f ? 0.f : ip);                    // :142-143
+                    pred[ch][a][e] = (double)ip;
+                }
+            } else {          // resize(..., mode='constant', cval=1 / 0.5 / 0)       :134,144,146
+                prob[a][e] = 1.0; ng[a][e] = 0.0;
+                pred[0][a][e] = pred[1][a][e] = pred[2][a][e] = 0.5;
+            }
+        }
+    CandPixel o;
+    o.non_gray = lerp2(ng[0][0], ng[0][1], ng[1][0], ng[1][1], tr.d, tc.d) > 0.9;
+    const double pr = lerp2(prob[0][0], prob[0][1], prob[1][0], prob[1][1], tr.d, tc.d);
+    o.valid = o.non_gray && pr < th_i;                                              // :203-204
+    for (int ch = 0; ch < 3; ++ch) {
+        const double v = lerp2(pred[ch][0][0], pred[ch][0][1], pred[ch][1][0], pred[ch][1][1], tr.d, tc.d) * 255;
+        o.q[ch] = (unsigned char)(int)v;                                            // uint8 canvas: truncation (:152-154)
+    }
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: correspondences per candidate, compacted in row-major order  (recognition.py:134-151,196-213)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cand_corr_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
+                                                        const float* __restrict__ y2, int K, float* __restrict__ corr,
+                                                        CandStat* __restrict__ cstat, PnpProblem* __restrict__ probs)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_ng;
+    __shared__ unsigned long long s_sv, s_su;
+    const int cand = blockIdx.x;
+    const int d = cand / K, slot = cand - d * K;
+    const DetInfo& D = dets[d];
+    const Stage1& S = s1[d];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* pts = corr + D.corr_off + (size_t)slot * 5 * D.corr_cap;
+    if (tid == 0) { s_ng = 0; s_sv = 0; s_su = 0; }
+    __syncthreads();
+    int total = 0;
+    if (slot < D.n_th && S.valid2[slot]) {
+        const Boxes& b = S.b2;
+        const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
+        const int h = b.v2 - b.v1, w = b.u2 - b.u1;
+        const int npx = h * w;
+        const float* y2c = y2 + (size_t)cand * 16384 * 4;
+        int ng_cnt = 0;
+        unsigned long long sv = 0, su = 0;
+        float* PX = pts; float* PY = pts + D.corr_cap; float* PZ = pts + 2 * (size_t)D.corr_cap;
+        float* PU = pts + 3 * (size_t)D.corr_cap; float* PV = pts + 4 * (size_t)D.corr_cap;
+        for (int base = 0; base < npx; base += 256) {
+            const int p = base + tid;
+            bool valid = false;
+            CandPixel cp;
+            int rr = 0, cc = 0;
+            if (p < npx) {
+                rr = p / w; cc = p - rr * w;
+                cp = cand_pixel(y2c, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+                valid = cp.valid;
+                if (cp.non_gray) { ++ng_cnt; sv += (unsigned)(b.v1 + rr); su += (unsigned)(b.u1 + cc); }
+            }
+            const unsigned long long bal = __ballot(valid);
+            const int before = __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (lane == 0) s_wave[wave] = __popcll(bal);
+            __syncthreads();
+            int off = total;
+            for (int k = 0; k < wave; ++k) off += s_wave[k];
+            const int chunk = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            if (valid) {
+                const int o = off + before;       // o < corr_cap: the clipped stage-2 region fits the stage-1 square
+                for (int ch = 0; ch < 3; ++ch) {
+                    double x = (double)cp.q[ch];
+                    x = x / 255;                                                   // :198
+                    x = x * 2 - 1;                                                 // :199
+                    x = x * D.obj_scale[ch] + D.obj_ct[ch];                        // :200-202
+                    (ch == 0 ? PX : ch == 1 ? PY : PZ)[o] = (float)x;             // solvePnPRansac stores float32
+                }
+                PU[o] = (float)(b.u1 + cc);                                        // :207-209 (u, v) + (u1, v1)
+                PV[o] = (float)(b.v1 + rr);
+            }
+            total += chunk;
+            __syncthreads();
+        }
+        atomicAdd(&s_ng, ng_cnt);
+        atomicAdd(&s_sv, sv);
+        atomicAdd(&s_su, su);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        CandStat cs;
+        cs.n_non_gray = s_ng; cs.n_corr = total; cs.sum_v = (long long)s_sv; cs.sum_u = (long long)s_su;
+        cstat[cand] = cs;
+        PnpProblem pb;
+        pb.pts = pts; pb.cap = D.corr_cap;
+        // n_non_gray < 10 -> the reference skips the candidate before PnP (:149-150)
+        pb.n = (s_ng >= 10) ? total : 0;
+        for (int k = 0; k < 9; ++k) pb.K[k] = D.K[k];
+        pb.mask = nullptr;
+        probs[cand] = pb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K8: candidate selection  (recognition.py:130-131,158-178,189-193)
+// ------------------------------------------------------------------------------------------
+__global__ void select_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
+                              const CandStat* __restrict__ cstat, const PnpResult* __restrict__ res, int K, int n_det,
+                              p2p_pose* __restrict__ poses)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_det) return;
+    const DetInfo& D = dets[d];
+    const Stage1& S = s1[d];
+    p2p_pose o;
+    memset(&o, 0, sizeof(o));
+    o.R[0] = o.R[4] = o.R[8] = 1.0;
+    o.n_inliers = -1; o.best_slot = -1; o.frac_inlier = -1.0;
+    o.n_init_mask = S.n_init_mask;
+    o.bbox_t[0] = D.b1.v1; o.bbox_t[1] = D.b1.v2; o.bbox_t[2] = D.b1.u1; o.bbox_t[3] = D.b1.u2;
+    o.n_candidates = S.n_cand;
+    if (!D.ok1) { o.status = P2P_POSE_CROP_TOO_SMALL; poses[d] = o; return; }
+    if (S.n_cand == 0) { o.status = P2P_POSE_NO_CANDIDATE; poses[d] = o; return; }
+    // the reference returns the box of the LAST candidate iterated (:133, :193)
+    o.bbox_t[0] = S.b2.v1; o.bbox_t[1] = S.b2.v2; o.bbox_t[2] = S.b2.u1; o.bbox_t[3] = S.b2.u2;
+    int max_inlier = -1;
+    double min_dist = 9999999;
+    for (int slot = 0; slot < D.n_th; ++slot) {
+        if (!S.valid2[slot]) continue;
+        const CandStat& cs = cstat[d * K + slot];
+        if (cs.n_non_gray < 10) continue;                                           // :149-150
+        const PnpResult& r = res[d * K + slot];
+        const double ct_v = (double)cs.sum_v / (double)cs.n_non_gray, ct_u = (double)cs.sum_u / (double)cs.n_non_gray;
+        double dist;
+        if (r.t[2] == 0) dist = 99999;                                             // :163-164
+        else {
+            const double pu = D.K[0] * r.t[0] / r.t[2] + D.K[2];
+            const double pv = D.K[4] * r.t[1] / r.t[2] + D.K[5];
+            dist = ((pv - ct_v) * (pv - ct_v) + (pu - ct_u) * (pu - ct_u)) / ((double)r.n_inliers + 1E-6);   // :168
+        }
+        if (dist < min_dist) {                                                      // :170-174
+            for (int k = 0; k < 9; ++k) o.R[k] = r.R[k];
+            for (int k = 0; k < 3; ++k) o.t[k] = r.t[k];
+            max_inlier = r.n_inliers;
+            min_dist = dist;
+            o.best_slot = slot;
+            o.ransac_iters = r.iters;
+        }
+    }
+    o.n_inliers = max_inlier;
+    if (max_inlier == -1) {                                                         // :189-191
+        o.status = P2P_POSE_PNP_FAILED;
+        o.R[0] = o.R[4] = o.R[8] = 1.0; o.R[1] = o.R[2] = o.R[3] = o.R[5] = o.R[6] = o.R[7] = 0.0;
+        o.t[0] = o.t[1] = o.t[2] = 0.0;
+        o.best_slot = -1;
+    } else {
+        o.status = P2P_POSE_OK;
+        o.frac_inlier = (double)max_inlier / (double)S.n_init_mask;                 // :193
+    }
+    poses[d] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// K9 (optional outputs): valid_mask_full and img_pred_f of the selected candidate (:175-177)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
+                                                          const p2p_pose* __restrict__ poses, const float* __restrict__ y2,
+                                                          int K, unsigned char* __restrict__ mask, long long mask_stride,
+                                                          unsigned char* __restrict__ pred, long long pred_stride)
+{
+    const int d = blockIdx.y;
+    const p2p_pose& P = poses[d];
+    if (P.status != P2P_POSE_OK) return;
+    const DetInfo& D = dets[d];
+    const Boxes& b = s1[d].b2;
+    const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
+    const int h = b.v2 - b.v1, w = b.u2 - b.u1;
+    const float* y2c = y2 + (size_t)(d * K + P.best_slot) * 16384 * 4;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
+        const int rr = p / w, cc = p - rr * w;
+        const CandPixel cp = cand_pixel(y2c, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+        if (mask) mask[(size_t)d * mask_stride + (size_t)(b.v1 + rr) * D.W + (b.u1 + cc)] = cp.valid ? 1 : 0;
+        if (pred && (long long)(p + 1) * 3 <= pred_stride) {
+            unsigned char* q = pred + (size_t)d * pred_stride + (size_t)p * 3;
+            q[0] = cp.q[0]; q[1] = cp.q[1]; q[2] = cp.q[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------
+static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
+                        const p2p_detection* dets, int n, p2p_pose* poses, const p2p_est_pose_opts& opt)
+{
+    int rc;
+    hipStream_t st = X.stream;
+    if (!X.pipe) X.pipe = new Pipeline();
+    Pipeline& P = *X.pipe;
+    if ((rc = X.ensure_workspace())) return rc;
+
+    // -- validate, order detections by object (weights locality; one generator pass per group)
+    int K = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        if (!objects[o].model || objects[o].n_outlier_th < 1 || objects[o].n_outlier_th > MAX_TH) {
+            set_error("object %d: model missing or n_outlier_th out of [1,%d]", o, MAX_TH);
+            return P2P_ERR_INVALID_ARG;
+        }
+        K = std::max(K, objects[o].n_outlier_th);
+    }
+    std::vector<int> perm(n);
+    std::iota(perm.begin(), perm.end(), 0);
+    for (int i = 0; i < n; ++i) {
+        if (dets[i].object < 0 || dets[i].object >= n_obj || dets[i].image < 0 || dets[i].image >= n_img) {
+            set_error("detection %d references object %d / image %d out of range", i, dets[i].object, dets[i].image);
+            return P2P_ERR_INVALID_ARG;
+        }
+    }
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return dets[a].object < dets[b].object; });
+    bool identity = true;
+    for (int i = 0; i < n; ++i) identity = identity && perm[i] == i;
+
+    // -- frames
+    std::vector<const void*> img_dev(n_img, nullptr);
+    {
+        size_t need = 0;
+        for (int i = 0; i < n_img; ++i) {
+            if (!images[i].data || images[i].height <= 0 || images[i].width <= 0) { set_error("image %d is empty", i); return P2P_ERR_INVALID_ARG; }
+            if (images[i].mem == P2P_MEM_HOST) need += ((size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1) + 255) / 256 * 256;
+        }
+        if ((rc = P.images.reserve(need))) return rc;
+        size_t off = 0;
+        for (int i = 0; i < n_img; ++i) {
+            const size_t bytes = (size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1);
+            if (images[i].mem == P2P_MEM_HOST) {
+                HIP_TRY(hipMemcpyAsync(P.images.as<char>() + off, images[i].data, bytes, hipMemcpyHostToDevice, st));
+                img_dev[i] = P.images.as<char>() + off;
+                off += (bytes + 255) / 256 * 256;
+            } else
+                img_dev[i] = images[i].data;
+        }
+    }
+
+    // -- per-detection constants + stage-1 geometry (recognition.py:71-79)
+    std::vector<DetInfo> hd(n);
+    long long corr_total = 0;
+    for (int i = 0; i < n; ++i) {
+        const p2p_detection& dt = dets[perm[i]];
+        const p2p_object& ob = objects[dt.object];
+        const p2p_image& im = images[dt.image];
+        DetInfo& D = hd[i];
+        memset(&D, 0, sizeof(D));
+        D.img = img_dev[dt.image];
+        D.H = im.height; D.W = im.width; D.img_f32 = im.dtype == P2P_IMG_F32;
+        D.obj = dt.object;
+        D.n_th = ob.n_outlier_th;
+        for (int k = 0; k < D.n_th; ++k) D.th_o[k] = (float)ob.outlier_th[k];
+        D.th_i = ob.inlier_th;
+        D.box_size = ob.box_size > 0 ? ob.box_size : 1.5;
+        D.cx_o = (dt.bbox[3] + dt.bbox[1]) / 2.0;
+        D.cy_o = (dt.bbox[2] + dt.bbox[0]) / 2.0;
+        for (int k = 0; k < 9; ++k) D.K[k] = dt.camK[k];
+        for (int k = 0; k < 3; ++k) { D.obj_scale[k] = ob.obj_scale[k]; D.obj_ct[k] = ob.obj_ct[k]; }
+        const double bb[4] = {(double)dt.bbox[0], (double)dt.bbox[1], (double)dt.bbox[2], (double)dt.bbox[3]};
+        D.b1 = get_boxes(bb, D.H, D.W, D.box_size, false, 0, 0, 9999);
+        D.ok1 = boxes_ok(D.b1, D.H, D.W) ? 1 : 0;
+        const long long side = std::max(D.b1.v2_ori - D.b1.v1_ori, 0);
+        D.corr_cap = D.ok1 ? (int)(side * side) : 0;
+        D.corr_off = corr_total;
+        corr_total += (long long)D.corr_cap * 5 * K;
+    }
+    if ((rc = P.det.reserve(sizeof(DetInfo) * n))) return rc;
+    if ((rc = P.s1.reserve(sizeof(Stage1) * n))) return rc;
+    if ((rc = P.cand.reserve(sizeof(CandStat) * n * K))) return rc;
+    if ((rc = P.probs.reserve(sizeof(PnpProblem) * n * K))) return rc;
+    if ((rc = P.results.reserve(sizeof(PnpResult) * n * K))) return rc;
+    if ((rc = P.poses.reserve(sizeof(p2p_pose) * n))) return rc;
+    if ((rc = P.x1.reserve(sizeof(float) * 16384 * 3 * (size_t)n))) return rc;
+    if ((rc = P.y1.reserve(sizeof(float) * 16384 * 4 * (size_t)n))) return rc;
+    if ((rc = P.x2.reserve(sizeof(float) * 16384 * 3 * (size_t)n * K))) return rc;
+    if ((rc = P.y2.reserve(sizeof(float) * 16384 * 4 * (size_t)n * K))) return rc;
+    if ((rc = P.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
+    HIP_TRY(hipMemcpyAsync(P.det.p, hd.data(), sizeof(DetInfo) * n, hipMemcpyHostToDevice, st));
+
+    const DetInfo* d_det = P.det.as<DetInfo>();
+    Stage1* d_s1 = P.s1.as<Stage1>();
+    float *x1 = P.x1.as<float>(), *y1 = P.y1.as<float>(), *x2 = P.x2.as<float>(), *y2 = P.y2.as<float>();
+
+    // object groups (contiguous in the sorted order)
+    struct Group { int obj, begin, end; };
+    std::vector<Group> groups;
+    for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && hd[j].obj == hd[i].obj) ++j;
+        groups.push_back({hd[i].obj, i, j});
+        i = j;
+    }
+    auto inject = [&](const float* src, float* dst, size_t per_det) -> int {
+        if (identity) {
+            HIP_TRY(hipMemcpyAsync(dst, src, per_det * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        } else
+            for (int i = 0; i < n; ++i)
+                HIP_TRY(hipMemcpyAsync(dst + per_det * i, src + per_det * perm[i], per_det * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return P2P_OK;
+    };
+
+    // -- stage 1
+    hipLaunchKernelGGL(stage1_input_kernel, dim3(n * 64), dim3(256), 0, st, d_det, x1);
+    HIP_TRY(hipGetLastError());
+    for (const Group& g : groups) {
+        const Model& M = *reinterpret_cast<const Model*>(objects[g.obj].model);
+        if ((rc = forward_async(X, M, x1 + (size_t)g.begin * 16384 * 3, g.end - g.begin, y1 + (size_t)g.begin * 16384 * 4))) return rc;
+    }
+    if (opt.inject1 && (rc = inject(opt.inject1, y1, 16384 * 4))) return rc;
+    hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(256), 0, st, d_det, y1, d_s1);
+    HIP_TRY(hipGetLastError());
+
+    // -- stage 2
+    hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, x2);
+    HIP_TRY(hipGetLastError());
+    for (const Group& g : groups) {
+        const Model& M = *reinterpret_cast<const Model*>(objects[g.obj].model);
+        if ((rc = forward_async(X, M, x2 + (size_t)g.begin * K * 16384 * 3, (g.end - g.begin) * K, y2 + (size_t)g.begin * K * 16384 * 4))) return rc;
+    }
+    if (opt.inject2) {
+        if (opt.inject_slots != K) { set_error("inject_slots (%d) must equal the largest n_outlier_th (%d)", opt.inject_slots, K); return P2P_ERR_INVALID_ARG; }
+        if ((rc = inject(opt.inject2, y2, (size_t)K * 16384 * 4))) return rc;
+    }
+
+    // -- correspondences, PnP-RANSAC, selection
+    hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y2, K, P.corr.as<float>(),
+                       P.cand.as<CandStat>(), P.probs.as<PnpProblem>());
+    HIP_TRY(hipGetLastError());
+    const int iters = opt.ransac_iterations > 0 ? opt.ransac_iterations : 100;
+    const double rerr = opt.reprojection_error > 0 ? opt.reprojection_error : 5.0;
+    const double conf = opt.confidence > 0 ? opt.confidence : 0.99;
+    HIP_TRY(launch_pnp_ransac(P.probs.as<PnpProblem>(), P.results.as<PnpResult>(), n * K, iters, rerr, conf, 6, st));
+    hipLaunchKernelGGL(select_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_det, d_s1, P.cand.as<CandStat>(),
+                       P.results.as<PnpResult>(), K, n, P.poses.as<p2p_pose>());
+    HIP_TRY(hipGetLastError());
+
+    std::vector<p2p_pose> hp(n);
+    HIP_TRY(hipMemcpyAsync(hp.data(), P.poses.p, sizeof(p2p_pose) * n, hipMemcpyDeviceToHost, st));
+
+    // -- optional outputs
+    std::vector<unsigned char> hmask, hpred;
+    if (opt.valid_mask || opt.img_pred) {
+        if (opt.valid_mask) {
+            if ((rc = P.mask.reserve((size_t)opt.mask_stride * n))) return rc;
+            HIP_TRY(hipMemsetAsync(P.mask.p, 0, (size_t)opt.mask_stride * n, st));
+        }
+        if (opt.img_pred) {
+            if ((rc = P.pred.reserve((size_t)opt.pred_stride * n))) return rc;
+            HIP_TRY(hipMemsetAsync(P.pred.p, 0, (size_t)opt.pred_stride * n, st));
+        }
+        for (int i = 0; i < n; ++i)
+            if (opt.valid_mask && (long long)hd[i].H * hd[i].W > opt.mask_stride) { set_error("mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
+        hipLaunchKernelGGL(render_best_kernel, dim3(64, n), dim3(256), 0, st, d_det, d_s1, P.poses.as<p2p_pose>(), y2, K,
+                           opt.valid_mask ? P.mask.as<unsigned char>() : nullptr, (long long)opt.mask_stride,
+                           opt.img_pred ? P.pred.as<unsigned char>() : nullptr, (long long)opt.pred_stride);
+        HIP_TRY(hipGetLastError());
+        if (opt.valid_mask) { hmask.resize((size_t)opt.mask_stride * n); HIP_TRY(hipMemcpyAsync(hmask.data(), P.mask.p, hmask.size(), hipMemcpyDeviceToHost, st)); }
+        if (opt.img_pred) { hpred.resize((size_t)opt.pred_stride * n); HIP_TRY(hipMemcpyAsync(hpred.data(), P.pred.p, hpred.size(), hipMemcpyDeviceToHost, st)); }
+    }
+    std::vector<float> hx1, hx2;
+    std::vector<Stage1> hs1;
+    std::vector<CandStat> hcs;
+    std::vector<PnpResult> hres;
+    if (opt.dbg_x1) { hx1.resize((size_t)n * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx1.data(), x1, hx1.size() * 4, hipMemcpyDeviceToHost, st)); }
+    if (opt.dbg_x2) { hx2.resize((size_t)n * K * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx2.data(), x2, hx2.size() * 4, hipMemcpyDeviceToHost, st)); }
+    if (opt.dbg_boxes2 || opt.dbg_cand) {
+        hs1.resize(n); hcs.resize((size_t)n * K); hres.resize((size_t)n * K);
+        HIP_TRY(hipMemcpyAsync(hs1.data(), d_s1, sizeof(Stage1) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hcs.data(), P.cand.p, sizeof(CandStat) * n * K, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hres.data(), P.results.p, sizeof(PnpResult) * n * K, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+
+    for (int i = 0; i < n; ++i) {
+        const int o = perm[i];
+        poses[o] = hp[i];
+        if (opt.valid_mask) memcpy(opt.valid_mask + (size_t)o * opt.mask_stride, hmask.data() + (size_t)i * opt.mask_stride, opt.mask_stride);
+        if (opt.img_pred) memcpy(opt.img_pred + (size_t)o * opt.pred_stride, hpred.data() + (size_t)i * opt.pred_stride, opt.pred_stride);
+        if (opt.dbg_x1) memcpy(opt.dbg_x1 + (size_t)o * 16384 * 3, hx1.data() + (size_t)i * 16384 * 3, 16384 * 3 * 4);
+        if (opt.dbg_x2) memcpy(opt.dbg_x2 + (size_t)o * K * 16384 * 3, hx2.data() + (size_t)i * K * 16384 * 3, (size_t)K * 16384 * 3 * 4);
+        if (opt.dbg_boxes2) memcpy(opt.dbg_boxes2 + (size_t)o * 12, &hs1[i].b2, sizeof(Boxes));
+        if (opt.dbg_cand)
+            for (int k = 0; k < K; ++k) {
+                int* c = opt.dbg_cand + ((size_t)o * K + k) * 4;
+                c[0] = hs1[i].valid2[k]; c[1] = hcs[(size_t)i * K + k].n_non_gray; c[2] = hcs[(size_t)i * K + k].n_corr;
+                c[3] = hres[(size_t)i * K + k].n_inliers;
+            }
+    }
+    return P2P_OK;
+}
+
+}  // namespace p2p
+
+using namespace p2p;
+
+extern "C" {
+
+int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images, int n_images,
+                       const p2p_detection* dets, int n_dets, p2p_pose* poses, const p2p_est_pose_opts* opts)
+{
+    if (!ctx || n_dets < 0 || (n_dets > 0 && (!objects || !images || !dets || !poses || n_objects <= 0 || n_images <= 0))) {
+        set_error("p2p_est_pose_batch: bad arguments");
+        return P2P_ERR_INVALID_ARG;
+    }
+    if (n_dets == 0) return P2P_OK;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    p2p_est_pose_opts o;
+    memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    return run_est_pose(*c, objects, n_objects, images, n_images, dets, n_dets, poses, o);
+}
+
+int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts, const double* img_pts, const int* offsets,
+                         int n_problems, int iterations, double reprojection_error, double confidence, double* R, double* t,
+                         int* info, int* ok, unsigned char* inlier_mask)
+{
+    if (!ctx || n_problems < 0 || (n_problems > 0 && (!camK || !obj_pts || !img_pts || !offsets || !R || !t || !info || !ok))) {
+        set_error("p2p_pnp_ransac_batch: bad arguments");
+        return P2P_ERR_INVALID_ARG;
+    }
+    if (n_problems == 0) return P2P_OK;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int N = offsets[n_problems];
+    // OpenCV converts the point sets to float32 before RANSAC; store them SoA per problem
+    std::vector<float> pts((size_t)std::max(N, 1) * 5);
+    std::vector<PnpProblem> pb(n_problems);
+    DevBuf dpts, dprob, dres, dmask;
+    int rc;
+    if ((rc = dpts.reserve(pts.size() * 4)) || (rc = dprob.reserve(sizeof(PnpProblem) * n_problems)) ||
+        (rc = dres.reserve(sizeof(PnpResult) * n_problems)) || (rc = dmask.reserve((size_t)std::max(N, 1)))) {
+        dpts.release(); dprob.release(); dres.release(); dmask.release();
+        return rc;
+    }
+    for (int p = 0; p < n_problems; ++p) {
+        const int o = offsets[p], n = offsets[p + 1] - o;
+        float* base = pts.data() + (size_t)o * 5;
+        for (int i = 0; i < n; ++i) {
+            base[i] = (float)obj_pts[3 * (size_t)(o + i)];
+            base[n + i] = (float)obj_pts[3 * (size_t)(o + i) + 1];
+            base[2 * n + i] = (float)obj_pts[3 * (size_t)(o + i) + 2];
+            base[3 * n + i] = (float)img_pts[2 * (size_t)(o + i)];
+            base[4 * n + i] = (float)img_pts[2 * (size_t)(o + i) + 1];
+        }
+        pb[p].pts = dpts.as<float>() + (size_t)o * 5;
+        pb[p].cap = n; pb[p].n = n;
+        for (int k = 0; k < 9; ++k) pb[p].K[k] = camK[9 * p + k];
+        pb[p].mask = inlier_mask ? dmask.as<unsigned char>() + o : nullptr;
+    }
+    auto cleanup = [&]() { dpts.release(); dprob.release(); dres.release(); dmask.release(); };
+    hipError_t e;
+    std::vector<PnpResult> res(n_problems);
+    if ((e = hipMemcpyAsync(dpts.p, pts.data(), pts.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(dprob.p, pb.data(), sizeof(PnpProblem) * n_problems, hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemsetAsync(dmask.p, 0, (size_t)std::max(N, 1), st)) != hipSuccess ||
+        (e = launch_pnp_ransac(dprob.as<PnpProblem>(), dres.as<PnpResult>(), n_problems, iterations > 0 ? iterations : 100,
+                               reprojection_error > 0 ? reprojection_error : 5.0, confidence > 0 ? confidence : 0.99, 5, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(res.data(), dres.p, sizeof(PnpResult) * n_problems, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (inlier_mask && (e = hipMemcpyAsync(inlier_mask, dmask.p, (size_t)N, hipMemcpyDeviceToHost, st)) != hipSuccess) ||
+        (e = hipStreamSynchronize(st)) != hipSuccess) {
+        set_error("p2p_pnp_ransac_batch: %s", hipGetErrorString(e));
+        cleanup();
+        return P2P_ERR_HIP;
+    }
+    for (int p = 0; p < n_problems; ++p) {
+        for (int k = 0; k < 9; ++k) R[9 * p + k] = res[p].R[k];
+        for (int k = 0; k < 3; ++k) t[3 * p + k] = res[p].t[k];
+        info[3 * p] = res[p].n_inliers; info[3 * p + 1] = res[p].iters; info[3 * p + 2] = res[p].best_iter;
+        ok[p] = res[p].ok;
+    }
+    cleanup();
+    return P2P_OK;
+}
+
+}  // extern "C"

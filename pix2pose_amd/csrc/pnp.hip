@@ -1,0 +1,885 @@
+// Batched EPnP + RANSAC on gfx950: one workgroup per PnP problem (= one stage-2 candidate).
+//
+// Replaces, per candidate, the call
+//     cv2.solvePnPRansac(obj, img, camK, None, flags=SOLVEPNP_EPNP, reprojectionError=5,
+//                        iterationsCount=100)  + cv2.Rodrigues(rvec)
+// of the reference (pix2pose_model/recognition.py:216-223; OpenCV 3.4.2.17, requirements.txt:3).
+//
+// OpenCV's RANSAC is sequential but its sampling is not data dependent: the RNG is re-seeded with
+// (uint64)-1 on every call and each iteration draws five distinct indices, so all minimal sets are
+// known up front.  The kernel therefore
+//   1. replays the multiply-with-carry generator once (lane 0) into LDS,
+//   2. solves the 5-point EPnP hypotheses in parallel, one lane each, in fp64,
+//   3. scores hypotheses in OpenCV's order with every lane striding over the correspondences and
+//      an LDS reduction of the inlier count, applying the same "best so far" rule and the same
+//      adaptive iteration bound (so it stops where OpenCV stops and picks the hypothesis OpenCV
+//      picks),
+//   4. re-fits EPnP on the inlier set with workgroup-wide reductions (the 2n x 12 system is
+//      never formed: M^T M has only four distinct weighted Gram sums of the barycentric
+//      coordinates), then the same beta / Gauss-Newton / absolute-orientation steps.
+// All arithmetic that decides an inlier uses OpenCV's types (float32 point storage, float32
+// projected points and squared distance) with FMA contraction disabled.
+#include "pipeline.h"
+
+#pragma clang fp contract(off)
+
+namespace p2p {
+namespace pnp {
+
+constexpr double kDblEps = 2.220446049250313e-16;
+constexpr double kDblMin = 2.2250738585072014e-308;
+
+// ---------------------------------------------------------------- cv::RNG (multiply with carry)
+struct Rng {
+    unsigned long long state;
+    __device__ explicit Rng(unsigned long long s) : state(s ? s : 0xffffffffULL) {}
+    __device__ unsigned next()
+    {
+        state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// ---------------------------------------------------------------- one-sided Jacobi SVD
+// At: n rows of length m (the columns of the m x n matrix A).  On exit the rows are the left
+// singular vectors, W the singular values in descending order, Vt (optional, n x n) the right ones.
+__device__ void jacobi_svd(double* At, int m, int n, double* W, double* Vt)
+{
+    const double eps = kDblEps * 10;
+    const int max_iter = m > 30 ? m : 30;
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
+        W[i] = sd;
+        if (Vt) { for (int k = 0; k < n; k++) Vt[i * n + k] = 0; Vt[i * n + i] = 1; }
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                double *Ai = At + i * m, *Aj = At + j * m;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot(p, beta);
+                double c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    const double t0 = c * Ai[k] + s * Aj[k];
+                    const double t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                if (Vt) {
+                    double *Vi = Vt + i * n, *Vj = Vt + j * n;
+                    for (int k = 0; k < n; k++) {
+                        const double t0 = c * Vi[k] + s * Vj[k];
+                        const double t1 = -s * Vi[k] + c * Vj[k];
+                        Vi[k] = t0; Vj[k] = t1;
+                    }
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (int k = 0; k < m; k++) { t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
+            if (Vt) for (int k = 0; k < n; k++) { t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t; }
+        }
+    }
+    // left vectors = rows / singular value; a zero singular value gets a deterministic
+    // pseudo-random direction orthogonal to the previous rows (what OpenCV's JacobiSVD does).
+    Rng rng(0x12345678ULL);
+    for (int i = 0; i < n; i++) {
+        double sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= kDblMin; ii++) {
+            const double val0 = 1. / m;
+            for (int k = 0; k < m; k++) At[i * m + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+            for (int it = 0; it < 2; it++)
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+                    for (int k = 0; k < m; k++) sd += At[i * m + k] * At[j * m + k];
+                    double asum = 0;
+                    for (int k = 0; k < m; k++) {
+                        const double t = At[i * m + k] - sd * At[j * m + k];
+                        At[i * m + k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+                    for (int k = 0; k < m; k++) At[i * m + k] *= asum;
+                }
+            sd = 0;
+            for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
+            sd = sqrt(sd);
+        }
+        const double s = sd > kDblMin ? 1 / sd : 0.;
+        for (int k = 0; k < m; k++) At[i * m + k] *= s;
+    }
+}
+
+// x = V diag(1/w) U^T b, singular values below sum(w)*2*eps dropped (OpenCV SVD back-substitution)
+__device__ void svd_backsubst(const double* w, const double* ut, const double* vt, int m, int n, const double* b, double* x)
+{
+    double thr = 0;
+    for (int i = 0; i < n; i++) thr += w[i];
+    thr *= kDblEps * 2;
+    for (int j = 0; j < n; j++) x[j] = 0;
+    for (int i = 0; i < n; i++) {
+        double wi = w[i];
+        if (fabs(wi) <= thr) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int k = 0; k < m; k++) s += ut[i * m + k] * b[k];
+        s *= wi;
+        for (int j = 0; j < n; j++) x[j] += s * vt[i * n + j];
+    }
+}
+
+// least squares A x = b (A row-major 6 x n, n <= 5) through the SVD
+__device__ void solve_svd6(const double* A, int n, const double* b, double* x)
+{
+    double w[5], ut[30], vt[25];
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 6; k++) ut[i * 6 + k] = A[k * n + i];
+    jacobi_svd(ut, 6, n, w, vt);
+    svd_backsubst(w, ut, vt, 6, n, b, x);
+}
+
+// SVD of a row-major 3x3: w, ut (rows = left vectors), vt
+__device__ void svd3(const double* A, double* w, double* ut, double* vt)
+{
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) ut[i * 3 + k] = A[k * 3 + i];
+    jacobi_svd(ut, 3, 3, w, vt);
+}
+
+__device__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ double dist2(const double* a, const double* b)
+{
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+
+// ---------------------------------------------------------------- Rodrigues
+__device__ void rodrigues_v2r(const double* r, double* R)
+{
+    const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < kDblEps) {
+        for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1. : 0.;
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
+    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * (k % 4 == 0 ? 1. : 0.) + c1 * rrt[k] + s * rx[k];
+}
+
+__device__ void rodrigues_r2v(const double* R, double* r)
+{
+    double w[3], ut[9], vt[9], Rn[9];
+    svd3(R, w, ut, vt);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += ut[k * 3 + i] * vt[k * 3 + j];
+            Rn[i * 3 + j] = s;
+        }
+    double rx = Rn[7] - Rn[5], ry = Rn[2] - Rn[6], rz = Rn[3] - Rn[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (Rn[0] + Rn[4] + Rn[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (Rn[0] + 1) * 0.5; rx = sqrt(t > 0. ? t : 0.);
+        t = (Rn[4] + 1) * 0.5; ry = sqrt(t > 0. ? t : 0.) * (Rn[1] < 0 ? -1. : 1.);
+        t = (Rn[8] + 1) * 0.5; rz = sqrt(t > 0. ? t : 0.) * (Rn[2] < 0 ? -1. : 1.);
+        if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (Rn[5] > 0) != (ry * rz > 0)) rz = -rz;
+        theta /= sqrt(rx * rx + ry * ry + rz * rz);
+        r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
+        return;
+    }
+    double vth = 1 / (2 * s);
+    vth *= theta;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+// ---------------------------------------------------------------- EPnP pieces shared by both paths
+struct Cam { double fu, fv, uc, vc; };
+
+// control points from centroid + covariance (3x3 SVD): cws[4][3]
+__device__ void control_points(const double* c0, const double* ptp, int n, double cws[4][3])
+{
+    double dc[3], uct[9], vt[9];
+    svd3(ptp, dc, uct, vt);
+    for (int j = 0; j < 3; j++) cws[0][j] = c0[j];
+    for (int i = 1; i < 4; i++) {
+        const double k = sqrt(dc[i - 1] / n);
+        for (int j = 0; j < 3; j++) cws[i][j] = c0[j] + k * uct[3 * (i - 1) + j];
+    }
+}
+
+// inverse (SVD pseudo-inverse) of CC[i][j-1] = cws[j][i] - cws[0][i]
+__device__ void cc_inverse(const double cws[4][3], double* ci)
+{
+    double cc[9], w[3], ut[9], vt[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
+    svd3(cc, w, ut, vt);
+    for (int col = 0; col < 3; col++) {
+        double b[3] = {0, 0, 0}, x[3];
+        b[col] = 1;
+        svd_backsubst(w, ut, vt, 3, 3, b, x);
+        for (int r = 0; r < 3; r++) ci[3 * r + col] = x[r];
+    }
+}
+
+__device__ void barycentric(const double* ci, const double cws[4][3], const double* p, double* a)
+{
+    for (int j = 0; j < 3; j++)
+        a[1 + j] = ci[3 * j] * (p[0] - cws[0][0]) + ci[3 * j + 1] * (p[1] - cws[0][1]) + ci[3 * j + 2] * (p[2] - cws[0][2]);
+    a[0] = 1.0 - a[1] - a[2] - a[3];
+}
+
+__device__ void compute_L_6x10(const double* ut, double* l)
+{
+    const double* v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    double dv[4][6][3];
+    for (int i = 0; i < 4; i++) {
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; j++) {
+            dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
+            dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
+            dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+            b++;
+            if (b > 3) { a++; b = a + 1; }
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double* row = l + 10 * i;
+        row[0] = dot3(dv[0][i], dv[0][i]);
+        row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
+        row[2] = dot3(dv[1][i], dv[1][i]);
+        row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
+        row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
+        row[5] = dot3(dv[2][i], dv[2][i]);
+        row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
+        row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
+        row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
+        row[9] = dot3(dv[3][i], dv[3][i]);
+    }
+}
+
+__device__ void compute_rho(const double cws[4][3], double* rho)
+{
+    rho[0] = dist2(cws[0], cws[1]); rho[1] = dist2(cws[0], cws[2]); rho[2] = dist2(cws[0], cws[3]);
+    rho[3] = dist2(cws[1], cws[2]); rho[4] = dist2(cws[1], cws[3]); rho[5] = dist2(cws[2], cws[3]);
+}
+
+// betas10 = [B11 B12 B22 B13 B23 B33 B14 B24 B34 B44]
+__device__ void betas_approx_1(const double* l, const double* rho, double* betas)      // [B11 B12 B13 B14]
+{
+    double l4[24], b4[4];
+    for (int i = 0; i < 6; i++) {
+        l4[4 * i] = l[10 * i]; l4[4 * i + 1] = l[10 * i + 1]; l4[4 * i + 2] = l[10 * i + 3]; l4[4 * i + 3] = l[10 * i + 6];
+    }
+    solve_svd6(l4, 4, rho, b4);
+    if (b4[0] < 0) {
+        betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0];
+    } else {
+        betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0];
+    }
+}
+
+__device__ void betas_approx_2(const double* l, const double* rho, double* betas)      // [B11 B12 B22]
+{
+    double l3[18], b3[3];
+    for (int i = 0; i < 6; i++) { l3[3 * i] = l[10 * i]; l3[3 * i + 1] = l[10 * i + 1]; l3[3 * i + 2] = l[10 * i + 2]; }
+    solve_svd6(l3, 3, rho, b3);
+    if (b3[0] < 0) {
+        betas[0] = sqrt(-b3[0]);
+        betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
+    } else {
+        betas[0] = sqrt(b3[0]);
+        betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
+    }
+    if (b3[1] < 0) betas[0] = -betas[0];
+    betas[2] = 0.0; betas[3] = 0.0;
+}
+
+__device__ void betas_approx_3(const double* l, const double* rho, double* betas)      // [B11 B12 B22 B13 B23]
+{
+    double l5[30], b5[5];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 5; j++) l5[5 * i + j] = l[10 * i + j];
+    solve_svd6(l5, 5, rho, b5);
+    if (b5[0] < 0) {
+        betas[0] = sqrt(-b5[0]);
+        betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+    } else {
+        betas[0] = sqrt(b5[0]);
+        betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+    }
+    if (b5[1] < 0) betas[0] = -betas[0];
+    betas[2] = b5[3] / betas[0];
+    betas[3] = 0.0;
+}
+
+// Householder least squares for the 6x4 Gauss-Newton system (A destroyed)
+__device__ void qr_solve(double* A, double* b, double* X)
+{
+    const int nr = 6, nc = 4;
+    double A1[4], A2[4];
+    for (int k = 0; k < nc; k++) {
+        double eta = fabs(A[k * nc + k]);
+        // (the scan below mirrors epnp.cpp: rows k .. nr-2; eta only rescales the column)
+        for (int i = k + 1; i < nr; i++) {
+            const double elt = fabs(A[(i - 1) * nc + k]);
+            if (eta < elt) eta = elt;
+        }
+        if (eta == 0) return;
+        double sum2 = 0.0;
+        const double inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) {
+            A[i * nc + k] *= inv_eta;
+            sum2 += A[i * nc + k] * A[i * nc + k];
+        }
+        double sigma = sqrt(sum2);
+        if (A[k * nc + k] < 0) sigma = -sigma;
+        A[k * nc + k] += sigma;
+        A1[k] = sigma * A[k * nc + k];
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double sum = 0;
+            for (int i = k; i < nr; i++) sum += A[i * nc + k] * A[i * nc + j];
+            const double tau = sum / A1[k];
+            for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
+        }
+    }
+    for (int j = 0; j < nc; j++) {
+        double tau = 0;
+        for (int i = j; i < nr; i++) tau += A[i * nc + j] * b[i];
+        tau /= A1[j];
+        for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
+    }
+    X[nc - 1] = b[nc - 1] / A2[nc - 1];
+    for (int i = nc - 2; i >= 0; i--) {
+        double sum = 0;
+        for (int j = i + 1; j < nc; j++) sum += A[i * nc + j] * X[j];
+        X[i] = (b[i] - sum) / A2[i];
+    }
+}
+
+__device__ void gauss_newton(const double* l, const double* rho, double* betas)
+{
+    for (int k = 0; k < 5; k++) {
+        double A[24], B[6], X[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 6; i++) {
+            const double* r = l + i * 10;
+            double* a = A + i * 4;
+            a[0] = 2 * r[0] * betas[0] + r[1] * betas[1] + r[3] * betas[2] + r[6] * betas[3];
+            a[1] = r[1] * betas[0] + 2 * r[2] * betas[1] + r[4] * betas[2] + r[7] * betas[3];
+            a[2] = r[3] * betas[0] + r[4] * betas[1] + 2 * r[5] * betas[2] + r[8] * betas[3];
+            a[3] = r[6] * betas[0] + r[7] * betas[1] + r[8] * betas[2] + 2 * r[9] * betas[3];
+            B[i] = rho[i] - (r[0] * betas[0] * betas[0] + r[1] * betas[0] * betas[1] + r[2] * betas[1] * betas[1] +
+                             r[3] * betas[0] * betas[2] + r[4] * betas[1] * betas[2] + r[5] * betas[2] * betas[2] +
+                             r[6] * betas[0] * betas[3] + r[7] * betas[1] * betas[3] + r[8] * betas[2] * betas[3] +
+                             r[9] * betas[3] * betas[3]);
+        }
+        qr_solve(A, B, X);
+        for (int i = 0; i < 4; i++) betas[i] += X[i];
+    }
+}
+
+__device__ void compute_ccs(const double* betas, const double* ut, double ccs[4][3])
+{
+    for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0;
+    for (int i = 0; i < 4; i++) {
+        const double* v = ut + 12 * (11 - i);
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[3 * j + k];
+    }
+}
+
+// absolute orientation from ABt (3x3) and the two centroids
+__device__ void orientation(const double* abt, const double* pc0, const double* pw0, double R[3][3], double t[3])
+{
+    double d[3], ut[9], vt[9];
+    svd3(abt, d, ut, vt);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += ut[k * 3 + i] * vt[k * 3 + j];
+            R[i][j] = s;
+        }
+    const double det = R[0][0] * R[1][1] * R[2][2] + R[0][1] * R[1][2] * R[2][0] + R[0][2] * R[1][0] * R[2][1] -
+                       R[0][2] * R[1][1] * R[2][0] - R[0][1] * R[1][0] * R[2][2] - R[0][0] * R[1][2] * R[2][1];
+    if (det < 0) { R[2][0] = -R[2][0]; R[2][1] = -R[2][1]; R[2][2] = -R[2][2]; }
+    t[0] = pc0[0] - dot3(R[0], pw0);
+    t[1] = pc0[1] - dot3(R[1], pw0);
+    t[2] = pc0[2] - dot3(R[2], pw0);
+}
+
+// ---------------------------------------------------------------- 5-point EPnP, one lane, sequential
+// pws[15] (object, mm), us[10] (pixels).  Sequential summation order = OpenCV's.
+__device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout)
+{
+    const int n = 5;
+    double cws[4][3], c0[3] = {0, 0, 0}, ptp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) c0[j] += pws[3 * i + j];
+    for (int j = 0; j < 3; j++) c0[j] /= n;
+    for (int i = 0; i < n; i++) {
+        double d[3];
+        for (int j = 0; j < 3; j++) d[j] = pws[3 * i + j] - c0[j];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) ptp[a * 3 + b] += d[a] * d[b];
+    }
+    control_points(c0, ptp, n, cws);
+    double ci[9], alphas[20];
+    cc_inverse(cws, ci);
+    for (int i = 0; i < n; i++) barycentric(ci, cws, pws + 3 * i, alphas + 4 * i);
+
+    double mtm[144];
+    for (int k = 0; k < 144; k++) mtm[k] = 0;
+    for (int i = 0; i < n; i++) {
+        const double* a = alphas + 4 * i;
+        double m1[12], m2[12];
+        const double u = us[2 * i], v = us[2 * i + 1];
+        for (int j = 0; j < 4; j++) {
+            m1[3 * j] = a[j] * cam.fu; m1[3 * j + 1] = 0.0; m1[3 * j + 2] = a[j] * (cam.uc - u);
+            m2[3 * j] = 0.0; m2[3 * j + 1] = a[j] * cam.fv; m2[3 * j + 2] = a[j] * (cam.vc - v);
+        }
+        for (int p = 0; p < 12; p++)
+            for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m1[p] * m1[q];
+        for (int p = 0; p < 12; p++)
+            for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m2[p] * m2[q];
+    }
+    double w12[12];
+    // symmetric matrix: rows == columns, so the row image of A^T is the matrix itself
+    jacobi_svd(mtm, 12, 12, w12, nullptr);
+    const double* ut = mtm;
+
+    double l[60], rho[6];
+    compute_L_6x10(ut, l);
+    compute_rho(cws, rho);
+
+    double best_err = 0;
+    for (int c = 1; c <= 3; c++) {
+        double betas[4];
+        if (c == 1) betas_approx_1(l, rho, betas);
+        else if (c == 2) betas_approx_2(l, rho, betas);
+        else betas_approx_3(l, rho, betas);
+        gauss_newton(l, rho, betas);
+        double ccs[4][3], pcs[15];
+        compute_ccs(betas, ut, ccs);
+        for (int i = 0; i < n; i++) {
+            const double* a = alphas + 4 * i;
+            for (int j = 0; j < 3; j++) pcs[3 * i + j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
+        }
+        if (pcs[2] < 0.0)
+            for (int i = 0; i < 3 * n; i++) pcs[i] = -pcs[i];
+        double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < 3; j++) { pc0[j] += pcs[3 * i + j]; pw0[j] += pws[3 * i + j]; }
+        for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+        double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < 3; j++) {
+                abt[3 * j] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i] - pw0[0]);
+                abt[3 * j + 1] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + 1] - pw0[1]);
+                abt[3 * j + 2] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + 2] - pw0[2]);
+            }
+        double R[3][3], t[3];
+        orientation(abt, pc0, pw0, R, t);
+        double sum2 = 0.0;
+        for (int i = 0; i < n; i++) {
+            const double* pw = pws + 3 * i;
+            const double Xc = dot3(R[0], pw) + t[0], Yc = dot3(R[1], pw) + t[1];
+            const double inv_Zc = 1.0 / (dot3(R[2], pw) + t[2]);
+            const double ue = cam.uc + cam.fu * Xc * inv_Zc, ve = cam.vc + cam.fv * Yc * inv_Zc;
+            const double u = us[2 * i], v = us[2 * i + 1];
+            sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+        }
+        const double err = sum2 / n;
+        if (c == 1 || err < best_err) {
+            best_err = err;
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) Rout[3 * i + j] = R[i][j];
+                tout[i] = t[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- workgroup reductions
+template <int NV>
+__device__ void block_reduce(double (&v)[NV], double* red /* LDS: >= 4*NV doubles */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wave * NV + k] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = red[k] + red[NV + k] + red[2 * NV + k] + red[3 * NV + k];
+    __syncthreads();
+}
+
+__device__ int block_reduce_int(int x, int* red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    const int s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return s;
+}
+
+__device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > kDblMin ? 1. - p : kDblMin;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < kDblMin) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// inlier test of OpenCV's PnPRansacCallback::computeError + findInliers
+__device__ __forceinline__ bool is_inlier(const double* R, const double* t, const Cam& cam, float X, float Y, float Z,
+                                          float iu, float iv, float thr2)
+{
+    const double Xd = X, Yd = Y, Zd = Z;
+    double x = R[0] * Xd + R[1] * Yd + R[2] * Zd + t[0];
+    double y = R[3] * Xd + R[4] * Yd + R[5] * Zd + t[1];
+    double z = R[6] * Xd + R[7] * Yd + R[8] * Zd + t[2];
+    z = z != 0. ? 1. / z : 1.;
+    x *= z; y *= z;
+    const float pu = (float)(x * cam.fu + cam.uc), pv = (float)(y * cam.fv + cam.vc);
+    const float du = iu - pu, dv = iv - pv;
+    const float err = du * du + dv * dv;
+    return err <= thr2;
+}
+
+constexpr int MAX_ITERS = 128;
+
+// One workgroup (256 threads) per problem.
+__global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __restrict__ probs, PnpResult* __restrict__ results,
+                                                         int iterations, double reproj_err, double confidence,
+                                                         int min_points)
+{
+    __shared__ int s_idx[MAX_ITERS][5];
+    __shared__ double s_R[MAX_ITERS][9];
+    __shared__ double s_t[MAX_ITERS][3];
+    __shared__ double s_red[4 * 56];
+    __shared__ int s_ired[4];
+    __shared__ int s_ctl[4];         // niters, best, max_good, iter
+    __shared__ double s_fit[64];     // refit scratch (control points, inverse, R, t ...)
+
+    const PnpProblem pb = probs[blockIdx.x];
+    PnpResult& out = results[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n = pb.n;
+    const float* PX = pb.pts;
+    const float* PY = pb.pts + (size_t)pb.cap;
+    const float* PZ = pb.pts + 2 * (size_t)pb.cap;
+    const float* PU = pb.pts + 3 * (size_t)pb.cap;
+    const float* PV = pb.pts + 4 * (size_t)pb.cap;
+    Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
+    if (iterations > MAX_ITERS) iterations = MAX_ITERS;
+
+    if (n < min_points || n < 5) {
+        if (tid == 0) {
+            for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1. : 0.;
+            out.t[0] = out.t[1] = out.t[2] = 0;
+            out.n_inliers = -1; out.iters = 0; out.best_iter = -1; out.ok = 0;
+        }
+        return;
+    }
+
+    // ---- 1. replay the sampler
+    const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
+    if (tid == 0) {
+        if (n == 5) {
+            for (int i = 0; i < 5; i++) s_idx[0][i] = i;
+        } else {
+            Rng rng(~0ULL);
+            for (int it = 0; it < n_hyp; it++)
+                for (int i = 0; i < 5;) {
+                    int idx_i, j;
+                    for (;;) {
+                        idx_i = s_idx[it][i] = rng.uniform(0, n);
+                        for (j = 0; j < i; j++) if (idx_i == s_idx[it][j]) break;
+                        if (j == i) break;
+                    }
+                    i++;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. hypotheses: one lane each
+    const double ifx = 1. / pb.K[0], ify = 1. / pb.K[4];
+    if (tid < n_hyp) {
+        double pws[15], us[10];
+        for (int i = 0; i < 5; i++) {
+            const int id = s_idx[tid][i];
+            pws[3 * i] = PX[id]; pws[3 * i + 1] = PY[id]; pws[3 * i + 2] = PZ[id];
+            // undistortPoints (identity distortion) stores float32 normalised coordinates; epnp re-applies fu, uc
+            const double xn = (double)(float)(((double)PU[id] - pb.K[2]) * ifx);
+            const double yn = (double)(float)(((double)PV[id] - pb.K[5]) * ify);
+            us[2 * i] = xn * pb.K[0] + pb.K[2];
+            us[2 * i + 1] = yn * pb.K[4] + pb.K[5];
+        }
+        double R[9], t[3], rvec[3];
+        epnp5(cam, pws, us, R, t);
+        rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
+        rodrigues_v2r(rvec, R);
+        for (int k = 0; k < 9; k++) s_R[tid][k] = R[k];
+        for (int k = 0; k < 3; k++) s_t[tid][k] = t[k];
+    }
+    if (tid == 0) { s_ctl[0] = n_hyp; s_ctl[1] = -1; s_ctl[2] = 0; s_ctl[3] = 0; }
+    __syncthreads();
+
+    // ---- 3. score in OpenCV's order with the adaptive bound
+    const float thr2 = (float)(reproj_err * reproj_err);
+    if (n == 5) {
+        if (tid == 0) { s_ctl[1] = 0; s_ctl[2] = 5; s_ctl[3] = 0; }
+        __syncthreads();
+    } else {
+        for (int it = 0;; ++it) {
+            if (it >= s_ctl[0]) break;           // uniform: s_ctl[0] is read after the barrier below
+            double R[9], t[3];
+            for (int k = 0; k < 9; k++) R[k] = s_R[it][k];
+            for (int k = 0; k < 3; k++) t[k] = s_t[it][k];
+            int cnt = 0;
+            for (int i = tid; i < n; i += 256) cnt += is_inlier(R, t, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2) ? 1 : 0;
+            const int good = block_reduce_int(cnt, s_ired);
+            if (tid == 0) {
+                const int mg = s_ctl[2];
+                if (good > (mg > 4 ? mg : 4)) {
+                    s_ctl[2] = good;
+                    s_ctl[1] = it;
+                    s_ctl[0] = ransac_update_num_iters(confidence, (double)(n - good) / n, 5, s_ctl[0]);
+                }
+                s_ctl[3] = it + 1;
+            }
+            __syncthreads();
+        }
+    }
+    const int best = s_ctl[1], max_good = s_ctl[2], iters_run = s_ctl[3];
+    if (best < 0 || max_good <= 0) {
+        if (tid == 0) {
+            for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1. : 0.;
+            out.t[0] = out.t[1] = out.t[2] = 0;
+            out.n_inliers = -1; out.iters = iters_run; out.best_iter = -1; out.ok = 0;
+        }
+        return;
+    }
+    if (n == 5) {   // solvePnPRansac returns the direct solution when npoints == model_points
+        if (tid == 0) {
+            for (int k = 0; k < 9; k++) out.R[k] = s_R[0][k];
+            for (int k = 0; k < 3; k++) out.t[k] = s_t[0][k];
+            out.n_inliers = 5; out.iters = 0; out.best_iter = 0; out.ok = 1;
+        }
+        if (pb.mask) for (int i = tid; i < n; i += 256) pb.mask[i] = 1;
+        return;
+    }
+
+    // ---- 4. re-fit EPnP on the inliers of the best hypothesis
+    double Rb[9], tb[3];
+    for (int k = 0; k < 9; k++) Rb[k] = s_R[best][k];
+    for (int k = 0; k < 3; k++) tb[k] = s_t[best][k];
+    const int m = max_good;
+
+    // pass A: centroid and covariance of the inlier object points
+    {
+        double v[3] = {0, 0, 0};
+        for (int i = tid; i < n; i += 256) {
+            const bool in = is_inlier(Rb, tb, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2);
+            if (pb.mask) pb.mask[i] = in ? 1 : 0;
+            if (in) { v[0] += PX[i]; v[1] += PY[i]; v[2] += PZ[i]; }
+        }
+        block_reduce<3>(v, s_red);
+        double c0[3] = {v[0] / m, v[1] / m, v[2] / m};
+        double q[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < n; i += 256)
+            if (is_inlier(Rb, tb, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2)) {
+                const double dx = PX[i] - c0[0], dy = PY[i] - c0[1], dz = PZ[i] - c0[2];
+                q[0] += dx * dx; q[1] += dx * dy; q[2] += dx * dz; q[3] += dy * dy; q[4] += dy * dz; q[5] += dz * dz;
+            }
+        block_reduce<6>(q, s_red);
+        if (tid == 0) {
+            const double ptp[9] = {q[0], q[1], q[2], q[1], q[3], q[4], q[2], q[4], q[5]};
+            double cws[4][3], ci[9];
+            control_points(c0, ptp, m, cws);
+            cc_inverse(cws, ci);
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 3; j++) s_fit[3 * i + j] = cws[i][j];
+            for (int k = 0; k < 9; k++) s_fit[12 + k] = ci[k];
+        }
+        __syncthreads();
+    }
+    double cws[4][3], ci[9];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 3; j++) cws[i][j] = s_fit[3 * i + j];
+    for (int k = 0; k < 9; k++) ci[k] = s_fit[12 + k];
+
+    // pass B: Gram sums.  M^T M[(j,p),(k,q)] only needs, over pairs (j<=k) of barycentric coords,
+    //   S0 = sum a_j a_k, S1 = sum a_j a_k du, S2 = sum a_j a_k dv, S3 = sum a_j a_k (du^2+dv^2)
+    // with du = uc-u, dv = vc-v; plus Sa[j] = sum a_j and A[j][c] = sum a_j (pw_c - pw0_c) for the
+    // absolute-orientation step (pc_i is linear in a_i, so no further pass over the points).
+    double g[56];
+#pragma unroll
+    for (int k = 0; k < 56; k++) g[k] = 0;
+    for (int i = tid; i < n; i += 256) {
+        if (!is_inlier(Rb, tb, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2)) continue;
+        const double p[3] = {PX[i], PY[i], PZ[i]};
+        double a[4];
+        barycentric(ci, cws, p, a);
+        const double du = cam.uc - (double)PU[i], dv = cam.vc - (double)PV[i];
+        const double dd = du * du + dv * dv;
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = j; k < 4; k++) {
+                const double ajk = a[j] * a[k];
+                g[e] += ajk; g[10 + e] += ajk * du; g[20 + e] += ajk * dv; g[30 + e] += ajk * dd;
+                ++e;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            g[40 + j] += a[j];
+            g[44 + 3 * j] += a[j] * (p[0] - cws[0][0]);
+            g[45 + 3 * j] += a[j] * (p[1] - cws[0][1]);
+            g[46 + 3 * j] += a[j] * (p[2] - cws[0][2]);
+        }
+    }
+    block_reduce<56>(g, s_red);
+
+    // thread 0: 12x12 SVD, betas, three (R,t) candidates -> LDS; then a last pass picks by reprojection error
+    if (tid == 0) {
+        double mtm[144];
+        auto pair = [](int j, int k) { if (j > k) { int t = j; j = k; k = t; } return j * 4 - j * (j - 1) / 2 + (k - j); };
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 4; k++) {
+                const int e = pair(j, k);
+                const double s0 = g[e], s1 = g[10 + e], s2 = g[20 + e], s3 = g[30 + e];
+                double* b = mtm + (3 * j) * 12 + 3 * k;
+                b[0] = cam.fu * cam.fu * s0; b[1] = 0;                     b[2] = cam.fu * s1;
+                b[12] = 0;                   b[13] = cam.fv * cam.fv * s0; b[14] = cam.fv * s2;
+                b[24] = cam.fu * s1;         b[25] = cam.fv * s2;          b[26] = s3;
+            }
+        double w12[12];
+        jacobi_svd(mtm, 12, 12, w12, nullptr);
+        const double* ut = mtm;
+        double l[60], rho[6];
+        compute_L_6x10(ut, l);
+        compute_rho(cws, rho);
+        for (int c = 0; c < 3; c++) {
+            double betas[4];
+            if (c == 0) betas_approx_1(l, rho, betas);
+            else if (c == 1) betas_approx_2(l, rho, betas);
+            else betas_approx_3(l, rho, betas);
+            gauss_newton(l, rho, betas);
+            double ccs[4][3];
+            compute_ccs(betas, ut, ccs);
+            // sign: depth of the FIRST inlier's camera-frame point (epnp solve_for_sign uses pcs[2])
+            {
+                int first = 0;
+                while (first < n && !is_inlier(Rb, tb, cam, PX[first], PY[first], PZ[first], PU[first], PV[first], thr2)) ++first;
+                const double p[3] = {PX[first], PY[first], PZ[first]};
+                double a[4];
+                barycentric(ci, cws, p, a);
+                const double z = a[0] * ccs[0][2] + a[1] * ccs[1][2] + a[2] * ccs[2][2] + a[3] * ccs[3][2];
+                if (z < 0.0)
+                    for (int i = 0; i < 4; i++)
+                        for (int j = 0; j < 3; j++) ccs[i][j] = -ccs[i][j];
+            }
+            double pc0[3], abt[9];
+            for (int j = 0; j < 3; j++) {
+                pc0[j] = (g[40] * ccs[0][j] + g[41] * ccs[1][j] + g[42] * ccs[2][j] + g[43] * ccs[3][j]) / m;
+                for (int k = 0; k < 3; k++)
+                    abt[3 * j + k] = ccs[0][j] * g[44 + k] + ccs[1][j] * g[47 + k] + ccs[2][j] * g[50 + k] + ccs[3][j] * g[53 + k];
+            }
+            double R[3][3], t[3];
+            orientation(abt, pc0, cws[0], R, t);
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) s_fit[21 + 12 * c + 3 * i + j] = R[i][j];
+                s_fit[21 + 12 * c + 9 + i] = t[i];
+            }
+        }
+    }
+    __syncthreads();
+    double Rc[3][9], tc[3][3];
+    for (int c = 0; c < 3; c++) {
+        for (int k = 0; k < 9; k++) Rc[c][k] = s_fit[21 + 12 * c + k];
+        for (int k = 0; k < 3; k++) tc[c][k] = s_fit[21 + 12 * c + 9 + k];
+    }
+    double e3[3] = {0, 0, 0};
+    for (int i = tid; i < n; i += 256) {
+        if (!is_inlier(Rb, tb, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2)) continue;
+        const double p[3] = {PX[i], PY[i], PZ[i]};
+        const double u = PU[i], v = PV[i];
+        for (int c = 0; c < 3; c++) {
+            const double Xc = dot3(Rc[c], p) + tc[c][0], Yc = dot3(Rc[c] + 3, p) + tc[c][1];
+            const double inv_Zc = 1.0 / (dot3(Rc[c] + 6, p) + tc[c][2]);
+            const double ue = cam.uc + cam.fu * Xc * inv_Zc, ve = cam.vc + cam.fv * Yc * inv_Zc;
+            e3[c] += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+        }
+    }
+    block_reduce<3>(e3, s_red);
+    if (tid == 0) {
+        int N = 0;
+        if (e3[1] < e3[0]) N = 1;
+        if (e3[2] < e3[N]) N = 2;
+        double rvec[3], R[9];
+        rodrigues_r2v(Rc[N], rvec);     // solvePnP returns rvec; the caller converts back (recognition.py:223)
+        rodrigues_v2r(rvec, R);
+        for (int k = 0; k < 9; k++) out.R[k] = R[k];
+        for (int k = 0; k < 3; k++) out.t[k] = tc[N][k];
+        out.n_inliers = max_good; out.iters = iters_run; out.best_iter = best; out.ok = 1;
+    }
+}
+
+}  // namespace pnp
+
+hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_problems, int iterations,
+                             double reproj_err, double confidence, int min_points, hipStream_t s)
+{
+    if (n_problems <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pnp::pnp_ransac_kernel, dim3(n_problems), dim3(256), 0, s, probs, results, iterations, reproj_err,
+                       confidence, min_points);
+    return hipGetLastError();
+}
+
+}  // namespace p2p

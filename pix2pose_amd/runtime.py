@@ -103,3 +103,124 @@ class Generator:
             self.close()
         except Exception:
             pass
+
+
+# --------------------------------------------------------------------------------------------
+# batched pose estimation (C ABI: p2p_est_pose_batch / p2p_pnp_ransac_batch)
+# --------------------------------------------------------------------------------------------
+class ObjectSpec:
+    """What one reference ``pix2pose`` instance holds per object (recognition.py:10-26)."""
+
+    def __init__(self, generator: Generator, obj_param, th_outlier=(0.1, 0.2, 0.3), th_inlier=0.1, box_size=1.5):
+        th_outlier = list(th_outlier)
+        if not 1 <= len(th_outlier) <= _lib.MAX_TH:
+            raise ValueError("th_outlier must hold 1..%d thresholds" % _lib.MAX_TH)
+        self.generator = generator
+        self.obj_param = np.asarray(obj_param, np.float64).reshape(6)
+        self.th_outlier = [float(t) for t in th_outlier]
+        self.th_inlier = float(th_inlier)
+        self.box_size = float(box_size)
+
+    def as_struct(self) -> "_lib.Object":
+        o = _lib.Object()
+        o.model = self.generator.handle
+        for k in range(3):
+            o.obj_scale[k] = self.obj_param[k]
+            o.obj_ct[k] = self.obj_param[3 + k]
+        o.n_outlier_th = len(self.th_outlier)
+        for k, t in enumerate(self.th_outlier):
+            o.outlier_th[k] = t
+        o.inlier_th = self.th_inlier
+        o.box_size = self.box_size
+        return o
+
+
+def _image_struct(img):
+    """numpy HxWx3 uint8/float32 array, or (device_ptr, H, W, 'u8'|'f32') for a frame already in HBM."""
+    s = _lib.Image()
+    if isinstance(img, tuple):
+        ptr, h, w, dt = img
+        s.data, s.height, s.width = ptr, h, w
+        s.dtype = 1 if dt == "f32" else 0
+        s.mem = _lib.MEM_DEVICE
+        return s, None
+    a = np.asarray(img)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("image must be HxWx3, got %r" % (a.shape,))
+    if a.dtype == np.uint8:
+        a = np.ascontiguousarray(a)
+        s.dtype = 0
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        s.dtype = 1
+    s.data, s.height, s.width, s.mem = a.ctypes.data, a.shape[0], a.shape[1], _lib.MEM_HOST
+    return s, a
+
+
+def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
+                   want_masks=False, debug=False, ransac_iterations=0, reprojection_error=0.0, confidence=0.0):
+    """detections: list of (image_idx, object_idx, bbox[v1,u1,v2,u2], camK 3x3).
+    Returns (poses: list[_lib.Pose], extras: dict)."""
+    n = len(detections)
+    objs = (_lib.Object * max(len(objects), 1))(*[o.as_struct() for o in objects])
+    keep = []
+    imgs = (_lib.Image * max(len(images), 1))()
+    for i, im in enumerate(images):
+        imgs[i], a = _image_struct(im)
+        keep.append(a)
+    dets = (_lib.Detection * max(n, 1))()
+    for i, (ii, oi, bbox, K) in enumerate(detections):
+        dets[i].image, dets[i].object = int(ii), int(oi)
+        for k in range(4):
+            dets[i].bbox[k] = int(bbox[k])
+        Kf = np.asarray(K, np.float64).reshape(9)
+        for k in range(9):
+            dets[i].camK[k] = Kf[k]
+    poses = (_lib.Pose * max(n, 1))()
+    opts = _lib.EstPoseOpts()
+    opts.ransac_iterations, opts.reprojection_error, opts.confidence = ransac_iterations, reprojection_error, confidence
+    opts.inject1, opts.inject2, opts.inject_slots = inject1, inject2, inject_slots
+    extras = {}
+    K = max([len(o.th_outlier) for o in objects], default=0)
+    if want_masks and n:
+        def hw(i):
+            im = images[detections[i][0]]
+            return (im[1], im[2]) if isinstance(im, tuple) else np.asarray(im).shape[:2]
+        mstride = max(hw(i)[0] * hw(i)[1] for i in range(n))
+        extras["valid_mask"] = np.zeros((n, mstride), np.uint8)
+        extras["img_pred"] = np.zeros((n, mstride * 3), np.uint8)
+        opts.valid_mask, opts.mask_stride = extras["valid_mask"].ctypes.data, mstride
+        opts.img_pred, opts.pred_stride = extras["img_pred"].ctypes.data, mstride * 3
+    if debug and n:
+        extras["x1"] = np.zeros((n, 128, 128, 3), np.float32)
+        extras["x2"] = np.zeros((n, K, 128, 128, 3), np.float32)
+        extras["boxes2"] = np.zeros((n, 12), np.int32)
+        extras["cand"] = np.zeros((n, K, 4), np.int32)
+        opts.dbg_x1, opts.dbg_x2 = extras["x1"].ctypes.data, extras["x2"].ctypes.data
+        opts.dbg_boxes2, opts.dbg_cand = extras["boxes2"].ctypes.data, extras["cand"].ctypes.data
+    _lib.check(_lib.lib().p2p_est_pose_batch(ctx.handle, objs, len(objects), imgs, len(images), dets, n, poses,
+                                             C.byref(opts)), "p2p_est_pose_batch")
+    return [poses[i] for i in range(n)], extras
+
+
+def pnp_ransac_batch(ctx: Context, Ks, objs, imgs, iterations=100, reproj_err=5.0, confidence=0.99, want_mask=False):
+    """Batch of independent cv2.solvePnPRansac(EPNP) problems on the GPU.
+    -> ok [P] bool, R [P,3,3], t [P,3], info [P,3] (n_inliers, iterations, best_iter), masks list|None"""
+    n_prob = len(objs)
+    offsets = np.zeros(n_prob + 1, np.int32)
+    offsets[1:] = np.cumsum([len(o) for o in objs])
+    obj = np.ascontiguousarray(np.concatenate(objs) if n_prob else np.zeros((0, 3)), np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(np.concatenate(imgs) if n_prob else np.zeros((0, 2)), np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(Ks, np.float64).reshape(n_prob, 9)
+    R = np.zeros((n_prob, 9)); t = np.zeros((n_prob, 3))
+    info = np.zeros((n_prob, 3), np.int32); ok = np.zeros(n_prob, np.int32)
+    mask = np.zeros(max(int(offsets[-1]), 1), np.uint8) if want_mask else None
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int)
+    _lib.check(_lib.lib().p2p_pnp_ransac_batch(ctx.handle, K.ctypes.data_as(dp), obj.ctypes.data_as(dp),
+                                               img.ctypes.data_as(dp), offsets.ctypes.data_as(ip), n_prob, iterations,
+                                               reproj_err, confidence, R.ctypes.data_as(dp), t.ctypes.data_as(dp),
+                                               info.ctypes.data_as(ip), ok.ctypes.data_as(ip),
+                                               mask.ctypes.data if want_mask else None), "p2p_pnp_ransac_batch")
+    masks = [mask[offsets[i]:offsets[i + 1]] for i in range(n_prob)] if want_mask else None
+    return ok.astype(bool), R.reshape(-1, 3, 3), t, info, masks
