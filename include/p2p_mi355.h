@@ -167,7 +167,7 @@ typedef struct {
     float* dbg_x1;
     float* dbg_x2;
     int* dbg_boxes2;            /* [n_det][12] stage-2 get_boxes result */
-    int* dbg_cand;              /* [n_det][K][4]: valid, n_non_gray, n_corr, n_inliers */
+    int* dbg_cand;              /* [n_det][K][6]: valid, n_non_gray, n_corr, n_inliers, ransac iters, best iter */
 } p2p_est_pose_opts;
 
 /* Blocking.  poses[i] corresponds to dets[i]. */

@@ -18,6 +18,10 @@
  * this restatement is pinned only by known-answer tests (synthetic pose -> project ->
  * recover) and an independent numpy EPnP in tests/test_oracle_pnp.py.
  */
+/* The 5-point systems are rank deficient (2-D null space), so which basis a solver lands on is
+ * decided by rounding.  Keep this file at strict sequential IEEE semantics: gcc's SLP vectoriser
+ * (-O3) re-associates some of the straight-line sums below and changes hypotheses. */
+#pragma GCC optimize("O2", "no-tree-vectorize", "no-tree-slp-vectorize")
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
@@ -64,7 +68,9 @@ static void jacobi_svd(double* At, int astep, double* W, double* Vt, int vstep, 
                 for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta);
+                /* OpenCV calls hypot(); written out so every libm gives the same bits (a minimal-set
+                 * system has a 2-D null space whose basis is decided by rounding) */
+                double beta = a - b, gamma = sqrt(p * p + beta * beta);
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);
@@ -766,4 +772,38 @@ void p2po_solve_pnp_ransac_batch(const double* K, const double* obj, const doubl
                                       confidence, R + 9 * p, t + 3 * p, mask, info + 3 * p);
         free(mask);
     }
+}
+
+/* debug/test helper: the (rvec, tvec) model RANSAC iteration `which` produces */
+int p2po_debug_hypothesis(const double* K, const double* obj, const double* img, int n, int which, double* rvec,
+                          double* tvec, int* idx_out)
+{
+    if (n < 6) return 0;
+    float* objf = (float*)malloc(sizeof(float) * 3 * n);
+    float* imgf = (float*)malloc(sizeof(float) * 2 * n);
+    for (int i = 0; i < 3 * n; i++) objf[i] = (float)obj[i];
+    for (int i = 0; i < 2 * n; i++) imgf[i] = (float)img[i];
+    cv_rng rng;
+    rng_init(&rng, (uint64_t)-1);
+    for (int iter = 0; iter <= which; iter++) {
+        int idx[5];
+        double o5[15], i5[10];
+        for (int i = 0; i < 5;) {
+            int idx_i, j;
+            for (;;) {
+                idx_i = idx[i] = rng_uniform(&rng, 0, n);
+                for (j = 0; j < i; j++) if (idx_i == idx[j]) break;
+                if (j == i) break;
+            }
+            for (int k = 0; k < 3; k++) o5[3 * i + k] = objf[3 * idx_i + k];
+            for (int k = 0; k < 2; k++) i5[2 * i + k] = imgf[2 * idx_i + k];
+            i++;
+        }
+        if (iter == which) {
+            solve_pnp_epnp(K, o5, i5, 5, 1, rvec, tvec);
+            for (int i = 0; i < 5; i++) idx_out[i] = idx[i];
+        }
+    }
+    free(objf); free(imgf);
+    return 1;
 }

@@ -714,9 +714,10 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         if (opt.dbg_boxes2) memcpy(opt.dbg_boxes2 + (size_t)o * 12, &hs1[i].b2, sizeof(Boxes));
         if (opt.dbg_cand)
             for (int k = 0; k < K; ++k) {
-                int* c = opt.dbg_cand + ((size_t)o * K + k) * 4;
+                int* c = opt.dbg_cand + ((size_t)o * K + k) * 6;
                 c[0] = hs1[i].valid2[k]; c[1] = hcs[(size_t)i * K + k].n_non_gray; c[2] = hcs[(size_t)i * K + k].n_corr;
                 c[3] = hres[(size_t)i * K + k].n_inliers;
+                c[4] = hres[(size_t)i * K + k].iters; c[5] = hres[(size_t)i * K + k].best_iter;
             }
     }
     return P2P_OK;

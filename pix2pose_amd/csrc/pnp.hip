@@ -29,6 +29,28 @@ namespace pnp {
 constexpr double kDblEps = 2.220446049250313e-16;
 constexpr double kDblMin = 2.2250738585072014e-308;
 
+// Correctly rounded double sqrt.  The gfx950 expansion of sqrt(double) (v_rsq_f64 + Goldschmidt
+// steps) is within 1 ulp but not always the IEEE result, and a 5-point EPnP system has a 2-D
+// null space whose basis is decided by rounding -- so one differing ulp changes a hypothesis.
+// One exact-residual correction step (fma(-g, g, x) is exact for g within 1 ulp of the root)
+// makes the device agree bit for bit with a host libm.
+__device__ inline double sqrt_cr(double x)
+{
+    double g = __builtin_sqrt(x);
+    if (!(x > 0.0) || !(g < 1.7976931348623157e308)) return g;
+    const double r = __builtin_fma(-g, g, x);
+    if (r > 0.0) {
+        const double gn = __longlong_as_double(__double_as_longlong(g) + 1);
+        const double rn = __builtin_fma(-gn, gn, x);
+        if (rn >= 0.0 || r > -rn) g = gn;
+    } else if (r < 0.0) {
+        const double gp = __longlong_as_double(__double_as_longlong(g) - 1);
+        const double rp = __builtin_fma(-gp, gp, x);
+        if (rp <= 0.0 || -r > rp) g = gp;
+    }
+    return g;
+}
+
 // ---------------------------------------------------------------- cv::RNG (multiply with carry)
 struct Rng {
     unsigned long long state;
@@ -61,16 +83,17 @@ __device__ void jacobi_svd(double* At, int m, int n, double* W, double* Vt)
                 double *Ai = At + i * m, *Aj = At + j * m;
                 double a = W[i], p = 0, b = W[j];
                 for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
-                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                if (fabs(p) <= eps * sqrt_cr(a * b)) continue;
                 p *= 2;
-                const double beta = a - b, gamma = hypot(p, beta);
+                // hypot() written out: identical bits on every libm (see oracle/pnp_oracle.c)
+                const double beta = a - b, gamma = sqrt_cr(p * p + beta * beta);
                 double c, s;
                 if (beta < 0) {
                     const double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
+                    s = sqrt_cr(delta / gamma);
                     c = p / (gamma * s * 2);
                 } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
+                    c = sqrt_cr((gamma + beta) / (gamma * 2));
                     s = p / (gamma * c * 2);
                 }
                 a = b = 0;
@@ -96,7 +119,7 @@ __device__ void jacobi_svd(double* At, int m, int n, double* W, double* Vt)
     for (int i = 0; i < n; i++) {
         double sd = 0;
         for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
-        W[i] = sqrt(sd);
+        W[i] = sqrt_cr(sd);
     }
     for (int i = 0; i < n - 1; i++) {
         int j = i;
@@ -130,7 +153,7 @@ __device__ void jacobi_svd(double* At, int m, int n, double* W, double* Vt)
                 }
             sd = 0;
             for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
-            sd = sqrt(sd);
+            sd = sqrt_cr(sd);
         }
         const double s = sd > kDblMin ? 1 / sd : 0.;
         for (int k = 0; k < m; k++) At[i * m + k] *= s;
@@ -182,7 +205,7 @@ __device__ double dist2(const double* a, const double* b)
 // ---------------------------------------------------------------- Rodrigues
 __device__ void rodrigues_v2r(const double* r, double* R)
 {
-    const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    const double theta = sqrt_cr(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
     if (theta < kDblEps) {
         for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1. : 0.;
         return;
@@ -205,18 +228,18 @@ __device__ void rodrigues_r2v(const double* R, double* r)
             Rn[i * 3 + j] = s;
         }
     double rx = Rn[7] - Rn[5], ry = Rn[2] - Rn[6], rz = Rn[3] - Rn[1];
-    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    const double s = sqrt_cr((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (Rn[0] + Rn[4] + Rn[8] - 1) * 0.5;
     c = c > 1. ? 1. : c < -1. ? -1. : c;
     double theta = acos(c);
     if (s < 1e-5) {
         if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
         double t;
-        t = (Rn[0] + 1) * 0.5; rx = sqrt(t > 0. ? t : 0.);
-        t = (Rn[4] + 1) * 0.5; ry = sqrt(t > 0. ? t : 0.) * (Rn[1] < 0 ? -1. : 1.);
-        t = (Rn[8] + 1) * 0.5; rz = sqrt(t > 0. ? t : 0.) * (Rn[2] < 0 ? -1. : 1.);
+        t = (Rn[0] + 1) * 0.5; rx = sqrt_cr(t > 0. ? t : 0.);
+        t = (Rn[4] + 1) * 0.5; ry = sqrt_cr(t > 0. ? t : 0.) * (Rn[1] < 0 ? -1. : 1.);
+        t = (Rn[8] + 1) * 0.5; rz = sqrt_cr(t > 0. ? t : 0.) * (Rn[2] < 0 ? -1. : 1.);
         if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (Rn[5] > 0) != (ry * rz > 0)) rz = -rz;
-        theta /= sqrt(rx * rx + ry * ry + rz * rz);
+        theta /= sqrt_cr(rx * rx + ry * ry + rz * rz);
         r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
         return;
     }
@@ -235,7 +258,7 @@ __device__ void control_points(const double* c0, const double* ptp, int n, doubl
     svd3(ptp, dc, uct, vt);
     for (int j = 0; j < 3; j++) cws[0][j] = c0[j];
     for (int i = 1; i < 4; i++) {
-        const double k = sqrt(dc[i - 1] / n);
+        const double k = sqrt_cr(dc[i - 1] / n);
         for (int j = 0; j < 3; j++) cws[i][j] = c0[j] + k * uct[3 * (i - 1) + j];
     }
 }
@@ -306,9 +329,9 @@ __device__ void betas_approx_1(const double* l, const double* rho, double* betas
     }
     solve_svd6(l4, 4, rho, b4);
     if (b4[0] < 0) {
-        betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0];
+        betas[0] = sqrt_cr(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0];
     } else {
-        betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0];
+        betas[0] = sqrt_cr(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0];
     }
 }
 
@@ -318,11 +341,11 @@ __device__ void betas_approx_2(const double* l, const double* rho, double* betas
     for (int i = 0; i < 6; i++) { l3[3 * i] = l[10 * i]; l3[3 * i + 1] = l[10 * i + 1]; l3[3 * i + 2] = l[10 * i + 2]; }
     solve_svd6(l3, 3, rho, b3);
     if (b3[0] < 0) {
-        betas[0] = sqrt(-b3[0]);
-        betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
+        betas[0] = sqrt_cr(-b3[0]);
+        betas[1] = (b3[2] < 0) ? sqrt_cr(-b3[2]) : 0.0;
     } else {
-        betas[0] = sqrt(b3[0]);
-        betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
+        betas[0] = sqrt_cr(b3[0]);
+        betas[1] = (b3[2] > 0) ? sqrt_cr(b3[2]) : 0.0;
     }
     if (b3[1] < 0) betas[0] = -betas[0];
     betas[2] = 0.0; betas[3] = 0.0;
@@ -335,11 +358,11 @@ __device__ void betas_approx_3(const double* l, const double* rho, double* betas
         for (int j = 0; j < 5; j++) l5[5 * i + j] = l[10 * i + j];
     solve_svd6(l5, 5, rho, b5);
     if (b5[0] < 0) {
-        betas[0] = sqrt(-b5[0]);
-        betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+        betas[0] = sqrt_cr(-b5[0]);
+        betas[1] = (b5[2] < 0) ? sqrt_cr(-b5[2]) : 0.0;
     } else {
-        betas[0] = sqrt(b5[0]);
-        betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+        betas[0] = sqrt_cr(b5[0]);
+        betas[1] = (b5[2] > 0) ? sqrt_cr(b5[2]) : 0.0;
     }
     if (b5[1] < 0) betas[0] = -betas[0];
     betas[2] = b5[3] / betas[0];
@@ -365,7 +388,7 @@ __device__ void qr_solve(double* A, double* b, double* X)
             A[i * nc + k] *= inv_eta;
             sum2 += A[i * nc + k] * A[i * nc + k];
         }
-        double sigma = sqrt(sum2);
+        double sigma = sqrt_cr(sum2);
         if (A[k * nc + k] < 0) sigma = -sigma;
         A[k * nc + k] += sigma;
         A1[k] = sigma * A[k * nc + k];
@@ -520,7 +543,7 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
             const double inv_Zc = 1.0 / (dot3(R[2], pw) + t[2]);
             const double ue = cam.uc + cam.fu * Xc * inv_Zc, ve = cam.vc + cam.fv * Yc * inv_Zc;
             const double u = us[2 * i], v = us[2 * i + 1];
-            sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+            sum2 += sqrt_cr((u - ue) * (u - ue) + (v - ve) * (v - ve));
         }
         const double err = sum2 / n;
         if (c == 1 || err < best_err) {
@@ -854,7 +877,7 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __res
             const double Xc = dot3(Rc[c], p) + tc[c][0], Yc = dot3(Rc[c] + 3, p) + tc[c][1];
             const double inv_Zc = 1.0 / (dot3(Rc[c] + 6, p) + tc[c][2]);
             const double ue = cam.uc + cam.fu * Xc * inv_Zc, ve = cam.vc + cam.fv * Yc * inv_Zc;
-            e3[c] += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+            e3[c] += sqrt_cr((u - ue) * (u - ue) + (v - ve) * (v - ve));
         }
     }
     block_reduce<3>(e3, s_red);

@@ -195,7 +195,7 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
         extras["x1"] = np.zeros((n, 128, 128, 3), np.float32)
         extras["x2"] = np.zeros((n, K, 128, 128, 3), np.float32)
         extras["boxes2"] = np.zeros((n, 12), np.int32)
-        extras["cand"] = np.zeros((n, K, 4), np.int32)
+        extras["cand"] = np.zeros((n, K, 6), np.int32)
         opts.dbg_x1, opts.dbg_x2 = extras["x1"].ctypes.data, extras["x2"].ctypes.data
         opts.dbg_boxes2, opts.dbg_cand = extras["boxes2"].ctypes.data, extras["cand"].ctypes.data
     _lib.check(_lib.lib().p2p_est_pose_batch(ctx.handle, objs, len(objects), imgs, len(images), dets, n, poses,

@@ -56,18 +56,25 @@ def test_pnp_edge_cases():
     from oracle import pnp_oracle as O
     from pix2pose_amd.runtime import default_context, pnp_ransac_batch
     rs = np.random.RandomState(5)
-    Ks, objs, imgs, _ = _scenes(3, seed0=7, n_pts=(200, 201))
+    Ks, objs, imgs, gts = _scenes(3, seed0=7, n_pts=(200, 201))
+    # exact (noise-free) five-point set: a minimal problem is only well posed without noise (the
+    # 12x12 system then has a 2-D null space whose basis is rounding dependent)
+    R5g, t5g = gts[0][0], gts[0][1]
+    P5 = rs.uniform(-1, 1, (5, 3)) * synth.OBJ_PARAM[:3]
+    uv5 = synth.project(synth.LM_K, R5g, t5g, P5)
     # too few points; exactly five; garbage (no model); empty problem
-    objs += [objs[0][:4], objs[0][:5], rs.uniform(-40, 40, (60, 3)), np.zeros((0, 3))]
-    imgs += [imgs[0][:4], imgs[0][:5], rs.uniform(0, 640, (60, 2)), np.zeros((0, 2))]
+    objs += [objs[0][:4], P5, rs.uniform(-40, 40, (60, 3)), np.zeros((0, 3))]
+    imgs += [imgs[0][:4], uv5, rs.uniform(0, 640, (60, 2)), np.zeros((0, 2))]
     Ks += [synth.LM_K] * 4
     ok, R, t, info, _ = pnp_ransac_batch(default_context(), Ks, objs, imgs)
     assert list(ok[:3]) == [True] * 3
     assert not ok[3] and ok[4] and not ok[5] and not ok[6]
     assert info[4, 0] == 5
-    ok5, R5, t5, _, _ = O.solve_pnp_ransac(objs[4], imgs[4], synth.LM_K)
-    dt, dr = synth.pose_error(R5, t5, R[4], t[4])
-    assert ok5 and dt < 1e-6 and dr < 1e-4
+    ok5, R5, t5, _, _ = O.solve_pnp_ransac(P5, uv5, synth.LM_K)
+    assert ok5
+    for Rx, tx in ((R5, t5), (R[4], t[4])):          # float32 point storage bounds the accuracy
+        dt, dr = synth.pose_error(R5g, t5g, Rx, tx)
+        assert dt < 0.05 and dr < 0.01, (dt, dr)
     for p in (3, 5, 6):      # failure convention of recognition.py:215,219: identity, zero, -1
         np.testing.assert_array_equal(R[p], np.eye(3))
         np.testing.assert_array_equal(t[p], np.zeros(3))
