@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- the Pix2Pose hot path on MI355X: crops/sec (AE fwd + PnP-RANSAC) at 128x128.
+
+One "step" = one pass of the hot path over one batch of synthetic detections per GPU:
+BASELINE.json configs[2] -- 256 detections (128x128 crops, LM-O-like object, outlier_th
+[0.2,0.3,0.35], inlier_th 0.2): stage-1 generator pass (256 inputs), stage-2 generator pass
+(768 inputs), 768 EPnP-RANSAC solves, candidate selection.  Frames, weights and the injected
+decoder maps are resident in HBM before the timed region (SURVEY.md section 8d explains why the
+decoder outputs are injected: no trained weights exist offline; the generator passes still run
+and are timed).  `value` = detections ("crops") per second over all ranks; each costs 4 generator
+forwards (10.70 GFLOP each) + 3 PnP-RANSAC solves.
+
+Multi-GPU: one process per GPU (torchrun), detections sharded with no data-path collective; the
+final (R, t, score) records are all-gathered with RCCL inside the timed step.  Weak scaling.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+AE_GFLOP = {"resnet50": 10.70, "paper": 12.58}        # SURVEY.md section 8a-L / BASELINE.md section 2
+PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+TH_O, TH_I = [0.2, 0.3, 0.35], 0.2                     # cfg/cfg_bop2020.json:8-9
+
+
+def cpu_baseline(backbone, weights, n_sample):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores, on a bounded
+    sample of the same workload: n_sample detections = 4*n_sample generator forwards (C, OpenMP
+    over all cores) + 3*n_sample sequential OpenCV-style PnP-RANSAC solves + the numpy glue."""
+    from oracle import ae_oracle, est_pose_oracle
+    from pix2pose_amd import synthetic
+    sc = synthetic.make_scene(n_sample, seed=12345)
+
+    def run():
+        n_ok = 0
+        for i in range(n_sample):
+            def predict(x, stage, slots=None, i=i):
+                ae_oracle.forward(weights, np.asarray(x, np.float32), backbone)      # the timed network pass
+                m = sc["inject1"][i][None] if stage == 1 else sc["inject2"][i][slots]
+                return [m[..., :3].copy(), m[..., 3:].copy()]
+            img_i, _, bbox, K = sc["dets"][i]
+            out = est_pose_oracle.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], TH_O, TH_I)
+            n_ok += not (isinstance(out[4], int) and out[4] == -1)
+        return n_ok
+    ae_oracle.forward(weights, np.zeros((1, 128, 128, 3), np.float32), backbone)      # warm up / build
+    t0 = time.time()
+    run()
+    dt = time.time() - t0
+    return {"value": n_sample / dt, "unit": "crops/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d detections (= %d generator forwards + %d PnP-RANSAC solves) of the same synthetic workload, "
+                      "oracle C/numpy restatement, OpenMP over all host cores, %.1f s" % (n_sample, 4 * n_sample, 3 * n_sample, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="detections per GPU per step")
+    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--chunk", type=int, default=256, help="generator inputs per pass (activation workspace)")
+    ap.add_argument("--cpu-sample", type=int, default=6, help="detections in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-inject", action="store_true", help="let PnP consume the random-weight generator output")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pix2pose_amd import synthetic, weights as W
+    from pix2pose_amd.parallel import gather_poses, poses_to_records
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
+
+    ctx = Context(local_rank, max_batch=args.chunk)
+    wts = W.synthetic_weights(args.backbone, 1)
+    gen = Generator(wts, args.backbone, ctx)
+    spec = ObjectSpec(gen, synthetic.OBJ_PARAM, TH_O, TH_I)
+    sc = synthetic.make_scene(args.batch, seed=1000 + rank)
+    frames = torch.from_numpy(sc["images"]).cuda()
+    images = [(frames[i].data_ptr(), frames.shape[1], frames.shape[2], "u8") for i in range(frames.shape[0])]
+    inj1 = torch.from_numpy(sc["inject1"]).cuda()
+    inj2 = torch.from_numpy(sc["inject2"]).cuda()
+    torch.cuda.synchronize()
+    kw = {} if args.no_inject else dict(inject1=inj1.data_ptr(), inject2=inj2.data_ptr(), inject_slots=3)
+
+    def step():
+        poses, _ = est_pose_batch(ctx, [spec], images, sc["dets"], **kw)
+        rec = poses_to_records(poses, base_id=rank * args.batch)
+        if world > 1:
+            rec = gather_poses(rec, device=torch.device("cuda", local_rank))      # RCCL all-gather of (R,t,score)
+        return poses, rec
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        poses, rec = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    n_ok = sum(1 for p in poses if p.status == 0)
+    errs = [synthetic.pose_error(sc["gt"][i][0], sc["gt"][i][1], np.array(p.R).reshape(3, 3), np.array(p.t))
+            for i, p in enumerate(poses) if p.status == 0]
+    total = world * args.batch * args.steps
+    value = total / dt
+    s0 = stats[0]
+    ach = s0["algo_flops"] / (s0["total_ms"] * 1e-3) / 1e12 if s0["total_ms"] > 0 else 0.0
+    all_ms = sum(s["total_ms"] for s in stats)
+    out = {
+        "metric": "crops/sec (AE fwd + PnP-RANSAC) at 128x128", "value": value, "unit": "crops/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: %d detections/GPU/step, 128x128 crops, %s generator "
+                               "(1 stage-1 + 3 stage-2 forwards per detection) + 3 EPnP-RANSAC solves per detection, "
+                               "outlier_th=[0.2,0.3,0.35], injected ellipsoid-NOCS decoder maps" % (args.batch, args.backbone),
+                   "detections_per_gpu": args.batch, "backbone": args.backbone, "parallelism": "dp%d" % world,
+                   "generator_chunk": args.chunk},
+        "ae_inputs_per_s": 4 * value,
+        "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
+        "poses_ok": n_ok, "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,
+        "roofline": {"bound": "mfma", "kernel": "igemm_kernel<2,2,2,2> (128x128 tile, fp32 MFMA implicit-GEMM conv)",
+                     "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                     "avg_launch_ms": s0["total_ms"] / max(s0["launches"], 1), "launches": s0["launches"],
+                     "algo_gflop_per_launch": s0["algo_flops"] / max(s0["launches"], 1) / 1e9,
+                     "share_of_step_time": s0["total_ms"] * 1e-3 / dt, "all_igemm_share_of_step_time": all_ms * 1e-3 / dt,
+                     "traffic": None},
+    }
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(args.backbone, wts, args.cpu_sample)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,23 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
                          double confidence, double* R, double* t, int* info, int* ok,
                          unsigned char* inlier_mask);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): when enabled, every launch of the implicit-GEMM convolution
+ * kernel is bracketed by HIP events on the context stream; stats are per tile configuration
+ * (0: 128x128, 1: 128x64, 2: 128x32).  algo_flops counts the layers' algorithmic FLOPs
+ * (2 x MACs of the reference layer), not padded work.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t launches;
+    double total_ms;
+    double algo_flops;
+} p2p_kernel_stats;
+
+int p2p_profile_enable(p2p_ctx* ctx, int on);
+/* Harvest finished events (synchronises the stream) and return the accumulated stats; reset
+ * clears the accumulators afterwards.  stats must hold 3 entries. */
+int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,10 @@ class EstPoseOpts(C.Structure):
                 ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p)]
 
 
+class KernelStats(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("algo_flops", C.c_double)]
+
+
 _lib = None
 
 
@@ -89,6 +93,8 @@ def lib():
     L.p2p_forward_async.argtypes = [vp, vp, vp, ci, vp]
     L.p2p_est_pose_batch.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,
                                      C.POINTER(Pose), C.POINTER(EstPoseOpts)]
+    L.p2p_profile_enable.argtypes = [vp, ci]
+    L.p2p_profile_read.argtypes = [vp, C.POINTER(KernelStats), ci]
     dp = C.POINTER(C.c_double)
     L.p2p_pnp_ransac_batch.argtypes = [vp, dp, dp, dp, C.POINTER(ci), ci, ci, C.c_double, C.c_double, dp, dp,
                                        C.POINTER(ci), C.POINTER(ci), vp]

@@ -43,6 +43,14 @@ struct Ctx {
     float* xyz_stage = nullptr;
     float* prob_stage = nullptr;
     Pipeline* pipe = nullptr;
+    // measurement hooks (p2p_profile_*)
+    bool profiling = false;
+    struct ProfEvent { hipEvent_t a, b; int cfg; double flops; };
+    std::vector<ProfEvent> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    p2p_kernel_stats prof_stats[3] = {};
+    hipEvent_t prof_get_event();
+    int prof_harvest();
     int ensure_workspace();
     void free_pipeline();
     ~Ctx();

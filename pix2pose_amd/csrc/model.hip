@@ -348,10 +348,12 @@ struct ConvCall {
     int mode = EPI_NORMAL;
     int ksplit = 1;
     float* partial = nullptr;
+    double algo_macs = -1;   // algorithmic MACs of this launch; < 0 => M * Cout * K (no padded work)
 };
 
-static int run_conv(hipStream_t st, const ConvLayer& L, const ConvCall& c)
+static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
 {
+    hipStream_t st = X.stream;
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.seg[0] = {c.s0.ptr, c.s0.C, c.s0.cstride, c.s0.coff};
@@ -379,12 +381,22 @@ static int run_conv(hipStream_t st, const ConvLayer& L, const ConvCall& c)
     p.out_cstride = c.out_cstride; p.out_coff = c.out_coff;
     p.mode = c.mode;
     const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? 1 : 2);
+    if (X.profiling) {
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), cfg,
+                          2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
+        if (!ev.a || !ev.b) return P2P_ERR_HIP;
+        HIP_TRY(hipEventRecord(ev.a, st));
+        HIP_TRY(launch_igemm(p, cfg, st));
+        HIP_TRY(hipEventRecord(ev.b, st));
+        X.prof_pending.push_back(ev);
+        return P2P_OK;
+    }
     HIP_TRY(launch_igemm(p, cfg, st));
     return P2P_OK;
 }
 
 // stride-1/2 Conv2D on a full tensor `in` [N,H,W,C] -> out [N,H/s,W/s,Cout]
-static int conv_layer(hipStream_t st, const ConvLayer& L, const float* in, int N, int H, int W, int C, int stride,
+static int conv_layer(Ctx& X, const ConvLayer& L, const float* in, int N, int H, int W, int C, int stride,
                       float* out, int act, const float* residual = nullptr)
 {
     ConvCall c;
@@ -392,11 +404,11 @@ static int conv_layer(hipStream_t st, const ConvLayer& L, const float* in, int N
     c.N = N; c.Hin = H; c.Win = W; c.Hg = H / stride; c.Wg = W / stride; c.in_stride = stride;
     c.out = out; c.Hout = c.Hg; c.Wout = c.Wg; c.out_cstride = L.Cout;
     c.act = act; c.residual = residual; c.res_cstride = L.Cout;
-    return run_conv(st, L, c);
+    return run_conv(X, L, c);
 }
 
 // 5x5 stride-1 'SAME' conv over the concatenation [a (Ca ch) || b[..., :Cb] (pixel stride cb_stride)]
-static int concat_conv(hipStream_t st, const ConvLayer& L, const float* a, int Ca, const float* b, int Cb,
+static int concat_conv(Ctx& X, const ConvLayer& L, const float* a, int Ca, const float* b, int Cb,
                        int cb_stride, int cb_off, int N, int H, float* out)
 {
     ConvCall c;
@@ -405,11 +417,11 @@ static int concat_conv(hipStream_t st, const ConvLayer& L, const float* a, int C
     c.N = N; c.Hin = H; c.Win = H; c.Hg = H; c.Wg = H;
     c.out = out; c.Hout = H; c.Wout = H; c.out_cstride = L.Cout;
     c.act = ACT_LEAKY;
-    return run_conv(st, L, c);
+    return run_conv(X, L, c);
 }
 
 // Conv2DTranspose 5x5/2 + BN + LeakyReLU as four phase convolutions
-static int deconv_layer(hipStream_t st, const Model& M, const char* name, const float* in, int N, int H, int C,
+static int deconv_layer(Ctx& X, const Model& M, const char* name, const float* in, int N, int H, int C,
                         float* out)
 {
     for (int ph = 0; ph < 4; ++ph) {
@@ -420,27 +432,27 @@ static int deconv_layer(hipStream_t st, const Model& M, const char* name, const 
         c.out = out; c.Hout = 2 * H; c.Wout = 2 * H; c.os = 2; c.oy = ph >> 1; c.ox = ph & 1;
         c.out_cstride = L.Cout;
         c.act = ACT_LEAKY;
-        int rc = run_conv(st, L, c);
+        int rc = run_conv(X, L, c);
         if (rc) return rc;
     }
     return P2P_OK;
 }
 
-static int res_block(hipStream_t st, const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H,
+static int res_block(const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H,
                      int Cin, int f1, int stride, bool shortcut, float* out)
 {
     int rc;
     const int Ho = H / stride;
     float* ta = X.act["t_a"];
     float* tb = X.act["t_b"];
-    if ((rc = conv_layer(st, M.L.at(n + "_2a"), in, N, H, H, Cin, stride, ta, ACT_RELU))) return rc;
-    if ((rc = conv_layer(st, M.L.at(n + "_2b"), ta, N, Ho, Ho, f1, 1, tb, ACT_RELU))) return rc;
+    if ((rc = conv_layer(X, M.L.at(n + "_2a"), in, N, H, H, Cin, stride, ta, ACT_RELU))) return rc;
+    if ((rc = conv_layer(X, M.L.at(n + "_2b"), ta, N, Ho, Ho, f1, 1, tb, ACT_RELU))) return rc;
     const float* res = in;
     if (shortcut) {
-        if ((rc = conv_layer(st, M.L.at(n + "_1"), in, N, H, H, Cin, stride, X.act["sc"], ACT_NONE))) return rc;
+        if ((rc = conv_layer(X, M.L.at(n + "_1"), in, N, H, H, Cin, stride, X.act["sc"], ACT_NONE))) return rc;
         res = X.act["sc"];
     }
-    return conv_layer(st, M.L.at(n + "_2c"), tb, N, Ho, Ho, f1, 1, out, ACT_RELU, res);
+    return conv_layer(X, M.L.at(n + "_2c"), tb, N, Ho, Ho, f1, 1, out, ACT_RELU, res);
 }
 
 // x_dev [n,128,128,3] -> xyzp_dev [n,128,128,4]; n <= ctx.max_batch
@@ -455,14 +467,14 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         const ConvLayer& c1 = M.L.at("conv1");
         HIP_TRY(launch_conv_first(x, n, 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift, ACT_RELU, LEAKY, A["f1"], 64, 64, st));
         HIP_TRY(launch_maxpool3s2(A["f1"], n, 64, 64, 64, A["p1"], st));
-        if ((rc = res_block(st, M, X, "res2a", A["p1"], n, 32, 64, 64, 1, true, A["o_a"]))) return rc;
-        if ((rc = res_block(st, M, X, "res2b", A["o_a"], n, 32, 256, 64, 1, false, A["o_b"]))) return rc;
-        if ((rc = res_block(st, M, X, "res2c", A["o_b"], n, 32, 256, 64, 1, false, A["f2"]))) return rc;
-        if ((rc = res_block(st, M, X, "res3a", A["f2"], n, 32, 256, 128, 2, true, A["o_a"]))) return rc;
-        if ((rc = res_block(st, M, X, "res3b", A["o_a"], n, 16, 512, 128, 1, false, A["o_b"]))) return rc;
-        if ((rc = res_block(st, M, X, "res3c", A["o_b"], n, 16, 512, 128, 1, false, A["o_a"]))) return rc;
-        if ((rc = res_block(st, M, X, "res3d", A["o_a"], n, 16, 512, 128, 1, false, A["f3"]))) return rc;
-        if ((rc = conv_layer(st, M.L.at("conv4"), A["f3"], n, 16, 16, 512, 2, A["f4"], ACT_LEAKY))) return rc;
+        if ((rc = res_block(M, X, "res2a", A["p1"], n, 32, 64, 64, 1, true, A["o_a"]))) return rc;
+        if ((rc = res_block(M, X, "res2b", A["o_a"], n, 32, 256, 64, 1, false, A["o_b"]))) return rc;
+        if ((rc = res_block(M, X, "res2c", A["o_b"], n, 32, 256, 64, 1, false, A["f2"]))) return rc;
+        if ((rc = res_block(M, X, "res3a", A["f2"], n, 32, 256, 128, 2, true, A["o_a"]))) return rc;
+        if ((rc = res_block(M, X, "res3b", A["o_a"], n, 16, 512, 128, 1, false, A["o_b"]))) return rc;
+        if ((rc = res_block(M, X, "res3c", A["o_b"], n, 16, 512, 128, 1, false, A["o_a"]))) return rc;
+        if ((rc = res_block(M, X, "res3d", A["o_a"], n, 16, 512, 128, 1, false, A["f3"]))) return rc;
+        if ((rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 512, 2, A["f4"], ACT_LEAKY))) return rc;
         // ae_model.py:186-188: f1[..., :32], f2[..., :128], f3[..., :128]
         s1 = A["f1"]; s1_stride = 64; s1_off = 0; s1_C = 32;
         s2 = A["f2"]; s2_stride = 256; s2_off = 0;
@@ -472,9 +484,9 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         // the skip is the _2 half, i.e. the upper channels of the merged output.
         const ConvLayer& c1 = M.L.at("conv1");
         HIP_TRY(launch_conv_first(x, n, 128, 128, c1.w, 5, 2, 1, 128, c1.scale, c1.shift, ACT_LEAKY, LEAKY, A["f1"], 64, 64, st));
-        if ((rc = conv_layer(st, M.L.at("conv2"), A["f1"], n, 64, 64, 128, 2, A["f2"], ACT_LEAKY))) return rc;
-        if ((rc = conv_layer(st, M.L.at("conv3"), A["f2"], n, 32, 32, 256, 2, A["f3"], ACT_LEAKY))) return rc;
-        if ((rc = conv_layer(st, M.L.at("conv4"), A["f3"], n, 16, 16, 256, 2, A["f4"], ACT_LEAKY))) return rc;
+        if ((rc = conv_layer(X, M.L.at("conv2"), A["f1"], n, 64, 64, 128, 2, A["f2"], ACT_LEAKY))) return rc;
+        if ((rc = conv_layer(X, M.L.at("conv3"), A["f2"], n, 32, 32, 256, 2, A["f3"], ACT_LEAKY))) return rc;
+        if ((rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 256, 2, A["f4"], ACT_LEAKY))) return rc;
         s1 = A["f1"]; s1_stride = 128; s1_off = 64; s1_C = 64;
         s2 = A["f2"]; s2_stride = 256; s2_off = 128;
         s3 = A["f3"]; s3_stride = 256; s3_off = 128;
@@ -487,7 +499,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         c.N = n; c.Hin = c.Win = c.Hg = c.Wg = 1;
         c.out = A["enc"]; c.Hout = c.Wout = 1; c.out_cstride = 256;
         c.ksplit = 32; c.partial = A["part"];
-        if ((rc = run_conv(st, L, c))) return rc;
+        if ((rc = run_conv(X, L, c))) return rc;
         HIP_TRY(launch_splitk_reduce(A["part"], 32, n, 256, L.scale, L.shift, ACT_NONE, LEAKY, A["enc"], st));
     }
     {
@@ -496,21 +508,22 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         c.s0 = {A["enc"], 256, 256, 0};
         c.N = n; c.Hin = c.Win = c.Hg = c.Wg = 1;
         c.out = A["dd"]; c.Hout = c.Wout = 1; c.out_cstride = 16384;
-        if ((rc = run_conv(st, L, c))) return rc;
+        if ((rc = run_conv(X, L, c))) return rc;
     }
-    if ((rc = deconv_layer(st, M, "up1", A["dd"], n, 8, 256, A["u1"]))) return rc;
-    if ((rc = concat_conv(st, M.L.at("deconv1"), A["u1"], 256, s3, 128, s3_stride, s3_off, n, 16, A["c1"]))) return rc;
-    if ((rc = deconv_layer(st, M, "up2", A["c1"], n, 16, 256, A["u2"]))) return rc;
-    if ((rc = concat_conv(st, M.L.at("deconv2"), A["u2"], 128, s2, 128, s2_stride, s2_off, n, 32, A["c2"]))) return rc;
-    if ((rc = deconv_layer(st, M, "up3", A["c2"], n, 32, 256, A["u3"]))) return rc;
-    if ((rc = concat_conv(st, M.L.at("deconv3"), A["u3"], 64, s1, s1_C, s1_stride, s1_off, n, 64, A["c3"]))) return rc;
+    if ((rc = deconv_layer(X, M, "up1", A["dd"], n, 8, 256, A["u1"]))) return rc;
+    if ((rc = concat_conv(X, M.L.at("deconv1"), A["u1"], 256, s3, 128, s3_stride, s3_off, n, 16, A["c1"]))) return rc;
+    if ((rc = deconv_layer(X, M, "up2", A["c1"], n, 16, 256, A["u2"]))) return rc;
+    if ((rc = concat_conv(X, M.L.at("deconv2"), A["u2"], 128, s2, 128, s2_stride, s2_off, n, 32, A["c2"]))) return rc;
+    if ((rc = deconv_layer(X, M, "up3", A["c2"], n, 32, 256, A["u3"]))) return rc;
+    if ((rc = concat_conv(X, M.L.at("deconv3"), A["u3"], 64, s1, s1_C, s1_stride, s1_off, n, 64, A["c3"]))) return rc;
     {
         ConvCall c;
         c.s0 = {A["c3"], 128, 128, 0};
         c.N = n; c.Hin = c.Win = c.Hg = c.Wg = 64;
         c.out = xyzp; c.Hout = c.Wout = 128; c.os = 2; c.out_cstride = 4;
         c.mode = EPI_HEAD;
-        if ((rc = run_conv(st, M.L.at("heads"), c))) return rc;
+        c.algo_macs = (double)n * 64 * 64 * 25 * 128 * 4;   // two Conv2DTranspose heads, 5x5 taps, 3+1 channels
+        if ((rc = run_conv(X, M.L.at("heads"), c))) return rc;
     }
     return P2P_OK;
 }
@@ -527,6 +540,30 @@ int forward_async(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp
     return P2P_OK;
 }
 
+hipEvent_t Ctx::prof_get_event()
+{
+    if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); return nullptr; }
+    return e;
+}
+
+int Ctx::prof_harvest()
+{
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (const ProfEvent& ev : prof_pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        prof_stats[ev.cfg].launches += 1;
+        prof_stats[ev.cfg].total_ms += ms;
+        prof_stats[ev.cfg].algo_flops += ev.flops;
+        prof_pool.push_back(ev.a);
+        prof_pool.push_back(ev.b);
+    }
+    prof_pending.clear();
+    return P2P_OK;
+}
+
 Model::~Model()
 {
     for (auto& kv : L) free_layer(kv.second);
@@ -540,6 +577,8 @@ Ctx::~Ctx()
     if (xyz_stage) hipFree(xyz_stage);
     if (prob_stage) hipFree(prob_stage);
     free_pipeline();
+    for (auto& ev : prof_pending) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (auto e : prof_pool) hipEventDestroy(e);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -596,6 +635,25 @@ int p2p_ctx_synchronize(p2p_ctx* ctx)
 }
 
 void* p2p_ctx_stream(p2p_ctx* ctx) { return ctx ? (void*)reinterpret_cast<Ctx*>(ctx)->stream : nullptr; }
+
+int p2p_profile_enable(p2p_ctx* ctx, int on)
+{
+    if (!ctx) { set_error("null ctx"); return P2P_ERR_INVALID_ARG; }
+    reinterpret_cast<Ctx*>(ctx)->profiling = on != 0;
+    return P2P_OK;
+}
+
+int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset)
+{
+    if (!ctx || !stats) { set_error("p2p_profile_read: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->prof_harvest();
+    if (rc) return rc;
+    for (int i = 0; i < 3; ++i) stats[i] = c->prof_stats[i];
+    if (reset) for (int i = 0; i < 3; ++i) c->prof_stats[i] = p2p_kernel_stats{};
+    return P2P_OK;
+}
 
 int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone, p2p_model** out)
 {
