@@ -168,6 +168,13 @@ typedef struct {
     float* dbg_x2;
     int* dbg_boxes2;            /* [n_det][12] stage-2 get_boxes result */
     int* dbg_cand;              /* [n_det][K][6]: valid, n_non_gray, n_corr, n_inliers, ransac iters, best iter */
+    /* score_type 2 support (reference tools/5_evaluation_bop_basic.py:307-316): per-detection
+     * detector masks, host pointer [n_det][det_mask_stride] bytes (non-zero = object), same H x W
+     * as the detection's frame; mask_stats (host, [n_det][3]) receives
+     * {intersection, union, valid_mask pixel count} of the detector mask with valid_mask_full. */
+    const unsigned char* det_mask;
+    int64_t det_mask_stride;
+    int64_t* mask_stats;
 } p2p_est_pose_opts;
 
 /* Blocking.  poses[i] corresponds to dets[i]. */

@@ -51,7 +51,8 @@ class EstPoseOpts(C.Structure):
                 ("inject1", C.c_void_p), ("inject2", C.c_void_p), ("inject_slots", C.c_int),
                 ("valid_mask", C.c_void_p), ("mask_stride", C.c_int64), ("img_pred", C.c_void_p),
                 ("pred_stride", C.c_int64), ("dbg_x1", C.c_void_p), ("dbg_x2", C.c_void_p),
-                ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p)]
+                ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p),
+                ("det_mask", C.c_void_p), ("det_mask_stride", C.c_int64), ("mask_stats", C.c_void_p)]
 
 
 class KernelStats(C.Structure):

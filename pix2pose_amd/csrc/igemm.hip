@@ -176,44 +176,73 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p)
         cur ^= 1;
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // ---- epilogue.  The accumulator tile is transposed through LDS (the staging buffers are
+    //      free after the last barrier) so that every thread then owns 4 consecutive channels of
+    //      one pixel: scale/shift, the residual and the output move as float4, and a 128-channel
+    //      pixel row is one contiguous 512-byte store.  (Lane-per-channel dword stores left the
+    //      1x1 ResNet-front layers epilogue-bound at ~1.2 TB/s.)
+    //      C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    constexpr int CLD = BN + 4;
+    static_assert(BM * CLD <= 2 * (BM + BN) * LDS_LD, "C tile must fit the staging buffers");
+    float* Cs = smem;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + li;
-        const bool cok = col < p.Cout;
-        if (p.ksplit > 1) {
-            float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (cok && m < p.M) part[(size_t)m * p.Cout + col] = acc[i][j][r];
-                }
-            continue;
-        }
-        const float sc = (cok && p.scale) ? p.scale[col] : 1.f;
-        const float sh = (cok && p.shift) ? p.shift[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int op = row_out[row];
-                if (!cok || op < 0) continue;
-                float v = fmaf(acc[i][j][r], sc, sh);
-                if (p.mode == EPI_HEAD) {
-                    // col = phase*4 + ch; phase = py*2 + px; ch 0..2 -> tanh (XYZ), ch 3 -> sigmoid (error)
-                    const int ch = col & 3, ph = col >> 2;
-                    const size_t o = (size_t)(op + (ph >> 1) * p.Wout + (ph & 1)) * 4 + ch;
-                    p.out[o] = ch < 3 ? tanhf(v) : 1.f / (1.f + __expf(-v));
-                } else {
-                    if (p.residual) v += p.residual[(size_t)op * p.res_cstride + col];
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : v * p.alpha;
-                    p.out[(size_t)op * p.out_cstride + p.out_coff + col] = v;
-                }
+                Cs[row * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
             }
+    __syncthreads();
+
+    constexpr int TPR = BN / 4;            // threads per pixel row
+    constexpr int RPP = 256 / TPR;         // rows per pass
+    const int c4 = (tid % TPR) * 4;
+    const int col = n0 + c4;
+    const int r0 = tid / TPR;
+    if (col >= p.Cout) return;             // Cout is a multiple of 4 on this path
+    if (p.ksplit > 1) {
+        float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+#pragma unroll 4
+        for (int r = r0; r < BM; r += RPP) {
+            const int m = m0 + r;
+            if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + col) = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+        }
+        return;
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+    for (int r = r0; r < BM; r += RPP) {
+        const int op = row_out[r];
+        if (op < 0) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        if (p.mode == EPI_HEAD) {
+            // col = phase*4 + ch: this thread holds (x, y, z, prob) of output pixel (2gy+py, 2gx+px)
+            const int ph = col >> 2;
+            f32x4 o;
+            o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
+            o[3] = 1.f / (1.f + __expf(-v[3]));
+            *reinterpret_cast<f32x4*>(p.out + (size_t)(op + (ph >> 1) * p.Wout + (ph & 1)) * 4) = o;
+        } else {
+            if (p.residual) {
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)op * p.res_cstride + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rs[e];
+            }
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+            }
+            *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
+        }
     }
 }
 

@@ -81,7 +81,7 @@ struct DevBuf {
 };
 
 struct Pipeline {
-    DevBuf det, s1, cand, probs, results, poses, x1, y1, x2, y2, corr, images, mask, pred;
+    DevBuf det, s1, cand, probs, results, poses, x1, y1, x2, y2, corr, images, mask, pred, dmask, mstat;
     ~Pipeline();
 };
 

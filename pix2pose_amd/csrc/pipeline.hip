@@ -50,7 +50,7 @@ void DevBuf::release()
 }
 Pipeline::~Pipeline()
 {
-    for (DevBuf* b : {&det, &s1, &cand, &probs, &results, &poses, &x1, &y1, &x2, &y2, &corr, &images, &mask, &pred}) b->release();
+    for (DevBuf* b : {&det, &s1, &cand, &probs, &results, &poses, &x1, &y1, &x2, &y2, &corr, &images, &mask, &pred, &dmask, &mstat}) b->release();
 }
 void Ctx::free_pipeline()
 {
@@ -516,6 +516,48 @@ __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// score_type 2: |det_mask AND valid_mask|, |det_mask OR valid_mask| (reference
+// tools/5_evaluation_bop_basic.py:307-316).  valid_mask_full is zero outside the selected
+// candidate's clipped box, so: union = |det_mask| + |valid| - inter, with |det_mask| over the frame.
+// stats[d] = {inter, det_count, valid_count}
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
+                                                       const p2p_pose* __restrict__ poses, const float* __restrict__ y2, int K,
+                                                       const unsigned char* __restrict__ det_mask, long long stride,
+                                                       unsigned long long* __restrict__ stats)
+{
+    const int d = blockIdx.y;
+    const DetInfo& D = dets[d];
+    const unsigned char* dm = det_mask + (size_t)d * stride;
+    unsigned long long inter = 0, dcount = 0, vcount = 0;
+    const long long npx = (long long)D.H * D.W;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npx; p += (long long)gridDim.x * 256) dcount += dm[p] != 0;
+    const p2p_pose& P = poses[d];
+    if (P.status == P2P_POSE_OK) {
+        const Boxes& b = s1[d].b2;
+        const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
+        const int h = b.v2 - b.v1, w = b.u2 - b.u1;
+        const float* y2c = y2 + (size_t)(d * K + P.best_slot) * 16384 * 4;
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
+            const int rr = p / w, cc = p - rr * w;
+            const CandPixel cp = cand_pixel(y2c, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+            if (cp.valid) {
+                ++vcount;
+                inter += dm[(size_t)(b.v1 + rr) * D.W + (b.u1 + cc)] != 0;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        inter += __shfl_down(inter, off, 64); dcount += __shfl_down(dcount, off, 64); vcount += __shfl_down(vcount, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (inter) atomicAdd(&stats[3 * d], inter);
+        if (dcount) atomicAdd(&stats[3 * d + 1], dcount);
+        if (vcount) atomicAdd(&stats[3 * d + 2], vcount);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
 static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
@@ -690,6 +732,23 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         if (opt.valid_mask) { hmask.resize((size_t)opt.mask_stride * n); HIP_TRY(hipMemcpyAsync(hmask.data(), P.mask.p, hmask.size(), hipMemcpyDeviceToHost, st)); }
         if (opt.img_pred) { hpred.resize((size_t)opt.pred_stride * n); HIP_TRY(hipMemcpyAsync(hpred.data(), P.pred.p, hpred.size(), hipMemcpyDeviceToHost, st)); }
     }
+    std::vector<unsigned long long> hstat;
+    if (opt.det_mask && opt.mask_stats) {
+        for (int i = 0; i < n; ++i)
+            if ((long long)hd[i].H * hd[i].W > opt.det_mask_stride) { set_error("det_mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
+        if ((rc = P.dmask.reserve((size_t)opt.det_mask_stride * n))) return rc;
+        if ((rc = P.mstat.reserve(sizeof(unsigned long long) * 3 * n))) return rc;
+        for (int i = 0; i < n; ++i)      // caller order -> sorted order
+            HIP_TRY(hipMemcpyAsync(P.dmask.as<unsigned char>() + (size_t)i * opt.det_mask_stride,
+                                   opt.det_mask + (size_t)perm[i] * opt.det_mask_stride, (size_t)hd[i].H * hd[i].W,
+                                   hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(P.mstat.p, 0, sizeof(unsigned long long) * 3 * n, st));
+        hipLaunchKernelGGL(mask_iou_kernel, dim3(32, n), dim3(256), 0, st, d_det, d_s1, P.poses.as<p2p_pose>(), y2, K,
+                           P.dmask.as<unsigned char>(), (long long)opt.det_mask_stride, P.mstat.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        hstat.resize((size_t)3 * n);
+        HIP_TRY(hipMemcpyAsync(hstat.data(), P.mstat.p, sizeof(unsigned long long) * 3 * n, hipMemcpyDeviceToHost, st));
+    }
     std::vector<float> hx1, hx2;
     std::vector<Stage1> hs1;
     std::vector<CandStat> hcs;
@@ -709,6 +768,10 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         poses[o] = hp[i];
         if (opt.valid_mask) memcpy(opt.valid_mask + (size_t)o * opt.mask_stride, hmask.data() + (size_t)i * opt.mask_stride, opt.mask_stride);
         if (opt.img_pred) memcpy(opt.img_pred + (size_t)o * opt.pred_stride, hpred.data() + (size_t)i * opt.pred_stride, opt.pred_stride);
+        if (!hstat.empty()) {
+            const long long inter = (long long)hstat[3 * i], dc = (long long)hstat[3 * i + 1], vc = (long long)hstat[3 * i + 2];
+            opt.mask_stats[3 * o] = inter; opt.mask_stats[3 * o + 1] = dc + vc - inter; opt.mask_stats[3 * o + 2] = vc;
+        }
         if (opt.dbg_x1) memcpy(opt.dbg_x1 + (size_t)o * 16384 * 3, hx1.data() + (size_t)i * 16384 * 3, 16384 * 3 * 4);
         if (opt.dbg_x2) memcpy(opt.dbg_x2 + (size_t)o * K * 16384 * 3, hx2.data() + (size_t)i * K * 16384 * 3, (size_t)K * 16384 * 3 * 4);
         if (opt.dbg_boxes2) memcpy(opt.dbg_boxes2 + (size_t)o * 12, &hs1[i].b2, sizeof(Boxes));

@@ -1,0 +1,232 @@
+"""Counterpart of the reference's RGB-only BOP evaluation driver (tools/5_evaluation_bop_basic.py)
+for the MI355X hot path -- SURVEY.md section 8f-1.
+
+Same contract where it touches the hot path: argv ``[gpu_id] [cfg] [dataset]``, the cfg keys
+(``backbone``, ``outlier_th`` 1-D => per-detection multi-threshold / 2-D => one fixed threshold per
+object, ``inlier_th``, ``score_type``, ``task_type``, ``cand_factor``, ``path_to_output``), per-image
+``camK``, candidate limiting, score_type-2 score ``det_score * frac_inlier * mask_iou * union``,
+per-image score normalisation + sort + ViVo truncation, and the bop19 CSV
+``pix2pose-iccv19_<dataset>-test.csv``.
+
+What differs: the 2D detector is an external repo and out of scope, so detections arrive
+*pre-dumped* (BASELINE.json configs[4]: "Mask-RCNN boxes pre-dumped"); and detections of many
+images are pooled into one device batch instead of one est_pose call each.
+
+Pre-dumped detections file (JSON)::
+
+    {"im_size": [W, H], "model_ids": [1, 5, ...],
+     "norm_factor": {"1": {"x_scale":..,"y_scale":..,"z_scale":..,"x_ct":..,"y_ct":..,"z_ct":..}, ...},
+     "weights": {"1": "path/to/obj01.npz" | "synthetic:resnet50:1", ...},
+     "targets": [{"scene_id":..,"im_id":..,"obj_id":..,"inst_count":..}, ...],      # test_targets_bop19.json
+     "images": [{"scene_id":..,"im_id":..,"rgb": "frame.npy|.png", "cam_K": [9 floats],
+                 "rois": [[v1,u1,v2,u2], ...], "obj_ids": [...], "scores": [...], "masks": "masks.npy" (optional, [H,W,n])}]}
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------- config
+def model_params_to_obj_param(mp: dict) -> np.ndarray:
+    """tools/bop_io.py:33-42: [x_scale, y_scale, z_scale, x_ct, y_ct, z_ct]."""
+    return np.array([mp["x_scale"], mp["y_scale"], mp["z_scale"], mp["x_ct"], mp["y_ct"], mp["z_ct"]], np.float64)
+
+
+def outlier_thresholds(cfg: dict, n_models: int):
+    """tools/5_evaluation_bop_basic.py:164-169,217-219: a 1-D list is shared by every object
+    (multi-threshold stage 2); a 2-D list gives one fixed threshold per object."""
+    th = cfg["outlier_th"]
+    if isinstance(th[0], list):
+        per = np.squeeze(np.array(th))
+        return [[float(per[m])] for m in range(n_models)]
+    return [[float(t) for t in th] for _ in range(n_models)]
+
+
+def group_targets(targets):
+    """tools/bop_io.py:9-31 get_target_list: consecutive targets of one image are grouped."""
+    out = []
+    prev = None
+    for tg in targets:
+        key = (tg["scene_id"], tg["im_id"])
+        if key != prev:
+            out.append([tg["scene_id"], tg["im_id"], [], []])
+            prev = key
+        out[-1][2].append(tg["obj_id"])
+        out[-1][3].append(tg["inst_count"])
+    return out
+
+
+# ---------------------------------------------------------------------------------- per-image logic
+def select_detections(rois, obj_ids, obj_id_targets, inst_counts, cand_factor):
+    """tools/5_evaluation_bop_basic.py:289-300: skip (-1,-1) rois and non-target objects; stop
+    taking candidates of an object once more than inst_count*cand_factor were taken."""
+    pred = np.zeros(len(inst_counts))
+    keep = []
+    for r_id, roi in enumerate(rois):
+        if roi[0] == -1 and roi[1] == -1:
+            continue
+        obj_id = obj_ids[r_id]
+        if obj_id not in obj_id_targets:
+            continue
+        g = obj_id_targets.index(obj_id)
+        if pred[g] > inst_counts[g] * cand_factor:
+            continue
+        pred[g] += 1
+        keep.append(r_id)
+    return keep
+
+
+def detection_score(det_score, frac_inlier, mask_stats, score_type, detect_type="rcnn"):
+    """:307-318.  mask_stats = (intersection, union) of the detector mask with valid_mask_full."""
+    if score_type == 2 and detect_type == "rcnn":
+        inter, union = mask_stats
+        mask_iou = 0 if union <= 0 else inter / union
+        return det_score * frac_inlier * mask_iou * union
+    return det_score
+
+
+def rank_image_results(results, obj_id_targets, inst_counts, task_type, scene_id, im_id, time_spend):
+    """:325-349.  results: list of dict(obj_id, score, R, t).  Normalise by the max score, sort
+    descending, apply the ViVo instance limits (only when task_type is the *string* '2', exactly as
+    the reference compares it)."""
+    if not results:
+        return []
+    score = np.array([r["score"] for r in results], np.float64)
+    score = score / np.max(score)
+    order = np.argsort(1 - score)
+    est = np.zeros(len(inst_counts))
+    total, n_inst = 0, np.sum(inst_counts)
+    rows = []
+    for rid in order:
+        r = results[rid]
+        g = obj_id_targets.index(r["obj_id"])
+        est[g] += 1
+        if task_type == '2' and est[g] > inst_counts[g]:
+            continue
+        rows.append({"scene_id": scene_id, "im_id": im_id, "obj_id": r["obj_id"], "score": score[rid],
+                     "R": np.asarray(r["R"]).flatten(), "t": np.asarray(r["t"]).flatten(), "time": time_spend})
+        total += 1
+        if task_type == '2' and total > n_inst:
+            break
+    return rows
+
+
+def save_bop_results(path, rows):
+    """bop_toolkit inout.save_bop_results, version 'bop19' (un-vendored; format per SURVEY 8f-1):
+    scene_id,im_id,obj_id,score,R,t,time with R (9) and t (3, mm) space separated."""
+    lines = ["scene_id,im_id,obj_id,score,R,t,time"]
+    for r in rows:
+        lines.append("{},{},{},{},{},{},{}".format(r["scene_id"], r["im_id"], r["obj_id"], r["score"],
+                                                   " ".join(map(str, np.asarray(r["R"]).flatten().tolist())),
+                                                   " ".join(map(str, np.asarray(r["t"]).flatten().tolist())),
+                                                   r.get("time", -1)))
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
+def output_name(dataset):
+    """:353-356."""
+    return "pix2pose-iccv19_%s-test-primesense.csv" % dataset if dataset == "tless" else "pix2pose-iccv19_%s-test.csv" % dataset
+
+
+def _load_frame(path):
+    if path.endswith(".npy"):
+        return np.load(path)
+    try:
+        from PIL import Image
+    except ImportError as e:  # pragma: no cover
+        raise RuntimeError("reading %s needs Pillow; dump frames as .npy instead" % path) from e
+    a = np.array(Image.open(path))
+    if a.ndim == 2:                      # gray datasets: copy to three channels (:260-266)
+        a = np.repeat(a[:, :, None], 3, axis=2)
+    return a[:, :, :3]
+
+
+# ---------------------------------------------------------------------------------- driver
+def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".", batch_images: int = 32,
+        detect_type: str = "rcnn", est_pose_kwargs=None):
+    """Evaluate a pre-dumped detection stream.  Returns the result rows (also written as CSV when
+    cfg['path_to_output'] is set)."""
+    from . import runtime, weights as W
+    backbone = cfg.get("backbone", "paper")                                   # :202-205
+    model_ids = list(dump["model_ids"])
+    th_o = outlier_thresholds(cfg, len(model_ids))
+    th_i = cfg["inlier_th"]
+    score_type, task_type, cand_factor = cfg["score_type"], cfg["task_type"], float(cfg["cand_factor"])
+    ctx = runtime.Context(device, max_batch=int(cfg.get("generator_chunk", 256)))
+    specs = []
+    for m, mid in enumerate(model_ids):                                       # one network per object (:206-225)
+        wfn = dump["weights"][str(mid)]
+        if not wfn.startswith("synthetic:"):
+            wfn = os.path.join(base_dir, wfn)
+        gen = runtime.Generator(W.load_weights(wfn, backbone), backbone, ctx)
+        specs.append(runtime.ObjectSpec(gen, model_params_to_obj_param(dump["norm_factor"][str(mid)]), th_o[m], th_i))
+    by_image = {(im["scene_id"], im["im_id"]): im for im in dump["images"]}
+    rows = []
+    tlist = group_targets(dump["targets"])
+    for b0 in range(0, len(tlist), batch_images):
+        chunk = tlist[b0:b0 + batch_images]
+        frames, dets, det_masks, owners = [], [], [], []
+        t1 = time.time()
+        for ti, (scene_id, im_id, obj_id_targets, inst_counts) in enumerate(chunk):
+            im = by_image.get((scene_id, im_id))
+            if im is None:
+                continue
+            frame = _load_frame(os.path.join(base_dir, im["rgb"]))
+            masks = np.load(os.path.join(base_dir, im["masks"])) if im.get("masks") else None
+            fi = len(frames)
+            frames.append(frame)
+            for r_id in select_detections(im["rois"], im["obj_ids"], obj_id_targets, inst_counts, cand_factor):
+                dets.append((fi, model_ids.index(im["obj_ids"][r_id]), [int(v) for v in im["rois"][r_id]], np.array(im["cam_K"], float).reshape(3, 3)))
+                owners.append((ti, r_id))
+                if score_type == 2 and detect_type == "rcnn":
+                    if masks is None:
+                        raise ValueError("score_type 2 needs detector masks for scene %s image %s" % (scene_id, im_id))
+                    det_masks.append(masks[:, :, r_id])
+        if not dets:
+            continue
+        poses, ex = runtime.est_pose_batch(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
+                                           **(est_pose_kwargs or {}))
+        dt = time.time() - t1
+        per_image = {}
+        for k, (ti, r_id) in enumerate(owners):
+            p = poses[k]
+            if p.status != 0:                                                 # frac_inlier == -1 (:305-306)
+                continue
+            scene_id, im_id, _, _ = chunk[ti]
+            im = by_image[(scene_id, im_id)]
+            ms = (int(ex["mask_stats"][k, 0]), int(ex["mask_stats"][k, 1])) if "mask_stats" in ex else None
+            sc = detection_score(im["scores"][r_id], p.frac_inlier, ms, score_type, detect_type)
+            per_image.setdefault(ti, []).append({"obj_id": im["obj_ids"][r_id], "score": sc,
+                                                 "R": np.array(p.R).reshape(3, 3), "t": np.array(p.t)})
+        for ti, (scene_id, im_id, obj_id_targets, inst_counts) in enumerate(chunk):
+            n_here = sum(1 for o in owners if o[0] == ti)
+            rows += rank_image_results(per_image.get(ti, []), obj_id_targets, inst_counts, task_type, scene_id, im_id,
+                                       dt * n_here / max(len(owners), 1))    # batch time amortised over its detections
+    out_dir = cfg.get("path_to_output")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        save_bop_results(os.path.join(out_dir, output_name(dataset)), rows)
+    return rows
+
+
+def main(argv):
+    if len(argv) < 4:
+        print("usage: python -m pix2pose_amd.eval_bop <gpu_id> <cfg.json> <dataset> [detections.json]")
+        return 2
+    device, cfg_fn, dataset = int(argv[1]), argv[2], argv[3]
+    cfg = json.load(open(cfg_fn))
+    det_fn = argv[4] if len(argv) > 4 else os.path.join(cfg["dataset_dir"], dataset, "detections_mi355.json")
+    dump = json.load(open(det_fn))
+    rows = run(cfg, dataset, dump, device=device, base_dir=os.path.dirname(os.path.abspath(det_fn)))
+    print("Saving %d results to %s" % (len(rows), os.path.join(cfg.get("path_to_output", "."), output_name(dataset))))
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main(sys.argv))

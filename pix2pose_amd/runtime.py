@@ -168,7 +168,8 @@ def _image_struct(img):
 
 
 def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
-                   want_masks=False, debug=False, ransac_iterations=0, reprojection_error=0.0, confidence=0.0):
+                   want_masks=False, debug=False, ransac_iterations=0, reprojection_error=0.0, confidence=0.0,
+                   det_masks=None):
     """detections: list of (image_idx, object_idx, bbox[v1,u1,v2,u2], camK 3x3).
     Returns (poses: list[_lib.Pose], extras: dict)."""
     n = len(detections)
@@ -201,6 +202,17 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
         extras["img_pred"] = np.zeros((n, mstride * 3), np.uint8)
         opts.valid_mask, opts.mask_stride = extras["valid_mask"].ctypes.data, mstride
         opts.img_pred, opts.pred_stride = extras["img_pred"].ctypes.data, mstride * 3
+    if det_masks is not None and n:
+        # score_type 2: IoU of each detector mask with valid_mask_full, computed on the device
+        dms = max(int(np.asarray(m).size) for m in det_masks)
+        dm = np.zeros((n, dms), np.uint8)
+        for i, m in enumerate(det_masks):
+            mm = np.ascontiguousarray(np.asarray(m) != 0, dtype=np.uint8).reshape(-1)
+            dm[i, :mm.size] = mm
+        extras["mask_stats"] = np.zeros((n, 3), np.int64)
+        extras["_dm"] = dm
+        opts.det_mask, opts.det_mask_stride = dm.ctypes.data, dms
+        opts.mask_stats = extras["mask_stats"].ctypes.data
     if debug and n:
         extras["x1"] = np.zeros((n, 128, 128, 3), np.float32)
         extras["x2"] = np.zeros((n, K, 128, 128, 3), np.float32)

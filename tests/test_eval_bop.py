@@ -1,0 +1,120 @@
+"""Harness counterpart of tools/5_evaluation_bop_basic.py: CPU tests of the per-image
+logic and CSV format; a GPU end-to-end run on a synthetic pre-dumped detection stream."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pix2pose_amd import eval_bop as E
+
+
+def test_threshold_selection_and_target_grouping():
+    assert E.outlier_thresholds({"outlier_th": [0.2, 0.3, 0.35]}, 2) == [[0.2, 0.3, 0.35]] * 2
+    assert E.outlier_thresholds({"outlier_th": [[0.1], [0.3], [0.2]]}, 3) == [[0.1], [0.3], [0.2]]   # cfg_tless_paper style
+    tg = [{"scene_id": 1, "im_id": 3, "obj_id": 5, "inst_count": 1}, {"scene_id": 1, "im_id": 3, "obj_id": 8, "inst_count": 2},
+          {"scene_id": 1, "im_id": 4, "obj_id": 5, "inst_count": 1}, {"scene_id": 2, "im_id": 4, "obj_id": 9, "inst_count": 1}]
+    assert E.group_targets(tg) == [[1, 3, [5, 8], [1, 2]], [1, 4, [5], [1]], [2, 4, [9], [1]]]
+
+
+def test_candidate_limiting_like_reference():
+    rois = [[0, 0, 5, 5], [-1, -1, 3, 3], [1, 1, 6, 6], [2, 2, 7, 7], [3, 3, 8, 8], [4, 4, 9, 9]]
+    obj_ids = [5, 5, 7, 5, 5, 5]
+    # inst_count 1, cand_factor 2: candidates are taken while pred <= 2, i.e. three of object 5
+    assert E.select_detections(rois, obj_ids, [5], [1], 2.0) == [0, 3, 4]
+    assert E.select_detections(rois, obj_ids, [5, 7], [1, 1], 0.0) == [0, 2]
+
+
+def test_scores_ranking_and_vivo_quirk():
+    assert E.detection_score(0.9, 0.5, (30, 60), 2) == 0.9 * 0.5 * 0.5 * 60
+    assert E.detection_score(0.9, 0.5, (0, 0), 2) == 0
+    assert E.detection_score(0.9, 0.5, None, 1) == 0.9
+    res = [{"obj_id": 5, "score": 2.0, "R": np.eye(3), "t": np.zeros(3)}, {"obj_id": 5, "score": 4.0, "R": np.eye(3), "t": np.ones(3)},
+           {"obj_id": 7, "score": 1.0, "R": np.eye(3), "t": np.ones(3) * 2}]
+    rows = E.rank_image_results(res, [5, 7], [1, 1], 2, 11, 22, 0.5)        # int 2: the reference's `=='2'` never fires
+    assert [r["score"] for r in rows] == [1.0, 0.5, 0.25] and [r["obj_id"] for r in rows] == [5, 5, 7]
+    rows = E.rank_image_results(res, [5, 7], [1, 1], '2', 11, 22, 0.5)      # string '2': ViVo truncation
+    assert [(r["obj_id"], r["score"]) for r in rows] == [(5, 1.0), (7, 0.25)]
+    assert E.rank_image_results([], [5], [1], 2, 1, 1, 0.0) == []
+
+
+def test_csv_format(tmp_path):
+    rows = [{"scene_id": 1, "im_id": 2, "obj_id": 3, "score": 0.5, "R": np.arange(9.0).reshape(3, 3), "t": np.array([1.5, -2.0, 700.25]), "time": 0.25}]
+    fn = str(tmp_path / E.output_name("lmo"))
+    E.save_bop_results(fn, rows)
+    lines = open(fn).read().split("\n")
+    assert lines[0] == "scene_id,im_id,obj_id,score,R,t,time"
+    assert lines[1] == "1,2,3,0.5,0.0 1.0 2.0 3.0 4.0 5.0 6.0 7.0 8.0,1.5 -2.0 700.25,0.25"
+    assert E.output_name("tless").endswith("tless-test-primesense.csv") and fn.endswith("pix2pose-iccv19_lmo-test.csv")
+
+
+@pytest.mark.gpu
+def test_harness_end_to_end_matches_per_detection_shim(tmp_path):
+    """A synthetic detection stream through the batched harness == the reference's flow (one shim
+    est_pose per detection + host-side mask IoU), including score_type 2 with detector masks."""
+    import torch
+    from pix2pose_amd import synthetic as S
+    from pix2pose_amd.recognition import pix2pose
+    from pix2pose_amd.runtime import Context
+    sc = S.make_scene(6, seed=21, n_images=2)
+    H, Wd = sc["images"].shape[1:3]
+    rs = np.random.RandomState(0)
+    images = []
+    for fi in range(2):
+        np.save(tmp_path / ("f%d.npy" % fi), sc["images"][fi])
+        ids = [i for i, d in enumerate(sc["dets"]) if d[0] == fi]
+        masks = np.zeros((H, Wd, len(ids)), bool)
+        for k, i in enumerate(ids):
+            b = sc["dets"][i][2]
+            masks[b[0] + 10:b[2] - 5, b[1] + 8:b[3] - 12, k] = True
+        np.save(tmp_path / ("m%d.npy" % fi), masks)
+        images.append({"scene_id": 1, "im_id": fi, "rgb": "f%d.npy" % fi, "cam_K": S.LM_K.reshape(-1).tolist(),
+                       "rois": [sc["dets"][i][2] for i in ids], "obj_ids": [1] * len(ids),
+                       "scores": [float(rs.uniform(0.5, 1)) for _ in ids], "masks": "m%d.npy" % fi, "_ids": ids})
+    dump = {"im_size": [Wd, H], "model_ids": [1], "weights": {"1": "synthetic:paper:1"},
+            "norm_factor": {"1": dict(zip(["x_scale", "y_scale", "z_scale", "x_ct", "y_ct", "z_ct"], S.OBJ_PARAM.tolist()))},
+            "targets": [{"scene_id": 1, "im_id": 0, "obj_id": 1, "inst_count": 5}, {"scene_id": 1, "im_id": 1, "obj_id": 1, "inst_count": 5}],
+            "images": images}
+    cfg = {"backbone": "paper", "outlier_th": [0.2, 0.3, 0.35], "inlier_th": 0.2, "score_type": 2, "task_type": 2,
+           "cand_factor": 2, "path_to_output": str(tmp_path / "out"), "generator_chunk": 32}
+    # injected decoder maps, in the harness's detection order (image 0 first, then image 1)
+    order = [i for im in images for i in im["_ids"]]
+    j1 = torch.from_numpy(sc["inject1"][order]).cuda()
+    j2 = torch.from_numpy(sc["inject2"][order]).cuda()
+    torch.cuda.synchronize()
+    rows = E.run(cfg, "lmo", dump, base_dir=str(tmp_path),
+                 est_pose_kwargs=dict(inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3))
+    assert os.path.exists(tmp_path / "out" / "pix2pose-iccv19_lmo-test.csv")
+    assert len(rows) >= 5
+    # the reference's flow, one detection at a time through the batch API of size 1 (same injection)
+    from pix2pose_amd import runtime
+    ctx = Context(0, max_batch=16)
+    p = pix2pose("synthetic:paper:1", S.LM_K, Wd, H, S.OBJ_PARAM, th_outlier=[0.2, 0.3, 0.35], th_inlier=0.2, backbone="paper", ctx=ctx)
+    exp = {}
+    for im in images:
+        masks = np.load(tmp_path / im["masks"])
+        res = []
+        for k, i in enumerate(im["_ids"]):
+            a1, a2 = torch.from_numpy(sc["inject1"][i:i + 1]).cuda(), torch.from_numpy(sc["inject2"][i:i + 1]).cuda()
+            torch.cuda.synchronize()
+            poses, ex = runtime.est_pose_batch(ctx, [p._spec()], [sc["images"][sc["dets"][i][0]]], [(0, 0, sc["dets"][i][2], S.LM_K)],
+                                               inject1=a1.data_ptr(), inject2=a2.data_ptr(), inject_slots=3, want_masks=True)
+            if poses[0].status != 0:
+                continue
+            vm = ex["valid_mask"][0][:H * Wd].reshape(H, Wd).astype(bool)
+            union = np.sum(np.logical_or(masks[:, :, k], vm))
+            iou = 0 if union <= 0 else np.sum(np.logical_and(masks[:, :, k], vm)) / union
+            res.append({"obj_id": 1, "score": im["scores"][k] * poses[0].frac_inlier * iou * union,
+                        "R": np.array(poses[0].R).reshape(3, 3), "t": np.array(poses[0].t)})
+        for r in E.rank_image_results(res, [1], [5], 2, 1, im["im_id"], 0.0):
+            exp.setdefault(im["im_id"], []).append(r)
+    got = {}
+    for r in rows:
+        got.setdefault(r["im_id"], []).append(r)
+    assert sorted(got) == sorted(exp)
+    for k in exp:
+        assert len(got[k]) == len(exp[k])
+        for a, b in zip(got[k], exp[k]):
+            assert abs(a["score"] - b["score"]) < 1e-12
+            np.testing.assert_array_equal(a["R"], b["R"])
+            np.testing.assert_array_equal(a["t"], b["t"])

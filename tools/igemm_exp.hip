@@ -1,0 +1,204 @@
+// Experimental variants of the implicit-GEMM kernel on one big-layer shape (development aid).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipix2pose_amd/csrc tools/igemm_exp.hip -o tools/igemm_exp
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "kernels.h"
+using namespace p2p;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// BK: k-step; NBUF: LDS buffers; MID: store next tile to LDS in the middle of the MFMA block; PRIO: setprio
+template <int BK, int NBUF, int MID, int PRIO, int EPI = 1>
+__global__ __launch_bounds__(256) void kexp(const IgemmParams p)
+{
+    constexpr int WGM = 2, WGN = 2, TM = 2, TN = 2;
+    constexpr int BM = 128, BN = 128;
+    constexpr int LD = BK + 4;
+    constexpr int CPR = BK / 4;              // float4 columns per row
+    constexpr int RPP = 256 / CPR;           // rows per pass
+    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+    __shared__ __attribute__((aligned(16))) float smem[(EPI == 0 || NBUF * (BM + BN) * LD > BM * (BN + 4)) ? NBUF * (BM + BN) * LD : BM * (BN + 4)];
+    __shared__ int row_base[BM], row_yx[BM], row_out[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN, li = lane & 31, lk = lane >> 5;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int t;
+    { const int b = blockIdx.x; const int q = nblk >> 3, r = nblk & 7; const int xcd = b & 7, idx = b >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+    const int tile_n = t % tiles_n, tile_m = t / tiles_n, m0 = tile_m * BM, n0 = tile_n * BN;
+    const int HgWg = p.Hg * p.Wg;
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r; int base = -1, yx = 0, op = -1;
+        if (m < p.M) { const int n = m / HgWg; const int rem = m - n * HgWg; const int gy = rem / p.Wg; const int gx = rem - gy * p.Wg;
+            base = n * p.Hin * p.Win; yx = ((gy * p.in_stride) << 16) | (gx * p.in_stride); op = (n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox; }
+        row_base[r] = base; row_yx[r] = yx; row_out[r] = op;
+    }
+    __syncthreads();
+    const int lrow = tid / CPR, lcol = (tid % CPR) * 4;
+    int a_base[A_PASSES], a_yx[A_PASSES];
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) { a_base[j] = row_base[lrow + RPP * j]; a_yx[j] = row_yx[lrow + RPP * j]; }
+    const float* wrow = p.w + (size_t)(n0 + lrow) * p.K + lcol;
+    const int ksteps = p.K / BK, cpt = (p.seg[0].C) / BK;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[A_PASSES], rb[B_PASSES];
+    auto gload = [&](int ks) {
+        const int tap = ks / cpt; const int chunk = ks - tap * cpt;
+        const IgemmSeg sg = p.seg[0];
+        const int c = chunk * BK + lcol;
+        const int dy = p.dy[tap], dx = p.dx[tap];
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            const int iy = (a_yx[j] >> 16) + dy, ix = (a_yx[j] & 0xffff) + dx;
+            const bool ok = a_base[j] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(sg.ptr + (size_t)(a_base[j] + iy * p.Win + ix) * sg.cstride + c);
+            ra[j] = v;
+        }
+        const float* wp = wrow + (size_t)ks * BK;
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(RPP * j) * p.K);
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * LD; float* Bs = As + BM * LD;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) *reinterpret_cast<f32x4*>(As + (lrow + RPP * j) * LD + lcol) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LD + lcol) = rb[j];
+    };
+    auto mma = [&](const float* As, const float* Bs, int kk) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LD + kk);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LD + kk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    };
+    gload(0); lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool more = ks + 1 < ksteps;
+        if (more) gload(ks + 1);
+        const float* As = smem + cur * (BM + BN) * LD + (wm * TM * 32 + li) * LD + lk * 4;
+        const float* Bs = smem + cur * (BM + BN) * LD + BM * LD + (wn * TN * 32 + li) * LD + lk * 4;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (NBUF == 2 && MID) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; kk += 8) mma(As, Bs, kk);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if (more) lstore(cur ^ 1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = BK / 2; kk < BK; kk += 8) mma(As, Bs, kk);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            cur ^= 1;
+        } else if (NBUF == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 8) mma(As, Bs, kk);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if (more) lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 8) mma(As, Bs, kk);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            if (more) lstore(0);
+            __syncthreads();
+        }
+    }
+    if (EPI == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { const int col = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const int op = row_out[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk]; if (op >= 0) p.out[(size_t)op * p.out_cstride + col] = acc[i][j][r]; } }
+        return;
+    }
+    // simple epilogue (transposed float4 stores)
+    constexpr int CLD = BN + 4;
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cs[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
+    __syncthreads();
+    const int c4 = (tid % 32) * 4, col = n0 + c4;
+    for (int r = tid / 32; r < BM; r += 8) {
+        const int op = row_out[r];
+        if (op < 0) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+        *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + col) = v;
+    }
+}
+
+template <int BK, int NBUF, int MID, int PRIO, int EPI = 1>
+static float run(const IgemmParams& p, int iters)
+{
+    const int tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((kexp<BK, NBUF, MID, PRIO, EPI>), dim3(tiles), dim3(256), 0, 0, p);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((kexp<BK, NBUF, MID, PRIO, EPI>), dim3(tiles), dim3(256), 0, 0, p);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    if (hipGetLastError() != hipSuccess) printf("launch error\n");
+    return ms / iters;
+}
+
+int main(int argc, char** argv)
+{
+    // deconv2-like: N x 32 x 32 x 256 -> 256, 5x5
+    const int N = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 32, C = argc > 3 ? atoi(argv[3]) : 256, Co = argc > 4 ? atoi(argv[4]) : 256, KS = argc > 5 ? atoi(argv[5]) : 5;
+    const size_t nin = (size_t)N * H * H * C, nout = (size_t)N * H * H * Co, nw = (size_t)((Co + 127) / 128 * 128) * KS * KS * C;
+    float *x, *w, *y;
+    hipMalloc(&x, nin * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, nout * 4);
+    std::vector<float> h(nin); for (size_t i = 0; i < nin; ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+    hipMemcpy(x, h.data(), nin * 4, hipMemcpyHostToDevice);
+    std::vector<float> hw(nw); for (size_t i = 0; i < nw; ++i) hw[i] = (float)((i * 40503u) >> 4 & 0xffff) / 65536.f - 0.5f;
+    hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
+    IgemmParams p; memset(&p, 0, sizeof(p));
+    p.seg[0] = {x, C, C, 0}; p.seg0_chunks = C / 32; p.chunks_per_tap = C / 32;
+    p.N = N; p.Hin = p.Win = H; p.Hg = p.Wg = H; p.M = N * H * H; p.in_stride = 1; p.ntaps = KS * KS;
+    for (int a = 0; a < KS; ++a) for (int b = 0; b < KS; ++b) { p.dy[a * KS + b] = a - KS / 2; p.dx[a * KS + b] = b - KS / 2; }
+    p.w = w; p.K = KS * KS * C; p.Cout = Co; p.ksteps = p.K / 32; p.ksplit = 1;
+    p.out = y; p.Hout = p.Wout = H; p.os = 1; p.out_cstride = Co;
+    const double gf = 2.0 * p.M * Co * p.K / 1e9;
+    const int it = 5;
+    float ms;
+    ms = run<32, 2, 0, 0>(p, it); printf("BK32 NBUF2            %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 2, 1, 0>(p, it); printf("BK32 NBUF2 MID        %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 2, 0, 1>(p, it); printf("BK32 NBUF2 PRIO       %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 2, 1, 1>(p, it); printf("BK32 NBUF2 MID PRIO   %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0>(p, it); printf("BK32 NBUF1            %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<16, 2, 0, 0>(p, it); printf("BK16 NBUF2            %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<16, 2, 1, 0>(p, it); printf("BK16 NBUF2 MID        %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<16, 1, 0, 0>(p, it); printf("BK16 NBUF1            %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 0>(p, it); printf("BK32 NBUF1 EPI0 (37KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<16, 2, 0, 0, 0>(p, it); printf("BK16 NBUF2 EPI0 (41KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<16, 1, 0, 0, 0>(p, it); printf("BK16 NBUF1 EPI0 (20KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 2, 0, 0, 0>(p, it); printf("BK32 NBUF2 EPI0 (74KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    return 0;
+}

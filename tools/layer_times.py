@@ -1,0 +1,32 @@
+"""Per-layer kernel durations of the stage-1 generator pass from a rocprofv3 rocpd database,
+annotated with algorithmic GFLOP and TFLOP/s (development aid)."""
+import sqlite3
+import sys
+
+LAYERS = [  # (name, MMAC per sample) in launch order for the resnet50 backbone
+    ("conv1", 38.5), ("maxpool", 0), ("res2a_2a", 4.2), ("res2a_2b", 37.7), ("res2a_1", 16.8), ("res2a_2c", 16.8),
+    ("res2b_2a", 16.8), ("res2b_2b", 37.7), ("res2b_2c", 16.8), ("res2c_2a", 16.8), ("res2c_2b", 37.7), ("res2c_2c", 16.8),
+    ("res3a_2a", 8.4), ("res3a_2b", 37.7), ("res3a_1", 33.6), ("res3a_2c", 16.8),
+    ("res3b_2a", 16.8), ("res3b_2b", 37.7), ("res3b_2c", 16.8), ("res3c_2a", 16.8), ("res3c_2b", 37.7), ("res3c_2c", 16.8),
+    ("res3d_2a", 16.8), ("res3d_2b", 37.7), ("res3d_2c", 16.8), ("conv4", 419.4), ("dense_enc", 8.4), ("splitk_reduce", 0),
+    ("dense_dec", 4.2), ("up1_p0", 16.8), ("up1_p1", 25.2), ("up1_p2", 25.2), ("up1_p3", 37.7), ("deconv1", 629.1),
+    ("up2_p0", 33.6), ("up2_p1", 50.3), ("up2_p2", 50.3), ("up2_p3", 75.5), ("deconv2", 1677.7),
+    ("up3_p0", 67.1), ("up3_p1", 100.7), ("up3_p2", 100.7), ("up3_p3", 151.0), ("deconv3", 1258.3), ("heads", 52.4)]
+
+
+def main(path, batch=256):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    idx = [i for i, r in enumerate(rows) if "stage1_input" in r[0]][-1]
+    ks = [r for r in rows[idx + 1:] if "copyBuffer" not in r[0]][:len(LAYERS)]
+    tot = 0
+    for (nm, mmac), r in zip(LAYERS, ks):
+        us = (r[2] - r[1]) / 1e3
+        tot += us
+        gf = 2 * mmac * batch / 1e3
+        print("%-14s %-28s %9.1f us %9.1f GFLOP %7.1f TFLOP/s" % (nm, r[0].replace("void p2p::", "").replace("p2p::", "")[:28], us, gf, gf / us * 1e3 / 1e3 * 1e3 if us else 0))
+    print("total %.1f us -> %.0f inputs/s" % (tot, batch / tot * 1e6))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 256)
