@@ -156,6 +156,15 @@ def main():
                      "share_of_step_time": s0["total_ms"] * 1e-3 / dt, "all_igemm_share_of_step_time": all_ms * 1e-3 / dt,
                      "traffic": None},
     }
+    # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes of this same
+    # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py), committed under profiles/
+    tfn = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tfn):
+        tr = json.load(open(tfn))
+        for k, v in tr.items():
+            if "igemm_kernel<2, 2, 2, 2>" in k:
+                out["roofline"]["traffic"] = v["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 PMC (FETCH_SIZE*2 + WRITE_SIZE), profiles/r01_traffic.json"
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.backbone, wts, args.cpu_sample)
     elif rank == 0:
