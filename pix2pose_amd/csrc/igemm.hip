@@ -19,8 +19,8 @@
 // lanes 0-31 take k..k+3 and lanes 32-63 take k+4..k+7, so the j-th element of every lane
 // forms one 32x32x2 MFMA step (the k-permutation is the same for A and B, which is all a
 // contraction needs).  Global->LDS is register-staged (the padded LDS image rules out
-// global_load_lds) and double-buffered: one barrier per K-step, loads for step k+1 are
-// issued before the 64 (128x128 tile) MFMAs of step k.
+// global_load_lds); the global loads of step k+1 are issued before the 64 (128x128 tile) MFMAs
+// of step k and written to the single LDS buffer between two barriers.
 #include "kernels.h"
 
 namespace p2p {
@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDS_LD = IGEMM_BK + 4;  // padded row stride (floats)
 
 template <int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p)
+__global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   // >= 3 waves per SIMD: <= 168 VGPR+AGPR
 {
     constexpr int BM = WGM * TM * 32;
     constexpr int BN = WGN * TN * 32;
@@ -39,7 +39,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p)
     constexpr int B_PASSES = BN / 32;
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+    // one staging buffer (two barriers per K-step) + a (TM*32)-row C tile for the epilogue: 38 KB for
+    // the 128x128 tile => 3 workgroups per CU (VGPR-limited) instead of 2; measured equal or better
+    // than double buffering on every layer shape (tools/igemm_exp.hip).
+    constexpr int STAGE_FLOATS = (BM + BN) * LDS_LD;
+    constexpr int CTILE_FLOATS = TM * 32 * (BN + 4);
+    __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > CTILE_FLOATS ? STAGE_FLOATS : CTILE_FLOATS];
     __shared__ int row_base[BM];   // n*Hin*Win, or -1 for rows past M
     __shared__ int row_yx[BM];     // (iy0 << 16) | ix0
     __shared__ int row_out[BM];    // output pixel index, or -1
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p)
         for (int j = 0; j < B_PASSES; ++j)
             rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * j) * p.K);
     };
-    auto lstore = [&](int buf) {
-        float* As = smem + buf * (BM + BN) * LDS_LD;
+    auto lstore = [&]() {
+        float* As = smem;
         float* Bs = As + BM * LDS_LD;
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j)
@@ -145,17 +150,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p)
 
     if (ks0 < ks1) {
         gload(ks0);
-        lstore(0);
+        lstore();
     }
     __syncthreads();
 
-    int cur = 0;
+    const float* As = smem + (wm * TM * 32 + li) * LDS_LD + lk * 4;
+    const float* Bs = smem + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + lk * 4;
     for (int ks = ks0; ks < ks1; ++ks) {
         const bool more = ks + 1 < ks1;
-        if (more) gload(ks + 1);
-
-        const float* As = smem + cur * (BM + BN) * LDS_LD + (wm * TM * 32 + li) * LDS_LD + lk * 4;
-        const float* Bs = smem + cur * (BM + BN) * LDS_LD + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + lk * 4;
+        if (more) gload(ks + 1);          // global loads of the next K-step fly under this step's MFMAs
 #pragma unroll
         for (int kk = 0; kk < IGEMM_BK; kk += 8) {
             f32x4 a[TM], b[TN];
@@ -171,78 +174,85 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        __syncthreads();                  // everyone is done reading the staging buffer
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue.  The accumulator tile is transposed through LDS (the staging buffers are
-    //      free after the last barrier) so that every thread then owns 4 consecutive channels of
-    //      one pixel: scale/shift, the residual and the output move as float4, and a 128-channel
-    //      pixel row is one contiguous 512-byte store.  (Lane-per-channel dword stores left the
-    //      1x1 ResNet-front layers epilogue-bound at ~1.2 TB/s.)
+    // ---- epilogue.  The accumulators are transposed through LDS (the staging buffer is free after
+    //      the last barrier), TM*32 pixel rows at a time (the rows of the waves with wm == h), so
+    //      that every thread then owns 4 consecutive channels of one pixel: scale/shift, the
+    //      residual and the output move as float4 and a 128-channel pixel row is one contiguous
+    //      512-byte store.  (Lane-per-channel dword stores left the 1x1 ResNet-front layers
+    //      epilogue-bound at ~1.2 TB/s.)
     //      C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     constexpr int CLD = BN + 4;
-    static_assert(BM * CLD <= 2 * (BM + BN) * LDS_LD, "C tile must fit the staging buffers");
-    float* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                Cs[row * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
-            }
-    __syncthreads();
-
     constexpr int TPR = BN / 4;            // threads per pixel row
-    constexpr int RPP = 256 / TPR;         // rows per pass
+    constexpr int RPP = 256 / TPR;         // rows per sweep of the workgroup
+    constexpr int PROWS = TM * 32;         // rows per pass
+    float* Cs = smem;
     const int c4 = (tid % TPR) * 4;
     const int col = n0 + c4;
     const int r0 = tid / TPR;
-    if (col >= p.Cout) return;             // Cout is a multiple of 4 on this path
-    if (p.ksplit > 1) {
-        float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
-#pragma unroll 4
-        for (int r = r0; r < BM; r += RPP) {
-            const int m = m0 + r;
-            if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + col) = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
-        }
-        return;
-    }
+    const bool cok = col < p.Cout;         // Cout is a multiple of 4 on this path
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-#pragma unroll 4
-    for (int r = r0; r < BM; r += RPP) {
-        const int op = row_out[r];
-        if (op < 0) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+    if (cok && p.ksplit <= 1) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+    }
+#pragma unroll 1
+    for (int h = 0; h < WGM; ++h) {
+        if (wm == h) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-        if (p.mode == EPI_HEAD) {
-            // col = phase*4 + ch: this thread holds (x, y, z, prob) of output pixel (2gy+py, 2gx+px)
-            const int ph = col >> 2;
-            f32x4 o;
-            o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
-            o[3] = 1.f / (1.f + __expf(-v[3]));
-            *reinterpret_cast<f32x4*>(p.out + (size_t)(op + (ph >> 1) * p.Wout + (ph & 1)) * 4) = o;
-        } else {
-            if (p.residual) {
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)op * p.res_cstride + col);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += rs[e];
-            }
-            if (p.act == ACT_RELU) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (p.act == ACT_LEAKY) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
-            }
-            *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
         }
+        __syncthreads();
+        if (cok) {
+#pragma unroll 2
+            for (int r = r0; r < PROWS; r += RPP) {
+                const int row = h * PROWS + r;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+                if (p.ksplit > 1) {
+                    const int m = m0 + row;
+                    if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.y * p.M + m) * p.Cout + col) = v;
+                    continue;
+                }
+                const int op = row_out[row];
+                if (op < 0) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                if (p.mode == EPI_HEAD) {
+                    // col = phase*4 + ch: this thread holds (x, y, z, prob) of output pixel (2gy+py, 2gx+px)
+                    const int ph = col >> 2;
+                    f32x4 o;
+                    o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
+                    o[3] = 1.f / (1.f + __expf(-v[3]));
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)(op + (ph >> 1) * p.Wout + (ph & 1)) * 4) = o;
+                } else {
+                    if (p.residual) {
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)op * p.res_cstride + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rs[e];
+                    }
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                    }
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
+                }
+            }
+        }
+        if (h + 1 < WGM) __syncthreads();
     }
 }
 

@@ -20,7 +20,9 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
     constexpr int CPR = BK / 4;              // float4 columns per row
     constexpr int RPP = 256 / CPR;           // rows per pass
     constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
-    __shared__ __attribute__((aligned(16))) float smem[(EPI == 0 || NBUF * (BM + BN) * LD > BM * (BN + 4)) ? NBUF * (BM + BN) * LD : BM * (BN + 4)];
+    constexpr int STG = NBUF * (BM + BN) * LD;
+    constexpr int CT = EPI == 0 ? 0 : (EPI == 1 ? BM * (BN + 4) : 64 * (BN + 4));
+    __shared__ __attribute__((aligned(16))) float smem[STG > CT ? STG : CT];
     __shared__ int row_base[BM], row_yx[BM], row_out[BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN, li = lane & 31, lk = lane >> 5;
@@ -134,6 +136,33 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
                 for (int r = 0; r < 16; ++r) { const int op = row_out[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk]; if (op >= 0) p.out[(size_t)op * p.out_cstride + col] = acc[i][j][r]; } }
         return;
     }
+    if (EPI == 2) {
+        constexpr int CLD2 = BN + 4;
+        float* Cs2 = smem;
+        const int c4b = (tid % 32) * 4, colb = n0 + c4b;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Cs2[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD2 + (wn * TN + j) * 32 + li] = acc[i][j][r];
+            }
+            __syncthreads();
+            for (int r = tid / 32; r < 64; r += 8) {
+                const int op = row_out[h * 64 + r];
+                if (op < 0) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs2 + r * CLD2 + c4b);
+                if (p.residual) { const f32x4 rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)op * p.res_cstride + colb); v += rs; }
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + colb) = v;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // simple epilogue (transposed float4 stores)
     constexpr int CLD = BN + 4;
     float* Cs = smem;
@@ -149,6 +178,8 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
         const int op = row_out[r];
         if (op < 0) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+        if (p.residual) { const f32x4 rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)op * p.res_cstride + col); v += rs; }
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + col) = v;
     }
 }
@@ -185,10 +216,16 @@ int main(int argc, char** argv)
     for (int a = 0; a < KS; ++a) for (int b = 0; b < KS; ++b) { p.dy[a * KS + b] = a - KS / 2; p.dx[a * KS + b] = b - KS / 2; }
     p.w = w; p.K = KS * KS * C; p.Cout = Co; p.ksteps = p.K / 32; p.ksplit = 1;
     p.out = y; p.Hout = p.Wout = H; p.os = 1; p.out_cstride = Co;
+    float* res = nullptr;
+    if (argc > 6 && atoi(argv[6])) { hipMalloc(&res, nout * 4); hipMemset(res, 0, nout * 4); p.residual = res; p.res_cstride = Co; }
     const double gf = 2.0 * p.M * Co * p.K / 1e9;
     const int it = 5;
     float ms;
     ms = run<32, 2, 0, 0>(p, it); printf("BK32 NBUF2            %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2>(p, it); printf("BK32 NBUF1 EPI2 (38KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 2, 0, 0, 2>(p, it); printf("BK32 NBUF2 EPI2 (74KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<16, 2, 0, 0, 2>(p, it); printf("BK16 NBUF2 EPI2 (41KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<16, 1, 0, 0, 2>(p, it); printf("BK16 NBUF1 EPI2 (34KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 2, 1, 0>(p, it); printf("BK32 NBUF2 MID        %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 2, 0, 1>(p, it); printf("BK32 NBUF2 PRIO       %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 2, 1, 1>(p, it); printf("BK32 NBUF2 MID PRIO   %8.3f ms %7.1f TF\n", ms, gf / ms);
