@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=256, help="generator inputs per pass (activation workspace)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="detections in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-inject", action="store_true", help="let PnP consume the random-weight generator output")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for dry runs)")
+    ap.add_argument("--same-device", action="store_true", help="debug: all ranks share cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -79,10 +81,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    coll_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     from pix2pose_amd import synthetic, weights as W
     from pix2pose_amd.parallel import gather_poses, poses_to_records
@@ -104,7 +112,7 @@ def main():
         poses, _ = est_pose_batch(ctx, [spec], images, sc["dets"], **kw)
         rec = poses_to_records(poses, base_id=rank * args.batch)
         if world > 1:
-            rec = gather_poses(rec, device=torch.device("cuda", local_rank))      # RCCL all-gather of (R,t,score)
+            rec = gather_poses(rec, device=coll_dev, pad_to=args.batch)          # RCCL all-gather of (R,t,score)
         return poses, rec
 
     def barrier():
@@ -125,7 +133,7 @@ def main():
     stats = ctx.profile_read(reset=True)
     ctx.profile(False)
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
