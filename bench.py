@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=256, help="generator inputs per pass (activation workspace)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="detections in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-inject", action="store_true", help="let PnP consume the random-weight generator output")
+    ap.add_argument("--overlap", action="store_true", help="detection-stream mode: submit/collect with two batches in flight "
+                    "(PnP tail on a second HIP stream) instead of one blocking p2p_est_pose_batch per step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="debug: all ranks share cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -94,7 +96,7 @@ def main():
 
     from pix2pose_amd import synthetic, weights as W
     from pix2pose_amd.parallel import gather_poses, poses_to_records
-    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch, est_pose_submit
 
     ctx = Context(local_rank, max_batch=args.chunk)
     wts = W.synthetic_weights(args.backbone, 1)
@@ -108,26 +110,42 @@ def main():
     torch.cuda.synchronize()
     kw = {} if args.no_inject else dict(inject1=inj1.data_ptr(), inject2=inj2.data_ptr(), inject_slots=3)
 
-    def step():
-        poses, _ = est_pose_batch(ctx, [spec], images, sc["dets"], **kw)
+    def finish(poses):
         rec = poses_to_records(poses, base_id=rank * args.batch)
         if world > 1:
             rec = gather_poses(rec, device=coll_dev, pad_to=args.batch)          # RCCL all-gather of (R,t,score)
         return poses, rec
+
+    def run_steps(k):
+        """k steps.  Default: one blocking p2p_est_pose_batch per step.  --overlap: detection-stream mode --
+        step i+1 is enqueued before step i is collected, so the PnP-RANSAC tail (second HIP stream), the
+        D2H and the pose gather overlap the next step's generator passes; every step's work still
+        completes inside the call."""
+        out = None
+        if not args.overlap:
+            for _ in range(k):
+                out = finish(est_pose_batch(ctx, [spec], images, sc["dets"], **kw)[0])
+            return out
+        pending = None
+        for _ in range(k):
+            nxt = est_pose_submit(ctx, [spec], images, sc["dets"], **kw)
+            if pending is not None:
+                out = finish(pending.collect())
+            pending = nxt
+        return finish(pending.collect()) if pending is not None else out
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run_steps(args.warmup)
     ctx.profile(True)
     ctx.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        poses, rec = step()
+    poses, rec = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     stats = ctx.profile_read(reset=True)
@@ -153,7 +171,7 @@ def main():
                                "(1 stage-1 + 3 stage-2 forwards per detection) + 3 EPnP-RANSAC solves per detection, "
                                "outlier_th=[0.2,0.3,0.35], injected ellipsoid-NOCS decoder maps" % (args.batch, args.backbone),
                    "detections_per_gpu": args.batch, "backbone": args.backbone, "parallelism": "dp%d" % world,
-                   "generator_chunk": args.chunk},
+                   "generator_chunk": args.chunk, "mode": "stream (submit/collect, 2 in flight)" if args.overlap else "blocking"},
         "ae_inputs_per_s": 4 * value,
         "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
         "poses_ok": n_ok, "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,

@@ -182,6 +182,17 @@ int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, c
                        int n_images, const p2p_detection* dets, int n_dets, p2p_pose* poses,
                        const p2p_est_pose_opts* opts);
 
+/* Asynchronous form of p2p_est_pose_batch for detection streams: `submit` only enqueues the batch
+ * (generator passes + glue on the context stream, PnP-RANSAC + selection + D2H on a second stream)
+ * and returns a ticket; `collect` waits for that batch and fills poses[n_dets].  At most two
+ * batches may be in flight, so the latency-bound PnP tail of batch i overlaps the generator
+ * passes of batch i+1.  Device-resident frames and injected maps must stay alive until the
+ * collect.  The optional mask / debug / det_mask outputs of p2p_est_pose_opts are blocking-only. */
+int p2p_est_pose_submit(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images,
+                        int n_images, const p2p_detection* dets, int n_dets, const p2p_est_pose_opts* opts,
+                        int* ticket);
+int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses);
+
 /* Replaces `cv2.solvePnPRansac(obj, img, camK, None, flags=EPNP, reprojectionError, iterationsCount)`
  * + `cv2.Rodrigues` (reference recognition.py:216-223) for a batch of independent problems.
  * Problem p owns points [offsets[p], offsets[p+1]) of obj_pts [N,3] (mm, double) and img_pts

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp2p_mi355.so")
+LIB_PATH = os.environ.get("P2P_LIB", os.path.join(_HERE, "libp2p_mi355.so"))     # P2P_LIB: development override
 
 P2P_OK = 0
 BACKBONE = {"paper": 0, "resnet50": 1}
@@ -94,6 +94,9 @@ def lib():
     L.p2p_forward_async.argtypes = [vp, vp, vp, ci, vp]
     L.p2p_est_pose_batch.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,
                                      C.POINTER(Pose), C.POINTER(EstPoseOpts)]
+    L.p2p_est_pose_submit.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,
+                                      C.POINTER(EstPoseOpts), C.POINTER(ci)]
+    L.p2p_est_pose_collect.argtypes = [vp, ci, C.POINTER(Pose)]
     L.p2p_profile_enable.argtypes = [vp, ci]
     L.p2p_profile_read.argtypes = [vp, C.POINTER(KernelStats), ci]
     dp = C.POINTER(C.c_double)

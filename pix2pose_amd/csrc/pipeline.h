@@ -68,8 +68,10 @@ struct PnpResult {
     int ok;
 };
 
+// workspace: pnp_workspace_bytes(n_problems) bytes of device memory (hypothesis models)
+size_t pnp_workspace_bytes(int n_problems);
 hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_problems, int iterations,
-                             double reproj_err, double confidence, int min_points, hipStream_t s);
+                             double reproj_err, double confidence, int min_points, double* workspace, hipStream_t s);
 
 // growable device buffer
 struct DevBuf {
@@ -80,8 +82,24 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Per-batch buffers that outlive the generator passes (read by PnP / selection): double buffered so
+// that the PnP-RANSAC tail of batch i (second stream) overlaps the generator passes of batch i+1.
+struct Slot {
+    DevBuf det, s1, cand, probs, results, poses, corr, hyp;
+    p2p_pose* host_poses = nullptr;     // pinned
+    size_t host_cap = 0;
+    std::vector<int> perm;
+    int n = 0;
+    int ticket = -1;                    // in-flight async batch, -1 = free
+    hipEvent_t done = nullptr;
+};
+
 struct Pipeline {
-    DevBuf det, s1, cand, probs, results, poses, x1, y1, x2, y2, corr, images, mask, pred, dmask, mstat;
+    Slot slot[2];
+    DevBuf x1, y1, x2, y2, images, mask, pred, dmask, mstat;
+    hipStream_t tail_stream = nullptr;  // PnP + selection + D2H of async batches
+    hipEvent_t corr_ready = nullptr;
+    int next_ticket = 0;
     ~Pipeline();
 };
 

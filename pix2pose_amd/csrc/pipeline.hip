@@ -50,7 +50,14 @@ void DevBuf::release()
 }
 Pipeline::~Pipeline()
 {
-    for (DevBuf* b : {&det, &s1, &cand, &probs, &results, &poses, &x1, &y1, &x2, &y2, &corr, &images, &mask, &pred, &dmask, &mstat}) b->release();
+    for (Slot& s : slot) {
+        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp}) b->release();
+        if (s.host_poses) (void)hipHostFree(s.host_poses);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (DevBuf* b : {&x1, &y1, &x2, &y2, &images, &mask, &pred, &dmask, &mstat}) b->release();
+    if (corr_ready) (void)hipEventDestroy(corr_ready);
+    if (tail_stream) (void)hipStreamDestroy(tail_stream);
 }
 void Ctx::free_pipeline()
 {
@@ -560,14 +567,33 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
+// async_ticket == nullptr: blocking call, results in `poses`.  Otherwise the batch is only enqueued:
+// generator passes and glue on the context stream, PnP-RANSAC + selection + D2H on the tail stream,
+// and p2p_est_pose_collect() picks the poses up.
 static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
-                        const p2p_detection* dets, int n, p2p_pose* poses, const p2p_est_pose_opts& opt)
+                        const p2p_detection* dets, int n, p2p_pose* poses, const p2p_est_pose_opts& opt, int* async_ticket)
 {
     int rc;
     hipStream_t st = X.stream;
     if (!X.pipe) X.pipe = new Pipeline();
     Pipeline& P = *X.pipe;
     if ((rc = X.ensure_workspace())) return rc;
+    const bool async = async_ticket != nullptr;
+    if (!P.tail_stream) {
+        HIP_TRY(hipStreamCreate(&P.tail_stream));
+        HIP_TRY(hipEventCreateWithFlags(&P.corr_ready, hipEventDisableTiming));
+        for (Slot& s : P.slot) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    Slot& SL = P.slot[async ? (P.next_ticket & 1) : 0];
+    if (SL.ticket >= 0) {
+        if (async) { set_error("two batches are already in flight: collect ticket %d first", SL.ticket); return P2P_ERR_CAPACITY; }
+        set_error("an asynchronous batch (ticket %d) is in flight: collect it before a blocking call", SL.ticket);
+        return P2P_ERR_CAPACITY;
+    }
+    if (async && (opt.valid_mask || opt.img_pred || opt.dbg_x1 || opt.dbg_x2 || opt.dbg_boxes2 || opt.dbg_cand || opt.det_mask)) {
+        set_error("optional mask / debug outputs are only available from the blocking call");
+        return P2P_ERR_INVALID_ARG;
+    }
 
     // -- validate, order detections by object (weights locality; one generator pass per group)
     int K = 0;
@@ -639,21 +665,22 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         D.corr_off = corr_total;
         corr_total += (long long)D.corr_cap * 5 * K;
     }
-    if ((rc = P.det.reserve(sizeof(DetInfo) * n))) return rc;
-    if ((rc = P.s1.reserve(sizeof(Stage1) * n))) return rc;
-    if ((rc = P.cand.reserve(sizeof(CandStat) * n * K))) return rc;
-    if ((rc = P.probs.reserve(sizeof(PnpProblem) * n * K))) return rc;
-    if ((rc = P.results.reserve(sizeof(PnpResult) * n * K))) return rc;
-    if ((rc = P.poses.reserve(sizeof(p2p_pose) * n))) return rc;
+    if ((rc = SL.det.reserve(sizeof(DetInfo) * n))) return rc;
+    if ((rc = SL.s1.reserve(sizeof(Stage1) * n))) return rc;
+    if ((rc = SL.cand.reserve(sizeof(CandStat) * n * K))) return rc;
+    if ((rc = SL.probs.reserve(sizeof(PnpProblem) * n * K))) return rc;
+    if ((rc = SL.results.reserve(sizeof(PnpResult) * n * K))) return rc;
+    if ((rc = SL.hyp.reserve(pnp_workspace_bytes(n * K)))) return rc;
+    if ((rc = SL.poses.reserve(sizeof(p2p_pose) * n))) return rc;
     if ((rc = P.x1.reserve(sizeof(float) * 16384 * 3 * (size_t)n))) return rc;
     if ((rc = P.y1.reserve(sizeof(float) * 16384 * 4 * (size_t)n))) return rc;
     if ((rc = P.x2.reserve(sizeof(float) * 16384 * 3 * (size_t)n * K))) return rc;
     if ((rc = P.y2.reserve(sizeof(float) * 16384 * 4 * (size_t)n * K))) return rc;
-    if ((rc = P.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
-    HIP_TRY(hipMemcpyAsync(P.det.p, hd.data(), sizeof(DetInfo) * n, hipMemcpyHostToDevice, st));
+    if ((rc = SL.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
+    HIP_TRY(hipMemcpyAsync(SL.det.p, hd.data(), sizeof(DetInfo) * n, hipMemcpyHostToDevice, st));
 
-    const DetInfo* d_det = P.det.as<DetInfo>();
-    Stage1* d_s1 = P.s1.as<Stage1>();
+    const DetInfo* d_det = SL.det.as<DetInfo>();
+    Stage1* d_s1 = SL.s1.as<Stage1>();
     float *x1 = P.x1.as<float>(), *y1 = P.y1.as<float>(), *x2 = P.x2.as<float>(), *y2 = P.y2.as<float>();
 
     // object groups (contiguous in the sorted order)
@@ -698,19 +725,40 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     }
 
     // -- correspondences, PnP-RANSAC, selection
-    hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y2, K, P.corr.as<float>(),
-                       P.cand.as<CandStat>(), P.probs.as<PnpProblem>());
+    hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
+                       SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>());
     HIP_TRY(hipGetLastError());
     const int iters = opt.ransac_iterations > 0 ? opt.ransac_iterations : 100;
     const double rerr = opt.reprojection_error > 0 ? opt.reprojection_error : 5.0;
     const double conf = opt.confidence > 0 ? opt.confidence : 0.99;
-    HIP_TRY(launch_pnp_ransac(P.probs.as<PnpProblem>(), P.results.as<PnpResult>(), n * K, iters, rerr, conf, 6, st));
-    hipLaunchKernelGGL(select_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_det, d_s1, P.cand.as<CandStat>(),
-                       P.results.as<PnpResult>(), K, n, P.poses.as<p2p_pose>());
+    hipStream_t ts = st;
+    if (async) {      // the latency-bound PnP tail runs beside the next batch's generator passes
+        ts = P.tail_stream;
+        HIP_TRY(hipEventRecord(P.corr_ready, st));
+        HIP_TRY(hipStreamWaitEvent(ts, P.corr_ready, 0));
+    }
+    HIP_TRY(launch_pnp_ransac(SL.probs.as<PnpProblem>(), SL.results.as<PnpResult>(), n * K, iters, rerr, conf, 6, SL.hyp.as<double>(), ts));
+    hipLaunchKernelGGL(select_kernel, dim3((n + 63) / 64), dim3(64), 0, ts, d_det, d_s1, SL.cand.as<CandStat>(),
+                       SL.results.as<PnpResult>(), K, n, SL.poses.as<p2p_pose>());
     HIP_TRY(hipGetLastError());
 
-    std::vector<p2p_pose> hp(n);
-    HIP_TRY(hipMemcpyAsync(hp.data(), P.poses.p, sizeof(p2p_pose) * n, hipMemcpyDeviceToHost, st));
+    if (SL.host_cap < (size_t)n) {
+        if (SL.host_poses) (void)hipHostFree(SL.host_poses);
+        SL.host_poses = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&SL.host_poses, sizeof(p2p_pose) * (size_t)n * 2, hipHostMallocDefault));
+        SL.host_cap = (size_t)n * 2;
+    }
+    p2p_pose* hp = SL.host_poses;
+    HIP_TRY(hipMemcpyAsync(hp, SL.poses.p, sizeof(p2p_pose) * n, hipMemcpyDeviceToHost, ts));
+    if (async) {
+        HIP_TRY(hipEventRecord(SL.done, ts));
+        // the slot's buffers are rewritten by the batch after next on the context stream
+        SL.perm = perm;
+        SL.n = n;
+        SL.ticket = P.next_ticket;
+        *async_ticket = P.next_ticket++;
+        return P2P_OK;
+    }
 
     // -- optional outputs
     std::vector<unsigned char> hmask, hpred;
@@ -725,7 +773,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         }
         for (int i = 0; i < n; ++i)
             if (opt.valid_mask && (long long)hd[i].H * hd[i].W > opt.mask_stride) { set_error("mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
-        hipLaunchKernelGGL(render_best_kernel, dim3(64, n), dim3(256), 0, st, d_det, d_s1, P.poses.as<p2p_pose>(), y2, K,
+        hipLaunchKernelGGL(render_best_kernel, dim3(64, n), dim3(256), 0, st, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
                            opt.valid_mask ? P.mask.as<unsigned char>() : nullptr, (long long)opt.mask_stride,
                            opt.img_pred ? P.pred.as<unsigned char>() : nullptr, (long long)opt.pred_stride);
         HIP_TRY(hipGetLastError());
@@ -743,7 +791,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
                                    opt.det_mask + (size_t)perm[i] * opt.det_mask_stride, (size_t)hd[i].H * hd[i].W,
                                    hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(P.mstat.p, 0, sizeof(unsigned long long) * 3 * n, st));
-        hipLaunchKernelGGL(mask_iou_kernel, dim3(32, n), dim3(256), 0, st, d_det, d_s1, P.poses.as<p2p_pose>(), y2, K,
+        hipLaunchKernelGGL(mask_iou_kernel, dim3(32, n), dim3(256), 0, st, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
                            P.dmask.as<unsigned char>(), (long long)opt.det_mask_stride, P.mstat.as<unsigned long long>());
         HIP_TRY(hipGetLastError());
         hstat.resize((size_t)3 * n);
@@ -758,8 +806,8 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     if (opt.dbg_boxes2 || opt.dbg_cand) {
         hs1.resize(n); hcs.resize((size_t)n * K); hres.resize((size_t)n * K);
         HIP_TRY(hipMemcpyAsync(hs1.data(), d_s1, sizeof(Stage1) * n, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(hcs.data(), P.cand.p, sizeof(CandStat) * n * K, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(hres.data(), P.results.p, sizeof(PnpResult) * n * K, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hcs.data(), SL.cand.p, sizeof(CandStat) * n * K, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hres.data(), SL.results.p, sizeof(PnpResult) * n * K, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
 
@@ -786,11 +834,48 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     return P2P_OK;
 }
 
+static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses)
+{
+    if (!X.pipe) { set_error("no batch was submitted"); return P2P_ERR_INVALID_ARG; }
+    for (Slot& s : X.pipe->slot)
+        if (s.ticket == ticket) {
+            HIP_TRY(hipEventSynchronize(s.done));
+            for (int i = 0; i < s.n; ++i) poses[s.perm[i]] = s.host_poses[i];
+            s.ticket = -1;
+            return P2P_OK;
+        }
+    set_error("ticket %d is not in flight", ticket);
+    return P2P_ERR_INVALID_ARG;
+}
+
 }  // namespace p2p
 
 using namespace p2p;
 
 extern "C" {
+
+int p2p_est_pose_submit(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images, int n_images,
+                        const p2p_detection* dets, int n_dets, const p2p_est_pose_opts* opts, int* ticket)
+{
+    if (!ctx || !ticket || n_dets <= 0 || !objects || !images || !dets || n_objects <= 0 || n_images <= 0) {
+        set_error("p2p_est_pose_submit: bad arguments");
+        return P2P_ERR_INVALID_ARG;
+    }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    p2p_est_pose_opts o;
+    memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    return run_est_pose(*c, objects, n_objects, images, n_images, dets, n_dets, nullptr, o, ticket);
+}
+
+int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses)
+{
+    if (!ctx || !poses) { set_error("p2p_est_pose_collect: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    return collect_est_pose(*c, ticket, poses);
+}
 
 int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images, int n_images,
                        const p2p_detection* dets, int n_dets, p2p_pose* poses, const p2p_est_pose_opts* opts)
@@ -805,7 +890,7 @@ int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, c
     p2p_est_pose_opts o;
     memset(&o, 0, sizeof(o));
     if (opts) o = *opts;
-    return run_est_pose(*c, objects, n_objects, images, n_images, dets, n_dets, poses, o);
+    return run_est_pose(*c, objects, n_objects, images, n_images, dets, n_dets, poses, o, nullptr);
 }
 
 int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts, const double* img_pts, const int* offsets,
@@ -824,11 +909,12 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
     // OpenCV converts the point sets to float32 before RANSAC; store them SoA per problem
     std::vector<float> pts((size_t)std::max(N, 1) * 5);
     std::vector<PnpProblem> pb(n_problems);
-    DevBuf dpts, dprob, dres, dmask;
+    DevBuf dpts, dprob, dres, dmask, dhyp;
     int rc;
     if ((rc = dpts.reserve(pts.size() * 4)) || (rc = dprob.reserve(sizeof(PnpProblem) * n_problems)) ||
-        (rc = dres.reserve(sizeof(PnpResult) * n_problems)) || (rc = dmask.reserve((size_t)std::max(N, 1)))) {
-        dpts.release(); dprob.release(); dres.release(); dmask.release();
+        (rc = dres.reserve(sizeof(PnpResult) * n_problems)) || (rc = dmask.reserve((size_t)std::max(N, 1))) ||
+        (rc = dhyp.reserve(pnp_workspace_bytes(n_problems)))) {
+        dpts.release(); dprob.release(); dres.release(); dmask.release(); dhyp.release();
         return rc;
     }
     for (int p = 0; p < n_problems; ++p) {
@@ -846,14 +932,14 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
         for (int k = 0; k < 9; ++k) pb[p].K[k] = camK[9 * p + k];
         pb[p].mask = inlier_mask ? dmask.as<unsigned char>() + o : nullptr;
     }
-    auto cleanup = [&]() { dpts.release(); dprob.release(); dres.release(); dmask.release(); };
+    auto cleanup = [&]() { dpts.release(); dprob.release(); dres.release(); dmask.release(); dhyp.release(); };
     hipError_t e;
     std::vector<PnpResult> res(n_problems);
     if ((e = hipMemcpyAsync(dpts.p, pts.data(), pts.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
         (e = hipMemcpyAsync(dprob.p, pb.data(), sizeof(PnpProblem) * n_problems, hipMemcpyHostToDevice, st)) != hipSuccess ||
         (e = hipMemsetAsync(dmask.p, 0, (size_t)std::max(N, 1), st)) != hipSuccess ||
         (e = launch_pnp_ransac(dprob.as<PnpProblem>(), dres.as<PnpResult>(), n_problems, iterations > 0 ? iterations : 100,
-                               reprojection_error > 0 ? reprojection_error : 5.0, confidence > 0 ? confidence : 0.99, 5, st)) != hipSuccess ||
+                               reprojection_error > 0 ? reprojection_error : 5.0, confidence > 0 ? confidence : 0.99, 5, dhyp.as<double>(), st)) != hipSuccess ||
         (e = hipMemcpyAsync(res.data(), dres.p, sizeof(PnpResult) * n_problems, hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (inlier_mask && (e = hipMemcpyAsync(inlier_mask, dmask.p, (size_t)N, hipMemcpyDeviceToHost, st)) != hipSuccess) ||
         (e = hipStreamSynchronize(st)) != hipSuccess) {

@@ -21,6 +21,14 @@
 // projected points and squared distance) with FMA contraction disabled.
 #include "pipeline.h"
 
+// minimum waves per SIMD the two PnP kernels are compiled for (caps their register allocation)
+#ifndef P2P_PNP_HYP_WAVES
+#define P2P_PNP_HYP_WAVES 1
+#endif
+#ifndef P2P_PNP_FIT_WAVES
+#define P2P_PNP_FIT_WAVES 2
+#endif
+
 #pragma clang fp contract(off)
 
 namespace p2p {
@@ -64,25 +72,40 @@ struct Rng {
 };
 
 // ---------------------------------------------------------------- one-sided Jacobi SVD
-// At: n rows of length m (the columns of the m x n matrix A).  On exit the rows are the left
-// singular vectors, W the singular values in descending order, Vt (optional, n x n) the right ones.
-__device__ void jacobi_svd(double* At, int m, int n, double* W, double* Vt)
+// At: N rows of length M (the columns of the M x N matrix A).  On exit the rows are the left
+// singular vectors, W the singular values in descending order, Vt (optional, N x N) the right ones.
+//
+// Compile-time sizes and fully unrolled loops: every index is static, so the matrix lives in
+// registers (a 12x12 fp64 matrix = 288 VGPRs) instead of per-lane scratch.  The solver is a long
+// serial dependency chain; with scratch arrays every element access was a memory round trip and one
+// 5-point EPnP took ~3 ms.  Operation order is unchanged (sequential sums), so results are bit for
+// bit those of the rolled loops.
+template <int M, int N, bool WITH_V>
+__device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N], double* Vt)
 {
     const double eps = kDblEps * 10;
-    const int max_iter = m > 30 ? m : 30;
-    for (int i = 0; i < n; i++) {
+    constexpr int max_iter = M > 30 ? M : 30;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
         double sd = 0;
-        for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
+#pragma unroll
+        for (int k = 0; k < M; k++) { const double t = At[i * M + k]; sd += t * t; }
         W[i] = sd;
-        if (Vt) { for (int k = 0; k < n; k++) Vt[i * n + k] = 0; Vt[i * n + i] = 1; }
+        if (WITH_V) {
+#pragma unroll
+            for (int k = 0; k < N; k++) Vt[i * N + k] = (k == i) ? 1. : 0.;
+        }
     }
+#pragma unroll 1
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
-        for (int i = 0; i < n - 1; i++)
-            for (int j = i + 1; j < n; j++) {
-                double *Ai = At + i * m, *Aj = At + j * m;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++)
+#pragma unroll
+            for (int j = i + 1; j < N; j++) {
                 double a = W[i], p = 0, b = W[j];
-                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+#pragma unroll
+                for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
                 if (fabs(p) <= eps * sqrt_cr(a * b)) continue;
                 p *= 2;
                 // hypot() written out: identical bits on every libm (see oracle/pnp_oracle.c)
@@ -97,103 +120,146 @@ __device__ void jacobi_svd(double* At, int m, int n, double* W, double* Vt)
                     s = p / (gamma * c * 2);
                 }
                 a = b = 0;
-                for (int k = 0; k < m; k++) {
-                    const double t0 = c * Ai[k] + s * Aj[k];
-                    const double t1 = -s * Ai[k] + c * Aj[k];
-                    Ai[k] = t0; Aj[k] = t1;
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    const double t0 = c * At[i * M + k] + s * At[j * M + k];
+                    const double t1 = -s * At[i * M + k] + c * At[j * M + k];
+                    At[i * M + k] = t0; At[j * M + k] = t1;
                     a += t0 * t0; b += t1 * t1;
                 }
                 W[i] = a; W[j] = b;
                 changed = true;
-                if (Vt) {
-                    double *Vi = Vt + i * n, *Vj = Vt + j * n;
-                    for (int k = 0; k < n; k++) {
-                        const double t0 = c * Vi[k] + s * Vj[k];
-                        const double t1 = -s * Vi[k] + c * Vj[k];
-                        Vi[k] = t0; Vj[k] = t1;
+                if (WITH_V) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const double t0 = c * Vt[i * N + k] + s * Vt[j * N + k];
+                        const double t1 = -s * Vt[i * N + k] + c * Vt[j * N + k];
+                        Vt[i * N + k] = t0; Vt[j * N + k] = t1;
                     }
                 }
             }
         if (!changed) break;
     }
-    for (int i = 0; i < n; i++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
         double sd = 0;
-        for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
+#pragma unroll
+        for (int k = 0; k < M; k++) { const double t = At[i * M + k]; sd += t * t; }
         W[i] = sqrt_cr(sd);
     }
-    for (int i = 0; i < n - 1; i++) {
+    // selection sort, descending (row i <-> row argmax_{k>=i} W[k]); the dynamic argmax becomes a
+    // chain of predicated swaps so the rows stay in registers
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
         int j = i;
-        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
-        if (i != j) {
-            double t = W[i]; W[i] = W[j]; W[j] = t;
-            for (int k = 0; k < m; k++) { t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
-            if (Vt) for (int k = 0; k < n; k++) { t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t; }
-        }
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+            if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+            if (j == k) {
+                double t = W[i]; W[i] = W[k]; W[k] = t;
+#pragma unroll
+                for (int e = 0; e < M; e++) { t = At[i * M + e]; At[i * M + e] = At[k * M + e]; At[k * M + e] = t; }
+                if (WITH_V) {
+#pragma unroll
+                    for (int e = 0; e < N; e++) { t = Vt[i * N + e]; Vt[i * N + e] = Vt[k * N + e]; Vt[k * N + e] = t; }
+                }
+            }
     }
     // left vectors = rows / singular value; a zero singular value gets a deterministic
     // pseudo-random direction orthogonal to the previous rows (what OpenCV's JacobiSVD does).
     Rng rng(0x12345678ULL);
-    for (int i = 0; i < n; i++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
         double sd = W[i];
+#pragma unroll 1
         for (int ii = 0; ii < 100 && sd <= kDblMin; ii++) {
-            const double val0 = 1. / m;
-            for (int k = 0; k < m; k++) At[i * m + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+            const double val0 = 1. / M;
+#pragma unroll
+            for (int k = 0; k < M; k++) At[i * M + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+#pragma unroll 1
             for (int it = 0; it < 2; it++)
+#pragma unroll
                 for (int j = 0; j < i; j++) {
                     sd = 0;
-                    for (int k = 0; k < m; k++) sd += At[i * m + k] * At[j * m + k];
+#pragma unroll
+                    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[j * M + k];
                     double asum = 0;
-                    for (int k = 0; k < m; k++) {
-                        const double t = At[i * m + k] - sd * At[j * m + k];
-                        At[i * m + k] = t;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        const double t = At[i * M + k] - sd * At[j * M + k];
+                        At[i * M + k] = t;
                         asum += fabs(t);
                     }
                     asum = asum > eps * 100 ? 1 / asum : 0;
-                    for (int k = 0; k < m; k++) At[i * m + k] *= asum;
+#pragma unroll
+                    for (int k = 0; k < M; k++) At[i * M + k] *= asum;
                 }
             sd = 0;
-            for (int k = 0; k < m; k++) { const double t = At[i * m + k]; sd += t * t; }
+#pragma unroll
+            for (int k = 0; k < M; k++) { const double t = At[i * M + k]; sd += t * t; }
             sd = sqrt_cr(sd);
         }
         const double s = sd > kDblMin ? 1 / sd : 0.;
-        for (int k = 0; k < m; k++) At[i * m + k] *= s;
+#pragma unroll
+        for (int k = 0; k < M; k++) At[i * M + k] *= s;
     }
 }
 
 // x = V diag(1/w) U^T b, singular values below sum(w)*2*eps dropped (OpenCV SVD back-substitution)
-__device__ void svd_backsubst(const double* w, const double* ut, const double* vt, int m, int n, const double* b, double* x)
+template <int M, int N>
+__device__ __forceinline__ void svd_backsubst_t(const double (&w)[N], const double (&ut)[N * M], const double (&vt)[N * N],
+                                                const double* b, double* x)
 {
     double thr = 0;
-    for (int i = 0; i < n; i++) thr += w[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) thr += w[i];
     thr *= kDblEps * 2;
-    for (int j = 0; j < n; j++) x[j] = 0;
-    for (int i = 0; i < n; i++) {
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
         double wi = w[i];
         if (fabs(wi) <= thr) continue;
         wi = 1 / wi;
         double s = 0;
-        for (int k = 0; k < m; k++) s += ut[i * m + k] * b[k];
+#pragma unroll
+        for (int k = 0; k < M; k++) s += ut[i * M + k] * b[k];
         s *= wi;
-        for (int j = 0; j < n; j++) x[j] += s * vt[i * n + j];
+#pragma unroll
+        for (int j = 0; j < N; j++) x[j] += s * vt[i * N + j];
     }
 }
 
-// least squares A x = b (A row-major 6 x n, n <= 5) through the SVD
-__device__ void solve_svd6(const double* A, int n, const double* b, double* x)
+// least squares A x = b (A row-major 6 x N, N <= 5) through the SVD
+template <int N>
+__device__ __forceinline__ void solve_svd6(const double* A, const double* b, double* x)
 {
-    double w[5], ut[30], vt[25];
-    for (int i = 0; i < n; i++)
-        for (int k = 0; k < 6; k++) ut[i * 6 + k] = A[k * n + i];
-    jacobi_svd(ut, 6, n, w, vt);
-    svd_backsubst(w, ut, vt, 6, n, b, x);
+    double w[N], ut[N * 6], vt[N * N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) ut[i * 6 + k] = A[k * N + i];
+    jacobi_svd_t<6, N, true>(ut, w, vt);
+    svd_backsubst_t<6, N>(w, ut, vt, b, x);
 }
 
 // SVD of a row-major 3x3: w, ut (rows = left vectors), vt
-__device__ void svd3(const double* A, double* w, double* ut, double* vt)
+__device__ __forceinline__ void svd3(const double* A, double (&w)[3], double (&ut)[9], double (&vt)[9])
 {
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int k = 0; k < 3; k++) ut[i * 3 + k] = A[k * 3 + i];
-    jacobi_svd(ut, 3, 3, w, vt);
+    jacobi_svd_t<3, 3, true>(ut, w, vt);
+}
+
+// 3x3 back-substitution used for the control-point inverse
+__device__ __forceinline__ void svd3_backsubst(const double (&w)[3], const double (&ut)[9], const double (&vt)[9], const double* b, double* x)
+{
+    svd_backsubst_t<3, 3>(w, ut, vt, b, x);
 }
 
 __device__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -207,6 +273,7 @@ __device__ void rodrigues_v2r(const double* r, double* R)
 {
     const double theta = sqrt_cr(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
     if (theta < kDblEps) {
+        #pragma unroll
         for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1. : 0.;
         return;
     }
@@ -214,6 +281,7 @@ __device__ void rodrigues_v2r(const double* r, double* R)
     const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
     const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
     const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = c * (k % 4 == 0 ? 1. : 0.) + c1 * rrt[k] + s * rx[k];
 }
 
@@ -221,9 +289,12 @@ __device__ void rodrigues_r2v(const double* R, double* r)
 {
     double w[3], ut[9], vt[9], Rn[9];
     svd3(R, w, ut, vt);
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             double s = 0;
+            #pragma unroll
             for (int k = 0; k < 3; k++) s += ut[k * 3 + i] * vt[k * 3 + j];
             Rn[i * 3 + j] = s;
         }
@@ -256,9 +327,12 @@ __device__ void control_points(const double* c0, const double* ptp, int n, doubl
 {
     double dc[3], uct[9], vt[9];
     svd3(ptp, dc, uct, vt);
+    #pragma unroll
     for (int j = 0; j < 3; j++) cws[0][j] = c0[j];
+    #pragma unroll
     for (int i = 1; i < 4; i++) {
         const double k = sqrt_cr(dc[i - 1] / n);
+        #pragma unroll
         for (int j = 0; j < 3; j++) cws[i][j] = c0[j] + k * uct[3 * (i - 1) + j];
     }
 }
@@ -267,19 +341,24 @@ __device__ void control_points(const double* c0, const double* ptp, int n, doubl
 __device__ void cc_inverse(const double cws[4][3], double* ci)
 {
     double cc[9], w[3], ut[9], vt[9];
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
     svd3(cc, w, ut, vt);
+    #pragma unroll
     for (int col = 0; col < 3; col++) {
         double b[3] = {0, 0, 0}, x[3];
         b[col] = 1;
-        svd_backsubst(w, ut, vt, 3, 3, b, x);
+        svd3_backsubst(w, ut, vt, b, x);
+        #pragma unroll
         for (int r = 0; r < 3; r++) ci[3 * r + col] = x[r];
     }
 }
 
 __device__ void barycentric(const double* ci, const double cws[4][3], const double* p, double* a)
 {
+    #pragma unroll
     for (int j = 0; j < 3; j++)
         a[1 + j] = ci[3 * j] * (p[0] - cws[0][0]) + ci[3 * j + 1] * (p[1] - cws[0][1]) + ci[3 * j + 2] * (p[2] - cws[0][2]);
     a[0] = 1.0 - a[1] - a[2] - a[3];
@@ -289,8 +368,10 @@ __device__ void compute_L_6x10(const double* ut, double* l)
 {
     const double* v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
     double dv[4][6][3];
+    #pragma unroll
     for (int i = 0; i < 4; i++) {
         int a = 0, b = 1;
+        #pragma unroll
         for (int j = 0; j < 6; j++) {
             dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
             dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
@@ -299,6 +380,7 @@ __device__ void compute_L_6x10(const double* ut, double* l)
             if (b > 3) { a++; b = a + 1; }
         }
     }
+    #pragma unroll
     for (int i = 0; i < 6; i++) {
         double* row = l + 10 * i;
         row[0] = dot3(dv[0][i], dv[0][i]);
@@ -324,10 +406,11 @@ __device__ void compute_rho(const double cws[4][3], double* rho)
 __device__ void betas_approx_1(const double* l, const double* rho, double* betas)      // [B11 B12 B13 B14]
 {
     double l4[24], b4[4];
+    #pragma unroll
     for (int i = 0; i < 6; i++) {
         l4[4 * i] = l[10 * i]; l4[4 * i + 1] = l[10 * i + 1]; l4[4 * i + 2] = l[10 * i + 3]; l4[4 * i + 3] = l[10 * i + 6];
     }
-    solve_svd6(l4, 4, rho, b4);
+    solve_svd6<4>(l4, rho, b4);
     if (b4[0] < 0) {
         betas[0] = sqrt_cr(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0];
     } else {
@@ -338,8 +421,9 @@ __device__ void betas_approx_1(const double* l, const double* rho, double* betas
 __device__ void betas_approx_2(const double* l, const double* rho, double* betas)      // [B11 B12 B22]
 {
     double l3[18], b3[3];
+    #pragma unroll
     for (int i = 0; i < 6; i++) { l3[3 * i] = l[10 * i]; l3[3 * i + 1] = l[10 * i + 1]; l3[3 * i + 2] = l[10 * i + 2]; }
-    solve_svd6(l3, 3, rho, b3);
+    solve_svd6<3>(l3, rho, b3);
     if (b3[0] < 0) {
         betas[0] = sqrt_cr(-b3[0]);
         betas[1] = (b3[2] < 0) ? sqrt_cr(-b3[2]) : 0.0;
@@ -354,9 +438,11 @@ __device__ void betas_approx_2(const double* l, const double* rho, double* betas
 __device__ void betas_approx_3(const double* l, const double* rho, double* betas)      // [B11 B12 B22 B13 B23]
 {
     double l5[30], b5[5];
+    #pragma unroll
     for (int i = 0; i < 6; i++)
+        #pragma unroll
         for (int j = 0; j < 5; j++) l5[5 * i + j] = l[10 * i + j];
-    solve_svd6(l5, 5, rho, b5);
+    solve_svd6<5>(l5, rho, b5);
     if (b5[0] < 0) {
         betas[0] = sqrt_cr(-b5[0]);
         betas[1] = (b5[2] < 0) ? sqrt_cr(-b5[2]) : 0.0;
@@ -374,9 +460,11 @@ __device__ void qr_solve(double* A, double* b, double* X)
 {
     const int nr = 6, nc = 4;
     double A1[4], A2[4];
+    #pragma unroll
     for (int k = 0; k < nc; k++) {
         double eta = fabs(A[k * nc + k]);
         // (the scan below mirrors epnp.cpp: rows k .. nr-2; eta only rescales the column)
+        #pragma unroll
         for (int i = k + 1; i < nr; i++) {
             const double elt = fabs(A[(i - 1) * nc + k]);
             if (eta < elt) eta = elt;
@@ -384,6 +472,7 @@ __device__ void qr_solve(double* A, double* b, double* X)
         if (eta == 0) return;
         double sum2 = 0.0;
         const double inv_eta = 1. / eta;
+        #pragma unroll
         for (int i = k; i < nr; i++) {
             A[i * nc + k] *= inv_eta;
             sum2 += A[i * nc + k] * A[i * nc + k];
@@ -393,22 +482,30 @@ __device__ void qr_solve(double* A, double* b, double* X)
         A[k * nc + k] += sigma;
         A1[k] = sigma * A[k * nc + k];
         A2[k] = -eta * sigma;
+        #pragma unroll
         for (int j = k + 1; j < nc; j++) {
             double sum = 0;
+            #pragma unroll
             for (int i = k; i < nr; i++) sum += A[i * nc + k] * A[i * nc + j];
             const double tau = sum / A1[k];
+            #pragma unroll
             for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
         }
     }
+    #pragma unroll
     for (int j = 0; j < nc; j++) {
         double tau = 0;
+        #pragma unroll
         for (int i = j; i < nr; i++) tau += A[i * nc + j] * b[i];
         tau /= A1[j];
+        #pragma unroll
         for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
     }
     X[nc - 1] = b[nc - 1] / A2[nc - 1];
+    #pragma unroll
     for (int i = nc - 2; i >= 0; i--) {
         double sum = 0;
+        #pragma unroll
         for (int j = i + 1; j < nc; j++) sum += A[i * nc + j] * X[j];
         X[i] = (b[i] - sum) / A2[i];
     }
@@ -416,8 +513,10 @@ __device__ void qr_solve(double* A, double* b, double* X)
 
 __device__ void gauss_newton(const double* l, const double* rho, double* betas)
 {
+    #pragma unroll 1
     for (int k = 0; k < 5; k++) {
         double A[24], B[6], X[4] = {0, 0, 0, 0};
+        #pragma unroll
         for (int i = 0; i < 6; i++) {
             const double* r = l + i * 10;
             double* a = A + i * 4;
@@ -431,16 +530,21 @@ __device__ void gauss_newton(const double* l, const double* rho, double* betas)
                              r[9] * betas[3] * betas[3]);
         }
         qr_solve(A, B, X);
+        #pragma unroll
         for (int i = 0; i < 4; i++) betas[i] += X[i];
     }
 }
 
 __device__ void compute_ccs(const double* betas, const double* ut, double ccs[4][3])
 {
+    #pragma unroll
     for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0;
+    #pragma unroll
     for (int i = 0; i < 4; i++) {
         const double* v = ut + 12 * (11 - i);
+        #pragma unroll
         for (int j = 0; j < 4; j++)
+            #pragma unroll
             for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[3 * j + k];
     }
 }
@@ -450,9 +554,12 @@ __device__ void orientation(const double* abt, const double* pc0, const double* 
 {
     double d[3], ut[9], vt[9];
     svd3(abt, d, ut, vt);
+    #pragma unroll
     for (int i = 0; i < 3; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) {
             double s = 0;
+            #pragma unroll
             for (int k = 0; k < 3; k++) s += ut[k * 3 + i] * vt[k * 3 + j];
             R[i][j] = s;
         }
@@ -470,38 +577,53 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
 {
     const int n = 5;
     double cws[4][3], c0[3] = {0, 0, 0}, ptp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    #pragma unroll
     for (int i = 0; i < n; i++)
+        #pragma unroll
         for (int j = 0; j < 3; j++) c0[j] += pws[3 * i + j];
+    #pragma unroll
     for (int j = 0; j < 3; j++) c0[j] /= n;
+    #pragma unroll
     for (int i = 0; i < n; i++) {
         double d[3];
+        #pragma unroll
         for (int j = 0; j < 3; j++) d[j] = pws[3 * i + j] - c0[j];
+        #pragma unroll
         for (int a = 0; a < 3; a++)
+            #pragma unroll
             for (int b = 0; b < 3; b++) ptp[a * 3 + b] += d[a] * d[b];
     }
     control_points(c0, ptp, n, cws);
     double ci[9], alphas[20];
     cc_inverse(cws, ci);
+    #pragma unroll
     for (int i = 0; i < n; i++) barycentric(ci, cws, pws + 3 * i, alphas + 4 * i);
 
     double mtm[144];
+    #pragma unroll
     for (int k = 0; k < 144; k++) mtm[k] = 0;
+    #pragma unroll
     for (int i = 0; i < n; i++) {
         const double* a = alphas + 4 * i;
         double m1[12], m2[12];
         const double u = us[2 * i], v = us[2 * i + 1];
+        #pragma unroll
         for (int j = 0; j < 4; j++) {
             m1[3 * j] = a[j] * cam.fu; m1[3 * j + 1] = 0.0; m1[3 * j + 2] = a[j] * (cam.uc - u);
             m2[3 * j] = 0.0; m2[3 * j + 1] = a[j] * cam.fv; m2[3 * j + 2] = a[j] * (cam.vc - v);
         }
+        #pragma unroll
         for (int p = 0; p < 12; p++)
+            #pragma unroll
             for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m1[p] * m1[q];
+        #pragma unroll
         for (int p = 0; p < 12; p++)
+            #pragma unroll
             for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m2[p] * m2[q];
     }
     double w12[12];
     // symmetric matrix: rows == columns, so the row image of A^T is the matrix itself
-    jacobi_svd(mtm, 12, 12, w12, nullptr);
+    jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
     const double* ut = mtm;
 
     double l[60], rho[6];
@@ -509,6 +631,7 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
     compute_rho(cws, rho);
 
     double best_err = 0;
+    #pragma unroll 1
     for (int c = 1; c <= 3; c++) {
         double betas[4];
         if (c == 1) betas_approx_1(l, rho, betas);
@@ -517,18 +640,26 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
         gauss_newton(l, rho, betas);
         double ccs[4][3], pcs[15];
         compute_ccs(betas, ut, ccs);
+        #pragma unroll
         for (int i = 0; i < n; i++) {
             const double* a = alphas + 4 * i;
+            #pragma unroll
             for (int j = 0; j < 3; j++) pcs[3 * i + j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j];
         }
         if (pcs[2] < 0.0)
+            #pragma unroll
             for (int i = 0; i < 3 * n; i++) pcs[i] = -pcs[i];
         double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+        #pragma unroll
         for (int i = 0; i < n; i++)
+            #pragma unroll
             for (int j = 0; j < 3; j++) { pc0[j] += pcs[3 * i + j]; pw0[j] += pws[3 * i + j]; }
+        #pragma unroll
         for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
         double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        #pragma unroll
         for (int i = 0; i < n; i++)
+            #pragma unroll
             for (int j = 0; j < 3; j++) {
                 abt[3 * j] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i] - pw0[0]);
                 abt[3 * j + 1] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + 1] - pw0[1]);
@@ -537,6 +668,7 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
         double R[3][3], t[3];
         orientation(abt, pc0, pw0, R, t);
         double sum2 = 0.0;
+        #pragma unroll
         for (int i = 0; i < n; i++) {
             const double* pw = pws + 3 * i;
             const double Xc = dot3(R[0], pw) + t[0], Yc = dot3(R[1], pw) + t[1];
@@ -548,7 +680,9 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
         const double err = sum2 / n;
         if (c == 1 || err < best_err) {
             best_err = err;
+            #pragma unroll
             for (int i = 0; i < 3; i++) {
+                #pragma unroll
                 for (int j = 0; j < 3; j++) Rout[3 * i + j] = R[i][j];
                 tout[i] = t[i];
             }
@@ -614,23 +748,19 @@ __device__ __forceinline__ bool is_inlier(const double* R, const double* t, cons
 
 constexpr int MAX_ITERS = 128;
 
-// One workgroup (256 threads) per problem.
-__global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __restrict__ probs, PnpResult* __restrict__ results,
-                                                         int iterations, double reproj_err, double confidence,
-                                                         int min_points)
+// Kernel 1 of 2 -- hypotheses.  One workgroup (128 lanes) per problem: lane 0 replays the sampler,
+// then one lane per minimal set solves the 5-point EPnP and stores the model (R from rvec, t) to
+// `hyp`.  A separate kernel because the register footprint of the inlined fp64 solver (it takes the
+// whole 512-entry file) must not be imposed on the scoring / refit phases, and so that the models of
+// ALL problems are solved in one resident round.
+__global__ __launch_bounds__(128, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
+                                                             int iterations, int min_points)
 {
     __shared__ int s_idx[MAX_ITERS][5];
-    __shared__ double s_R[MAX_ITERS][9];
-    __shared__ double s_t[MAX_ITERS][3];
-    __shared__ double s_red[4 * 56];
-    __shared__ int s_ired[4];
-    __shared__ int s_ctl[4];         // niters, best, max_good, iter
-    __shared__ double s_fit[64];     // refit scratch (control points, inverse, R, t ...)
-
     const PnpProblem pb = probs[blockIdx.x];
-    PnpResult& out = results[blockIdx.x];
     const int tid = threadIdx.x;
     const int n = pb.n;
+    if (n < min_points || n < 5) return;
     const float* PX = pb.pts;
     const float* PY = pb.pts + (size_t)pb.cap;
     const float* PZ = pb.pts + 2 * (size_t)pb.cap;
@@ -638,15 +768,6 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __res
     const float* PV = pb.pts + 4 * (size_t)pb.cap;
     Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
     if (iterations > MAX_ITERS) iterations = MAX_ITERS;
-
-    if (n < min_points || n < 5) {
-        if (tid == 0) {
-            for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1. : 0.;
-            out.t[0] = out.t[1] = out.t[2] = 0;
-            out.n_inliers = -1; out.iters = 0; out.best_iter = -1; out.ok = 0;
-        }
-        return;
-    }
 
     // ---- 1. replay the sampler
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
@@ -686,8 +807,63 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __res
         epnp5(cam, pws, us, R, t);
         rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
         rodrigues_v2r(rvec, R);
-        for (int k = 0; k < 9; k++) s_R[tid][k] = R[k];
-        for (int k = 0; k < 3; k++) s_t[tid][k] = t[k];
+        double* h = hyp + ((size_t)blockIdx.x * MAX_ITERS + tid) * 12;
+        for (int k = 0; k < 9; k++) h[k] = R[k];
+        for (int k = 0; k < 3; k++) h[9 + k] = t[k];
+    }
+}
+
+// State handed from the scoring kernel to the refit kernels (one record per problem).
+struct PnpFit {
+    double cws[12];      // control points of the inlier set
+    double ci[9];        // inverse of the control-point basis
+    double g[56];        // Gram sums (see pass B)
+    double a_first[4];   // barycentric coordinates of the first inlier (sign disambiguation)
+    double cand[36];     // three (R, t) candidates from the refit solve
+    int best, max_good, iters, state;   // state: 0 = refit pending, 1 = result already final
+};
+
+// Kernel 2 of 4 -- scoring in OpenCV's order with the adaptive bound, then the two reduction passes
+// of the EPnP refit over the inliers of the winning hypothesis (centroid/covariance -> control
+// points; Gram sums).  One workgroup (256 threads) per problem.
+__global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
+                                                              PnpResult* __restrict__ results, PnpFit* __restrict__ fits, int iterations,
+                                                              double reproj_err, double confidence, int min_points)
+{
+    PnpFit& fit = fits[blockIdx.x];
+    __shared__ double s_R[MAX_ITERS][9];
+    __shared__ double s_t[MAX_ITERS][3];
+    __shared__ double s_red[4 * 56];
+    __shared__ int s_ired[4];
+    __shared__ int s_ctl[4];         // niters, best, max_good, iter
+    __shared__ double s_fit[24];     // control points + inverse, thread 0 -> all
+
+    const PnpProblem pb = probs[blockIdx.x];
+    PnpResult& out = results[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n = pb.n;
+    const float* PX = pb.pts;
+    const float* PY = pb.pts + (size_t)pb.cap;
+    const float* PZ = pb.pts + 2 * (size_t)pb.cap;
+    const float* PU = pb.pts + 3 * (size_t)pb.cap;
+    const float* PV = pb.pts + 4 * (size_t)pb.cap;
+    Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
+    if (iterations > MAX_ITERS) iterations = MAX_ITERS;
+
+    if (n < min_points || n < 5) {
+        if (tid == 0) {
+            for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1. : 0.;
+            out.t[0] = out.t[1] = out.t[2] = 0;
+            out.n_inliers = -1; out.iters = 0; out.best_iter = -1; out.ok = 0;
+            fit.state = 1;
+        }
+        return;
+    }
+    const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
+    for (int i = tid; i < n_hyp * 12; i += 256) {
+        const int h = i / 12, k = i - h * 12;
+        const double v = hyp[((size_t)blockIdx.x * MAX_ITERS + h) * 12 + k];
+        if (k < 9) s_R[h][k] = v; else s_t[h][k - 9] = v;
     }
     if (tid == 0) { s_ctl[0] = n_hyp; s_ctl[1] = -1; s_ctl[2] = 0; s_ctl[3] = 0; }
     __syncthreads();
@@ -724,6 +900,7 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __res
             for (int k = 0; k < 9; k++) out.R[k] = (k % 4 == 0) ? 1. : 0.;
             out.t[0] = out.t[1] = out.t[2] = 0;
             out.n_inliers = -1; out.iters = iters_run; out.best_iter = -1; out.ok = 0;
+            fit.state = 1;
         }
         return;
     }
@@ -732,6 +909,7 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __res
             for (int k = 0; k < 9; k++) out.R[k] = s_R[0][k];
             for (int k = 0; k < 3; k++) out.t[k] = s_t[0][k];
             out.n_inliers = 5; out.iters = 0; out.best_iter = 0; out.ok = 1;
+            fit.state = 1;
         }
         if (pb.mask) for (int i = tid; i < n; i += 256) pb.mask[i] = 1;
         return;
@@ -809,64 +987,123 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __res
     }
     block_reduce<56>(g, s_red);
 
-    // thread 0: 12x12 SVD, betas, three (R,t) candidates -> LDS; then a last pass picks by reprojection error
     if (tid == 0) {
-        double mtm[144];
-        auto pair = [](int j, int k) { if (j > k) { int t = j; j = k; k = t; } return j * 4 - j * (j - 1) / 2 + (k - j); };
-        for (int j = 0; j < 4; j++)
-            for (int k = 0; k < 4; k++) {
-                const int e = pair(j, k);
-                const double s0 = g[e], s1 = g[10 + e], s2 = g[20 + e], s3 = g[30 + e];
-                double* b = mtm + (3 * j) * 12 + 3 * k;
-                b[0] = cam.fu * cam.fu * s0; b[1] = 0;                     b[2] = cam.fu * s1;
-                b[12] = 0;                   b[13] = cam.fv * cam.fv * s0; b[14] = cam.fv * s2;
-                b[24] = cam.fu * s1;         b[25] = cam.fv * s2;          b[26] = s3;
-            }
-        double w12[12];
-        jacobi_svd(mtm, 12, 12, w12, nullptr);
-        const double* ut = mtm;
-        double l[60], rho[6];
-        compute_L_6x10(ut, l);
-        compute_rho(cws, rho);
-        for (int c = 0; c < 3; c++) {
-            double betas[4];
-            if (c == 0) betas_approx_1(l, rho, betas);
-            else if (c == 1) betas_approx_2(l, rho, betas);
-            else betas_approx_3(l, rho, betas);
-            gauss_newton(l, rho, betas);
-            double ccs[4][3];
-            compute_ccs(betas, ut, ccs);
-            // sign: depth of the FIRST inlier's camera-frame point (epnp solve_for_sign uses pcs[2])
-            {
-                int first = 0;
-                while (first < n && !is_inlier(Rb, tb, cam, PX[first], PY[first], PZ[first], PU[first], PV[first], thr2)) ++first;
-                const double p[3] = {PX[first], PY[first], PZ[first]};
-                double a[4];
-                barycentric(ci, cws, p, a);
-                const double z = a[0] * ccs[0][2] + a[1] * ccs[1][2] + a[2] * ccs[2][2] + a[3] * ccs[3][2];
-                if (z < 0.0)
-                    for (int i = 0; i < 4; i++)
-                        for (int j = 0; j < 3; j++) ccs[i][j] = -ccs[i][j];
-            }
-            double pc0[3], abt[9];
-            for (int j = 0; j < 3; j++) {
-                pc0[j] = (g[40] * ccs[0][j] + g[41] * ccs[1][j] + g[42] * ccs[2][j] + g[43] * ccs[3][j]) / m;
-                for (int k = 0; k < 3; k++)
-                    abt[3 * j + k] = ccs[0][j] * g[44 + k] + ccs[1][j] * g[47 + k] + ccs[2][j] * g[50 + k] + ccs[3][j] * g[53 + k];
-            }
-            double R[3][3], t[3];
-            orientation(abt, pc0, cws[0], R, t);
-            for (int i = 0; i < 3; i++) {
-                for (int j = 0; j < 3; j++) s_fit[21 + 12 * c + 3 * i + j] = R[i][j];
-                s_fit[21 + 12 * c + 9 + i] = t[i];
-            }
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 3; j++) fit.cws[3 * i + j] = cws[i][j];
+        for (int k = 0; k < 9; k++) fit.ci[k] = ci[k];
+        for (int k = 0; k < 56; k++) fit.g[k] = g[k];
+        // epnp's solve_for_sign looks at the depth of the FIRST inlier's camera-frame point
+        int first = 0;
+        while (first < n && !is_inlier(Rb, tb, cam, PX[first], PY[first], PZ[first], PU[first], PV[first], thr2)) ++first;
+        const double p[3] = {PX[first], PY[first], PZ[first]};
+        double a[4];
+        barycentric(ci, cws, p, a);
+        for (int k = 0; k < 4; k++) fit.a_first[k] = a[k];
+        fit.best = best; fit.max_good = max_good; fit.iters = iters_run; fit.state = 0;
+    }
+}
+
+// Kernel 3 of 4 -- the refit solve: one LANE per problem (register-resident 12x12 SVD, betas,
+// Gauss-Newton, absolute orientation for the three beta cases).
+__global__ __launch_bounds__(64, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
+{
+    const int pi = blockIdx.x * 64 + threadIdx.x;
+    if (pi >= n_problems) return;
+    PnpFit& fit = fits[pi];
+    if (fit.state != 0) return;
+    const PnpProblem& pb = probs[pi];
+    Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
+    double g[56], cws[4][3];
+#pragma unroll
+    for (int k = 0; k < 56; k++) g[k] = fit.g[k];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) cws[i][j] = fit.cws[3 * i + j];
+    const int m = fit.max_good;
+    double mtm[144];
+    // pair index of (j,k), j <= k, in the order pass B enumerates them
+    constexpr int PAIR[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = PAIR[j][k];
+            const double s0 = g[e], s1 = g[10 + e], s2 = g[20 + e], s3 = g[30 + e];
+            const int o = (3 * j) * 12 + 3 * k;
+            mtm[o] = cam.fu * cam.fu * s0; mtm[o + 1] = 0;                     mtm[o + 2] = cam.fu * s1;
+            mtm[o + 12] = 0;               mtm[o + 13] = cam.fv * cam.fv * s0; mtm[o + 14] = cam.fv * s2;
+            mtm[o + 24] = cam.fu * s1;     mtm[o + 25] = cam.fv * s2;          mtm[o + 26] = s3;
+        }
+    double w12[12];
+    jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
+    const double* ut = mtm;
+    double l[60], rho[6];
+    compute_L_6x10(ut, l);
+    compute_rho(cws, rho);
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        double betas[4];
+        if (c == 0) betas_approx_1(l, rho, betas);
+        else if (c == 1) betas_approx_2(l, rho, betas);
+        else betas_approx_3(l, rho, betas);
+        gauss_newton(l, rho, betas);
+        double ccs[4][3];
+        compute_ccs(betas, ut, ccs);
+        const double z = fit.a_first[0] * ccs[0][2] + fit.a_first[1] * ccs[1][2] + fit.a_first[2] * ccs[2][2] + fit.a_first[3] * ccs[3][2];
+        if (z < 0.0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) ccs[i][j] = -ccs[i][j];
+        }
+        double pc0[3], abt[9];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            pc0[j] = (g[40] * ccs[0][j] + g[41] * ccs[1][j] + g[42] * ccs[2][j] + g[43] * ccs[3][j]) / m;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                abt[3 * j + k] = ccs[0][j] * g[44 + k] + ccs[1][j] * g[47 + k] + ccs[2][j] * g[50 + k] + ccs[3][j] * g[53 + k];
+        }
+        double R[3][3], t[3];
+        orientation(abt, pc0, cws[0], R, t);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) fit.cand[12 * c + 3 * i + j] = R[i][j];
+            fit.cand[12 * c + 9 + i] = t[i];
         }
     }
-    __syncthreads();
+}
+
+// Kernel 4 of 4 -- pick among the three candidates by mean reprojection error over the inliers and
+// write the result (through the same rvec round trip solvePnP + cv2.Rodrigues perform).
+__global__ __launch_bounds__(256) void pnp_fit_select_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
+                                                             const PnpFit* __restrict__ fits, PnpResult* __restrict__ results,
+                                                             double reproj_err)
+{
+    __shared__ double s_red[4 * 3];
+    const PnpFit& fit = fits[blockIdx.x];
+    if (fit.state != 0) return;
+    const PnpProblem pb = probs[blockIdx.x];
+    PnpResult& out = results[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n = pb.n;
+    const float* PX = pb.pts;
+    const float* PY = pb.pts + (size_t)pb.cap;
+    const float* PZ = pb.pts + 2 * (size_t)pb.cap;
+    const float* PU = pb.pts + 3 * (size_t)pb.cap;
+    const float* PV = pb.pts + 4 * (size_t)pb.cap;
+    Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
+    const float thr2 = (float)(reproj_err * reproj_err);
+    double Rb[9], tb[3];
+    const double* hb = hyp + ((size_t)blockIdx.x * MAX_ITERS + fit.best) * 12;
+    for (int k = 0; k < 9; k++) Rb[k] = hb[k];
+    for (int k = 0; k < 3; k++) tb[k] = hb[9 + k];
     double Rc[3][9], tc[3][3];
     for (int c = 0; c < 3; c++) {
-        for (int k = 0; k < 9; k++) Rc[c][k] = s_fit[21 + 12 * c + k];
-        for (int k = 0; k < 3; k++) tc[c][k] = s_fit[21 + 12 * c + 9 + k];
+        for (int k = 0; k < 9; k++) Rc[c][k] = fit.cand[12 * c + k];
+        for (int k = 0; k < 3; k++) tc[c][k] = fit.cand[12 * c + 9 + k];
     }
     double e3[3] = {0, 0, 0};
     for (int i = tid; i < n; i += 256) {
@@ -890,18 +1127,31 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(const PnpProblem* __res
         rodrigues_v2r(rvec, R);
         for (int k = 0; k < 9; k++) out.R[k] = R[k];
         for (int k = 0; k < 3; k++) out.t[k] = tc[N][k];
-        out.n_inliers = max_good; out.iters = iters_run; out.best_iter = best; out.ok = 1;
+        out.n_inliers = fit.max_good; out.iters = fit.iters; out.best_iter = fit.best; out.ok = 1;
     }
 }
 
 }  // namespace pnp
 
+size_t pnp_workspace_bytes(int n_problems)
+{
+    return (size_t)n_problems * (pnp::MAX_ITERS * 12 * sizeof(double) + sizeof(pnp::PnpFit));
+}
+
 hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_problems, int iterations,
-                             double reproj_err, double confidence, int min_points, hipStream_t s)
+                             double reproj_err, double confidence, int min_points, double* workspace, hipStream_t s)
 {
     if (n_problems <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pnp::pnp_ransac_kernel, dim3(n_problems), dim3(256), 0, s, probs, results, iterations, reproj_err,
-                       confidence, min_points);
+    hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(n_problems), dim3(128), 0, s, probs, workspace, iterations, min_points);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    pnp::PnpFit* fits = reinterpret_cast<pnp::PnpFit*>(workspace + (size_t)n_problems * pnp::MAX_ITERS * 12);
+    hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
+                       reproj_err, confidence, min_points);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, s, probs, fits, n_problems);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);
     return hipGetLastError();
 }
 

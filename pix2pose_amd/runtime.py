@@ -225,6 +225,49 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
     return [poses[i] for i in range(n)], extras
 
 
+class PendingBatch:
+    """Handle of a batch enqueued with est_pose_submit (keeps the argument buffers alive)."""
+
+    def __init__(self, ctx, ticket, n, keep):
+        self.ctx, self.ticket, self.n, self._keep = ctx, ticket, n, keep
+
+    def collect(self):
+        """Wait for the batch; -> list of p2p_pose records in the caller's detection order."""
+        poses = (_lib.Pose * max(self.n, 1))()
+        _lib.check(_lib.lib().p2p_est_pose_collect(self.ctx.handle, self.ticket, poses), "p2p_est_pose_collect")
+        self._keep = None
+        return [poses[i] for i in range(self.n)]
+
+
+def est_pose_submit(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
+                    ransac_iterations=0, reprojection_error=0.0, confidence=0.0) -> PendingBatch:
+    """Asynchronous est_pose_batch for detection streams: enqueue and return; at most two batches in
+    flight per context.  The PnP-RANSAC tail of this batch overlaps the generator passes of the next."""
+    n = len(detections)
+    objs = (_lib.Object * max(len(objects), 1))(*[o.as_struct() for o in objects])
+    keep = [objs, objects]
+    imgs = (_lib.Image * max(len(images), 1))()
+    for i, im in enumerate(images):
+        imgs[i], a = _image_struct(im)
+        keep.append(a)
+    dets = (_lib.Detection * max(n, 1))()
+    for i, (ii, oi, bbox, K) in enumerate(detections):
+        dets[i].image, dets[i].object = int(ii), int(oi)
+        for k in range(4):
+            dets[i].bbox[k] = int(bbox[k])
+        Kf = np.asarray(K, np.float64).reshape(9)
+        for k in range(9):
+            dets[i].camK[k] = Kf[k]
+    opts = _lib.EstPoseOpts()
+    opts.ransac_iterations, opts.reprojection_error, opts.confidence = ransac_iterations, reprojection_error, confidence
+    opts.inject1, opts.inject2, opts.inject_slots = inject1, inject2, inject_slots
+    ticket = C.c_int(-1)
+    _lib.check(_lib.lib().p2p_est_pose_submit(ctx.handle, objs, len(objects), imgs, len(images), dets, n, C.byref(opts),
+                                              C.byref(ticket)), "p2p_est_pose_submit")
+    keep += [imgs, dets, images]
+    return PendingBatch(ctx, ticket.value, n, keep)
+
+
 def pnp_ransac_batch(ctx: Context, Ks, objs, imgs, iterations=100, reproj_err=5.0, confidence=0.99, want_mask=False):
     """Batch of independent cv2.solvePnPRansac(EPNP) problems on the GPU.
     -> ok [P] bool, R [P,3,3], t [P,3], info [P,3] (n_inliers, iterations, best_iter), masks list|None"""

@@ -70,3 +70,40 @@ def test_est_pose_256_detections_invariants():
         R = np.array(p.R).reshape(3, 3)
         assert abs(np.linalg.det(R) - 1) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
         assert 0 < p.frac_inlier <= 4.0 and p.n_inliers >= 5
+
+
+def test_async_submit_collect_equals_blocking():
+    """Stream mode (two batches in flight, PnP tail on a second HIP stream) returns exactly what the
+    blocking call returns, batch after batch; misuse is reported, not hung."""
+    import torch
+    from pix2pose_amd import _lib
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch, est_pose_submit
+    ctx = Context(0, max_batch=64)
+    gen = Generator(W.synthetic_weights("paper", 1), "paper", ctx)
+    spec = ObjectSpec(gen, S.OBJ_PARAM, TH_O, TH_I)
+    scenes = [S.make_scene(24, seed=40 + k) for k in range(4)]
+    inj = [(torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()) for sc in scenes]
+    torch.cuda.synchronize()
+    ref = [est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3)[0]
+           for sc, (a, b) in zip(scenes, inj)]
+    pend, got = [], []
+    for sc, (a, b) in zip(scenes, inj):
+        pend.append(est_pose_submit(ctx, [spec], list(sc["images"]), sc["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3))
+        if len(pend) == 2:
+            got.append(pend.pop(0).collect())
+    while pend:
+        got.append(pend.pop(0).collect())
+    for r, g in zip(ref, got):
+        assert [_key(x) for x in r] == [_key(x) for x in g]
+    # three in flight -> capacity error; blocking call while one is in flight -> error; then recover
+    a, b = inj[0]
+    p1 = est_pose_submit(ctx, [spec], list(scenes[0]["images"]), scenes[0]["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3)
+    p2 = est_pose_submit(ctx, [spec], list(scenes[0]["images"]), scenes[0]["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3)
+    with pytest.raises(_lib.P2PError):
+        est_pose_submit(ctx, [spec], list(scenes[0]["images"]), scenes[0]["dets"])
+    with pytest.raises(_lib.P2PError):
+        est_pose_batch(ctx, [spec], list(scenes[0]["images"]), scenes[0]["dets"])
+    assert [_key(x) for x in p1.collect()] == [_key(x) for x in ref[0]]
+    assert [_key(x) for x in p2.collect()] == [_key(x) for x in ref[0]]
+    with pytest.raises(_lib.P2PError):
+        p2.collect()                      # ticket no longer in flight
