@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     __shared__ int row_base[BM];   // n*Hin*Win, or -1 for rows past M
     __shared__ int row_yx[BM];     // (iy0 << 16) | ix0
     __shared__ int row_out[BM];    // output pixel index, or -1
+    __shared__ int s_tap[IGEMM_MAX_TAPS + 3];   // dy * Win + dx (pixels): read from LDS in the K loop --
+                                                // indexing the kernarg arrays there costs a dependent
+                                                // global load + wait at the top of every K-step
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
+    if (tid < p.ntaps) s_tap[tid] = (int)p.dy[tid] * p.Win + (int)p.dx[tid];
     const int HgWg = p.Hg * p.Wg;
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
@@ -90,16 +94,38 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     }
     __syncthreads();
 
-    // ---- loader state: thread handles rows (tid>>3)+32*j, 16-byte column segment (tid&7)
+    // ---- loader state: thread handles rows (tid>>3)+32*j, 16-byte column segment (tid&7).
+    //      The gather uses raw buffer loads (32-bit per-lane byte offsets against a wave-uniform
+    //      descriptor): per K-step and row it costs one add, one bit test and one select -- a tap
+    //      that falls outside the image gets an out-of-range offset and the hardware returns zeros,
+    //      so there is no branch and no pointer arithmetic in the loop.  Which taps are inside the
+    //      image is a per-row bit mask computed once per tile.
     const int lrow = tid >> 3;
     const int lcol = (tid & 7) * 4;
-    int a_base[A_PASSES], a_yx[A_PASSES];
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned a_off0[A_PASSES], a_off1[A_PASSES], a_mask[A_PASSES];
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
-        a_base[j] = row_base[lrow + 32 * j];
-        a_yx[j] = row_yx[lrow + 32 * j];
+        const int base = row_base[lrow + 32 * j];
+        const int yx = row_yx[lrow + 32 * j];
+        const int iy0 = yx >> 16, ix0 = yx & 0xffff;
+        const unsigned pix = (unsigned)(base + iy0 * p.Win + ix0);
+        a_off0[j] = (pix * (unsigned)p.seg[0].cstride + (unsigned)(p.seg[0].coff + lcol)) * 4u;
+        a_off1[j] = (pix * (unsigned)p.seg[1].cstride + (unsigned)(p.seg[1].coff + lcol)) * 4u;
+        unsigned m = 0;
+        if (base >= 0)
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int iy = iy0 + (int)p.dy[t], ix = ix0 + (int)p.dx[t];
+                if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) m |= 1u << t;
+            }
+        a_mask[j] = m;
     }
-    const float* wrow = p.w + (size_t)(n0 + lrow) * p.K + lcol;
+    unsigned b_off[B_PASSES];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) b_off[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)p.K + (unsigned)lcol) * 4u;
+    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].ptr, 0, p.seg_bytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.seg[1].ptr ? p.seg[1].ptr : p.seg[0].ptr), 0, p.seg_bytes[1], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
     // ---- split-K range
     const int ks_per = (p.ksteps + p.ksplit - 1) / p.ksplit;
@@ -116,26 +142,21 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
 
     f32x4 ra[A_PASSES], rb[B_PASSES];
 
-    auto gload = [&](int ks) {
-        const int tap = ks / p.chunks_per_tap;
-        const int chunk = ks - tap * p.chunks_per_tap;
-        const int s = chunk >= p.seg0_chunks;
-        const IgemmSeg sg = p.seg[s];
-        const int c = (s ? chunk - p.seg0_chunks : chunk) * IGEMM_BK + sg.coff + lcol;
-        const int dy = p.dy[tap], dx = p.dx[tap];
+    // (tap, chunk) of a K-step are carried incrementally (no division in the loop).
+    auto gload = [&](int ks, int tap, int chunk) {
+        const bool s1 = chunk >= p.seg0_chunks;                      // wave-uniform
+        const int toff = __builtin_amdgcn_readfirstlane(
+            (s_tap[tap] * (s1 ? p.seg[1].cstride : p.seg[0].cstride) + (s1 ? chunk - p.seg0_chunks : chunk) * IGEMM_BK) * 4);
+        const unsigned bit = 1u << tap;
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) {
-            const int iy = (a_yx[j] >> 16) + dy;
-            const int ix = (a_yx[j] & 0xffff) + dx;
-            const bool ok = a_base[j] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(sg.ptr + (size_t)(a_base[j] + iy * p.Win + ix) * sg.cstride + c);
-            ra[j] = v;
+            const unsigned off = (a_mask[j] & bit) ? (s1 ? a_off1[j] : a_off0[j]) + (unsigned)toff : OOB;
+            ra[j] = __builtin_bit_cast(f32x4, s1 ? __builtin_amdgcn_raw_buffer_load_b128(rs_a1, off, 0, 0)
+                                                 : __builtin_amdgcn_raw_buffer_load_b128(rs_a0, off, 0, 0));
         }
-        const float* wp = wrow + (size_t)ks * IGEMM_BK;
+        const int koff = ks * (IGEMM_BK * 4);                         // bytes along K, wave-uniform
 #pragma unroll
-        for (int j = 0; j < B_PASSES; ++j)
-            rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * j) * p.K);
+        for (int j = 0; j < B_PASSES; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[j], koff, 0));
     };
     auto lstore = [&]() {
         float* As = smem;
@@ -148,8 +169,9 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
             *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_LD + lcol) = rb[j];
     };
 
+    int tap = ks0 / p.chunks_per_tap, chunk = ks0 - tap * p.chunks_per_tap;
     if (ks0 < ks1) {
-        gload(ks0);
+        gload(ks0, tap, chunk);
         lstore();
     }
     __syncthreads();
@@ -158,7 +180,8 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     const float* Bs = smem + BM * LDS_LD + (wn * TN * 32 + li) * LDS_LD + lk * 4;
     for (int ks = ks0; ks < ks1; ++ks) {
         const bool more = ks + 1 < ks1;
-        if (more) gload(ks + 1);          // global loads of the next K-step fly under this step's MFMAs
+        if (++chunk == p.chunks_per_tap) { chunk = 0; ++tap; }
+        if (more) gload(ks + 1, tap, chunk);   // global loads of the next K-step fly under this step's MFMAs
 #pragma unroll
         for (int kk = 0; kk < IGEMM_BK; kk += 8) {
             f32x4 a[TM], b[TN];

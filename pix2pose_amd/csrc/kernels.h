@@ -33,6 +33,8 @@ struct IgemmParams {
     int ntaps;
     int8_t dy[IGEMM_MAX_TAPS + 3];
     int8_t dx[IGEMM_MAX_TAPS + 3];
+    unsigned seg_bytes[2]; // byte extent of each segment's tensor (buffer-descriptor range)
+    unsigned w_bytes;      // byte extent of the weight panel
     const float* w;        // [Cout_pad][K], K = ntaps * Cin_total, rows padded to a multiple of 128
     int K;
     int Cout;

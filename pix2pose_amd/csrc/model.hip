@@ -371,6 +371,17 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     p.ntaps = L.ntaps;
     memcpy(p.dy, L.dy, sizeof(L.dy));
     memcpy(p.dx, L.dx, sizeof(L.dx));
+    {
+        // buffer-descriptor ranges (32-bit): tensors are < 4 GB for max_batch <= 1024
+        const size_t px = (size_t)c.N * c.Hin * c.Win;
+        const size_t b0 = px * c.s0.cstride * sizeof(float), b1 = px * c.s1.cstride * sizeof(float);
+        const size_t bw = (size_t)((L.Cout + 127) / 128 * 128) * L.K * sizeof(float);
+        if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) {
+            set_error("run_conv: tensor exceeds the 4 GB buffer-descriptor range (lower max_batch)");
+            return P2P_ERR_CAPACITY;
+        }
+        p.seg_bytes[0] = (unsigned)b0; p.seg_bytes[1] = (unsigned)(c.s1.ptr ? b1 : b0); p.w_bytes = (unsigned)bw;
+    }
     p.w = L.w; p.K = L.K; p.Cout = L.Cout;
     p.ksteps = L.K / IGEMM_BK;
     p.ksplit = c.ksplit; p.partial = c.partial;

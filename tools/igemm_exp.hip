@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // BK: k-step; NBUF: LDS buffers; MID: store next tile to LDS in the middle of the MFMA block; PRIO: setprio
-template <int BK, int NBUF, int MID, int PRIO, int EPI = 1>
+template <int BK, int NBUF, int MID, int PRIO, int EPI = 1, int ABL = 0>
 __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
 {
     constexpr int WGM = 2, WGN = 2, TM = 2, TN = 2;
@@ -64,12 +64,14 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
             const int iy = (a_yx[j] >> 16) + dy, ix = (a_yx[j] & 0xffff) + dx;
             const bool ok = a_base[j] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(sg.ptr + (size_t)(a_base[j] + iy * p.Win + ix) * sg.cstride + c);
+            size_t off = (size_t)(a_base[j] + iy * p.Win + ix) * sg.cstride + c;
+            if (ABL & 4) off &= 1023;
+            if (ok) v = *reinterpret_cast<const f32x4*>(sg.ptr + off);
             ra[j] = v;
         }
         const float* wp = wrow + (size_t)ks * BK;
 #pragma unroll
-        for (int j = 0; j < B_PASSES; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(RPP * j) * p.K);
+        for (int j = 0; j < B_PASSES; ++j) { size_t off = (size_t)(RPP * j) * p.K; if (ABL & 4) off &= 1023; rb[j] = *reinterpret_cast<const f32x4*>((ABL & 4 ? p.w : wp) + off); }
     };
     auto lstore = [&](int buf) {
         float* As = smem + buf * (BM + BN) * LD; float* Bs = As + BM * LD;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
     int cur = 0;
     for (int ks = 0; ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
-        if (more) gload(ks + 1);
+        if (more && !(ABL & 1)) gload(ks + 1);
         const float* As = smem + cur * (BM + BN) * LD + (wm * TM * 32 + li) * LD + lk * 4;
         const float* Bs = smem + cur * (BM + BN) * LD + BM * LD + (wn * TN * 32 + li) * LD + lk * 4;
         if (PRIO) __builtin_amdgcn_s_setprio(1);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
             for (int kk = 0; kk < BK; kk += 8) mma(As, Bs, kk);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
-            if (more) lstore(0);
+            if (more && !(ABL & 2)) lstore(0);
             __syncthreads();
         }
     }
@@ -184,15 +186,118 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
     }
 }
 
-template <int BK, int NBUF, int MID, int PRIO, int EPI = 1>
+
+// distance-2 register prefetch: loads for step k+2 are issued while step k computes (two register sets)
+__global__ __launch_bounds__(256) void kpf2(const IgemmParams p)
+{
+    constexpr int BK = 32, WGN = 2, TM = 2, TN = 2, BM = 128, BN = 128, LD = 36, RPP = 32, A_PASSES = 4, B_PASSES = 4;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LD];
+    __shared__ int row_base[BM], row_yx[BM], row_out[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN, li = lane & 31, lk = lane >> 5;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int t;
+    { const int b = blockIdx.x; const int q = nblk >> 3, r = nblk & 7; const int xcd = b & 7, idx = b >> 3;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+    const int tile_n = t % tiles_n, tile_m = t / tiles_n, m0 = tile_m * BM, n0 = tile_n * BN;
+    const int HgWg = p.Hg * p.Wg;
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r; int base = -1, yx = 0, op = -1;
+        if (m < p.M) { const int n = m / HgWg; const int rem = m - n * HgWg; const int gy = rem / p.Wg; const int gx = rem - gy * p.Wg;
+            base = n * p.Hin * p.Win; yx = ((gy * p.in_stride) << 16) | (gx * p.in_stride); op = (n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox; }
+        row_base[r] = base; row_yx[r] = yx; row_out[r] = op;
+    }
+    __syncthreads();
+    const int lrow = tid / 8, lcol = (tid % 8) * 4;
+    int a_base[A_PASSES], a_yx[A_PASSES];
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) { a_base[j] = row_base[lrow + RPP * j]; a_yx[j] = row_yx[lrow + RPP * j]; }
+    const float* wrow = p.w + (size_t)(n0 + lrow) * p.K + lcol;
+    const int ksteps = p.K / BK, cpt = (p.seg[0].C) / BK;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
+    auto gload = [&](int ks, f32x4* ra, f32x4* rb) {
+        const int tap = ks / cpt; const int chunk = ks - tap * cpt;
+        const IgemmSeg sg = p.seg[0];
+        const int c = chunk * BK + lcol;
+        const int dy = p.dy[tap], dx = p.dx[tap];
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) {
+            const int iy = (a_yx[j] >> 16) + dy, ix = (a_yx[j] & 0xffff) + dx;
+            const bool ok = a_base[j] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(sg.ptr + (size_t)(a_base[j] + iy * p.Win + ix) * sg.cstride + c);
+            ra[j] = v;
+        }
+        const float* wp = wrow + (size_t)ks * BK;
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(RPP * j) * p.K);
+    };
+    auto lstore = [&](const f32x4* ra, const f32x4* rb) {
+        float* As = smem; float* Bs = As + BM * LD;
+#pragma unroll
+        for (int j = 0; j < A_PASSES; ++j) *reinterpret_cast<f32x4*>(As + (lrow + RPP * j) * LD + lcol) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LD + lcol) = rb[j];
+    };
+    const float* As = smem + (wm * TM * 32 + li) * LD + lk * 4;
+    const float* Bs = smem + BM * LD + (wn * TN * 32 + li) * LD + lk * 4;
+    auto compute = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LD + kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LD + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+    gload(0, ra0, rb0); lstore(ra0, rb0);
+    if (ksteps > 1) gload(1, ra0, rb0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ks += 2) {       // ksteps even in the probed shapes
+        if (ks + 2 < ksteps) gload(ks + 2, ra1, rb1);
+        compute();
+        __syncthreads();
+        if (ks + 1 < ksteps) { lstore(ra0, rb0); }
+        __syncthreads();
+        if (ks + 3 < ksteps) gload(ks + 3, ra0, rb0);
+        if (ks + 1 < ksteps) compute();
+        __syncthreads();
+        if (ks + 2 < ksteps) { lstore(ra1, rb1); }
+        __syncthreads();
+    }
+    float* o = p.out;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int col = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int op = row_out[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk]; if (op >= 0) o[(size_t)op * p.out_cstride + col] = acc[i][j][r]; } }
+}
+
+template <int BK, int NBUF, int MID, int PRIO, int EPI = 1, int ABL = 0>
 static float run(const IgemmParams& p, int iters)
 {
     const int tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((kexp<BK, NBUF, MID, PRIO, EPI>), dim3(tiles), dim3(256), 0, 0, p);
+    hipLaunchKernelGGL((kexp<BK, NBUF, MID, PRIO, EPI, ABL>), dim3(tiles), dim3(256), 0, 0, p);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((kexp<BK, NBUF, MID, PRIO, EPI>), dim3(tiles), dim3(256), 0, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((kexp<BK, NBUF, MID, PRIO, EPI, ABL>), dim3(tiles), dim3(256), 0, 0, p);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     if (hipGetLastError() != hipSuccess) printf("launch error\n");
@@ -214,15 +319,29 @@ int main(int argc, char** argv)
     p.seg[0] = {x, C, C, 0}; p.seg0_chunks = C / 32; p.chunks_per_tap = C / 32;
     p.N = N; p.Hin = p.Win = H; p.Hg = p.Wg = H; p.M = N * H * H; p.in_stride = 1; p.ntaps = KS * KS;
     for (int a = 0; a < KS; ++a) for (int b = 0; b < KS; ++b) { p.dy[a * KS + b] = a - KS / 2; p.dx[a * KS + b] = b - KS / 2; }
-    p.w = w; p.K = KS * KS * C; p.Cout = Co; p.ksteps = p.K / 32; p.ksplit = 1;
+    p.zeros = w; p.w = w; p.K = KS * KS * C; p.Cout = Co; p.ksteps = p.K / 32; p.ksplit = 1;
     p.out = y; p.Hout = p.Wout = H; p.os = 1; p.out_cstride = Co;
     float* res = nullptr;
     if (argc > 6 && atoi(argv[6])) { hipMalloc(&res, nout * 4); hipMemset(res, 0, nout * 4); p.residual = res; p.res_cstride = Co; }
     const double gf = 2.0 * p.M * Co * p.K / 1e9;
     const int it = 5;
     float ms;
+    {
+        const int tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        hipLaunchKernelGGL(kpf2, dim3(tiles), dim3(256), 0, 0, p); hipDeviceSynchronize();
+        hipEventRecord(a);
+        for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kpf2, dim3(tiles), dim3(256), 0, 0, p);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b); ms /= it;
+        printf("prefetch distance 2    %8.3f ms %7.1f TF\n", ms, gf / ms);
+    }
     ms = run<32, 2, 0, 0>(p, it); printf("BK32 NBUF2            %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2>(p, it); printf("BK32 NBUF1 EPI2 (38KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 4>(p, it); printf("  ablate: hot-line loads %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 1>(p, it); printf("  ablate: no gload      %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 2>(p, it); printf("  ablate: no lstore     %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 3>(p, it); printf("  ablate: neither       %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 2, 0, 0, 2>(p, it); printf("BK32 NBUF2 EPI2 (74KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<16, 2, 0, 0, 2>(p, it); printf("BK16 NBUF2 EPI2 (41KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<16, 1, 0, 0, 2>(p, it); printf("BK16 NBUF1 EPI2 (34KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
