@@ -11,9 +11,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // BK: k-step; NBUF: LDS buffers; MID: store next tile to LDS in the middle of the MFMA block; PRIO: setprio
+__device__ unsigned long long g_clk[4];
 template <int BK, int NBUF, int MID, int PRIO, int EPI = 1, int ABL = 0>
 __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
 {
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     constexpr int WGM = 2, WGN = 2, TM = 2, TN = 2;
     constexpr int BM = 128, BN = 128;
     constexpr int LD = BK + 4;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
                 for (int r = 0; r < 16; ++r) { const int op = row_out[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk]; if (op >= 0) p.out[(size_t)op * p.out_cstride + col] = acc[i][j][r]; } }
         return;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = clock64() - c0; g_clk[1] = wall_clock64() - w0; }
     if (EPI == 2) {
         constexpr int CLD2 = BN + 4;
         float* Cs2 = smem;
@@ -301,6 +304,8 @@ static float run(const IgemmParams& p, int iters)
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     if (hipGetLastError() != hipSuccess) printf("launch error\n");
+    unsigned long long h[4]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), sizeof(h));
+    printf("   [block0: %llu shader clk / %llu wall ticks -> %.3f GHz if wall=100MHz]\n", h[0], h[1], (double)h[0] / (double)h[1] * 0.1);
     return ms / iters;
 }
 
@@ -319,7 +324,7 @@ int main(int argc, char** argv)
     p.seg[0] = {x, C, C, 0}; p.seg0_chunks = C / 32; p.chunks_per_tap = C / 32;
     p.N = N; p.Hin = p.Win = H; p.Hg = p.Wg = H; p.M = N * H * H; p.in_stride = 1; p.ntaps = KS * KS;
     for (int a = 0; a < KS; ++a) for (int b = 0; b < KS; ++b) { p.dy[a * KS + b] = a - KS / 2; p.dx[a * KS + b] = b - KS / 2; }
-    p.zeros = w; p.w = w; p.K = KS * KS * C; p.Cout = Co; p.ksteps = p.K / 32; p.ksplit = 1;
+    p.w = w; p.K = KS * KS * C; p.Cout = Co; p.ksteps = p.K / 32; p.ksplit = 1;
     p.out = y; p.Hout = p.Wout = H; p.os = 1; p.out_cstride = Co;
     float* res = nullptr;
     if (argc > 6 && atoi(argv[6])) { hipMalloc(&res, nout * 4); hipMemset(res, 0, nout * 4); p.residual = res; p.res_cstride = Co; }
