@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=256, help="generator inputs per pass (activation workspace)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="detections in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-inject", action="store_true", help="let PnP consume the random-weight generator output")
+    ap.add_argument("--objects", type=int, default=1, help="number of object models the detections are spread over "
+                    "(BASELINE.json configs[3] uses 30; the headline config uses 1)")
     ap.add_argument("--overlap", action="store_true", help="detection-stream mode: submit/collect with two batches in flight "
                     "(PnP tail on a second HIP stream) instead of one blocking p2p_est_pose_batch per step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for dry runs)")
@@ -102,7 +104,11 @@ def main():
     wts = W.synthetic_weights(args.backbone, 1)
     gen = Generator(wts, args.backbone, ctx)
     spec = ObjectSpec(gen, synthetic.OBJ_PARAM, TH_O, TH_I)
+    specs = [spec] + [ObjectSpec(Generator(W.synthetic_weights(args.backbone, 1 + k), args.backbone, ctx), synthetic.OBJ_PARAM, TH_O, TH_I)
+                      for k in range(1, args.objects)]
     sc = synthetic.make_scene(args.batch, seed=1000 + rank)
+    if args.objects > 1:
+        sc["dets"] = [(d[0], i % args.objects, d[2], d[3]) for i, d in enumerate(sc["dets"])]
     frames = torch.from_numpy(sc["images"]).cuda()
     images = [(frames[i].data_ptr(), frames.shape[1], frames.shape[2], "u8") for i in range(frames.shape[0])]
     inj1 = torch.from_numpy(sc["inject1"]).cuda()
@@ -124,11 +130,11 @@ def main():
         out = None
         if not args.overlap:
             for _ in range(k):
-                out = finish(est_pose_batch(ctx, [spec], images, sc["dets"], **kw)[0])
+                out = finish(est_pose_batch(ctx, specs, images, sc["dets"], **kw)[0])
             return out
         pending = None
         for _ in range(k):
-            nxt = est_pose_submit(ctx, [spec], images, sc["dets"], **kw)
+            nxt = est_pose_submit(ctx, specs, images, sc["dets"], **kw)
             if pending is not None:
                 out = finish(pending.collect())
             pending = nxt
@@ -171,7 +177,7 @@ def main():
                                "(1 stage-1 + 3 stage-2 forwards per detection) + 3 EPnP-RANSAC solves per detection, "
                                "outlier_th=[0.2,0.3,0.35], injected ellipsoid-NOCS decoder maps" % (args.batch, args.backbone),
                    "detections_per_gpu": args.batch, "backbone": args.backbone, "parallelism": "dp%d" % world,
-                   "generator_chunk": args.chunk, "mode": "stream (submit/collect, 2 in flight)" if args.overlap else "blocking"},
+                   "generator_chunk": args.chunk, "objects": args.objects, "mode": "stream (submit/collect, 2 in flight)" if args.overlap else "blocking"},
         "ae_inputs_per_s": 4 * value,
         "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
         "poses_ok": n_ok, "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,

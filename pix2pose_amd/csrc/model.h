@@ -36,8 +36,20 @@ struct Pipeline;   // est_pose workspaces (pipeline.hip)
 struct Ctx {
     int device = 0;
     int max_batch = 0;
-    hipStream_t stream = nullptr;
-    std::map<std::string, float*> act;    // activation workspace, sized for max_batch inputs
+    hipStream_t stream = nullptr;         // == lane[0].stream
+    // A lane = a HIP stream + its own activation workspace.  Lane 0 serves every single-object call;
+    // the side lanes let the generator passes of DIFFERENT objects in a mixed batch run concurrently
+    // (each is a small launch sequence that cannot fill 256 CUs alone; BASELINE.json configs[3]).
+    static constexpr int N_LANES = 4;
+    struct Lane {
+        hipStream_t stream = nullptr;
+        std::map<std::string, float*> act;    // activation workspace, sized for max_batch inputs
+        hipEvent_t done = nullptr;
+    };
+    Lane lane[N_LANES];
+    Lane* cur = &lane[0];                 // lane the next forward_chunk() runs on
+    hipEvent_t fork = nullptr;
+    int ensure_lane(int i);
     float* x_stage = nullptr;
     float* xyzp_stage = nullptr;
     float* xyz_stage = nullptr;

@@ -315,14 +315,29 @@ static const struct { const char* name; size_t per_sample; } kBuffers[] = {
     {"f3", 16 * 16 * 512},
 };
 
-int Ctx::ensure_workspace()
+int Ctx::ensure_lane(int i)
 {
-    if (!act.empty()) return P2P_OK;
+    Lane& ln = lane[i];
+    if (!ln.act.empty()) return P2P_OK;
+    if (!ln.stream) {
+        if (i == 0) ln.stream = stream;
+        else HIP_TRY(hipStreamCreate(&ln.stream));
+    }
+    if (!ln.done) HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    if (!fork) HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     for (const auto& b : kBuffers) {
         float* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, b.per_sample * (size_t)max_batch * sizeof(float)));
-        act[b.name] = d;
+        ln.act[b.name] = d;
     }
+    return P2P_OK;
+}
+
+int Ctx::ensure_workspace()
+{
+    if (x_stage) return P2P_OK;
+    int rc = ensure_lane(0);
+    if (rc) return rc;
     HIP_TRY(hipMalloc((void**)&x_stage, (size_t)max_batch * 128 * 128 * 3 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&xyzp_stage, (size_t)max_batch * 128 * 128 * 4 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&xyz_stage, (size_t)max_batch * 128 * 128 * 3 * sizeof(float)));
@@ -353,7 +368,7 @@ struct ConvCall {
 
 static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
 {
-    hipStream_t st = X.stream;
+    hipStream_t st = X.cur->stream;
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.seg[0] = {c.s0.ptr, c.s0.C, c.s0.cstride, c.s0.coff};
@@ -454,14 +469,14 @@ static int res_block(const Model& M, Ctx& X, const std::string& n, const float* 
 {
     int rc;
     const int Ho = H / stride;
-    float* ta = X.act["t_a"];
-    float* tb = X.act["t_b"];
+    float* ta = X.cur->act["t_a"];
+    float* tb = X.cur->act["t_b"];
     if ((rc = conv_layer(X, M.L.at(n + "_2a"), in, N, H, H, Cin, stride, ta, ACT_RELU))) return rc;
     if ((rc = conv_layer(X, M.L.at(n + "_2b"), ta, N, Ho, Ho, f1, 1, tb, ACT_RELU))) return rc;
     const float* res = in;
     if (shortcut) {
-        if ((rc = conv_layer(X, M.L.at(n + "_1"), in, N, H, H, Cin, stride, X.act["sc"], ACT_NONE))) return rc;
-        res = X.act["sc"];
+        if ((rc = conv_layer(X, M.L.at(n + "_1"), in, N, H, H, Cin, stride, X.cur->act["sc"], ACT_NONE))) return rc;
+        res = X.cur->act["sc"];
     }
     return conv_layer(X, M.L.at(n + "_2c"), tb, N, Ho, Ho, f1, 1, out, ACT_RELU, res);
 }
@@ -470,8 +485,8 @@ static int res_block(const Model& M, Ctx& X, const std::string& n, const float* 
 int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
 {
     int rc;
-    hipStream_t st = X.stream;
-    auto& A = X.act;
+    hipStream_t st = X.cur->stream;
+    auto& A = X.cur->act;
     const float *s1, *s2, *s3;      // skip tensors and their pixel strides / channel offsets
     int s1_stride, s1_off, s1_C, s2_stride, s2_off, s3_stride, s3_off;
     if (M.backbone == P2P_BACKBONE_RESNET50) {
@@ -582,7 +597,12 @@ Model::~Model()
 
 Ctx::~Ctx()
 {
-    for (auto& kv : act) hipFree(kv.second);
+    for (Lane& ln : lane) {
+        for (auto& kv : ln.act) hipFree(kv.second);
+        if (ln.done) hipEventDestroy(ln.done);
+        if (ln.stream && ln.stream != stream) hipStreamDestroy(ln.stream);
+    }
+    if (fork) hipEventDestroy(fork);
     if (x_stage) hipFree(x_stage);
     if (xyzp_stage) hipFree(xyzp_stage);
     if (xyz_stage) hipFree(xyz_stage);

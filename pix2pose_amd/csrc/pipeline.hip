@@ -692,6 +692,32 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         groups.push_back({hd[i].obj, i, j});
         i = j;
     }
+    // Generator passes of the object groups.  One group: the context stream.  Several groups (mixed
+    // batch): round-robin over the context's lanes (stream + private activation workspace) so that the
+    // small per-object launch sequences overlap; fork/join with events around them.
+    auto forward_groups = [&](int per_det, const float* xin, float* yout) -> int {
+        const int nl = groups.size() > 1 ? std::min<int>((int)groups.size(), Ctx::N_LANES) : 1;
+        if (nl > 1) {
+            for (int l = 1; l < nl; ++l) { int r = X.ensure_lane(l); if (r) return r; }
+            HIP_TRY(hipEventRecord(X.fork, st));
+            for (int l = 1; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(X.lane[l].stream, X.fork, 0));
+        }
+        int r = P2P_OK;
+        for (size_t gi = 0; gi < groups.size() && !r; ++gi) {
+            const Group& g = groups[gi];
+            const Model& M = *reinterpret_cast<const Model*>(objects[g.obj].model);
+            X.cur = &X.lane[gi % nl];
+            r = forward_async(X, M, xin + (size_t)g.begin * per_det * 16384 * 3, (g.end - g.begin) * per_det,
+                              yout + (size_t)g.begin * per_det * 16384 * 4);
+        }
+        X.cur = &X.lane[0];
+        if (r) return r;
+        for (int l = 1; l < nl; ++l) {
+            HIP_TRY(hipEventRecord(X.lane[l].done, X.lane[l].stream));
+            HIP_TRY(hipStreamWaitEvent(st, X.lane[l].done, 0));
+        }
+        return P2P_OK;
+    };
     auto inject = [&](const float* src, float* dst, size_t per_det) -> int {
         if (identity) {
             HIP_TRY(hipMemcpyAsync(dst, src, per_det * n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -704,10 +730,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     // -- stage 1
     hipLaunchKernelGGL(stage1_input_kernel, dim3(n * 64), dim3(256), 0, st, d_det, x1);
     HIP_TRY(hipGetLastError());
-    for (const Group& g : groups) {
-        const Model& M = *reinterpret_cast<const Model*>(objects[g.obj].model);
-        if ((rc = forward_async(X, M, x1 + (size_t)g.begin * 16384 * 3, g.end - g.begin, y1 + (size_t)g.begin * 16384 * 4))) return rc;
-    }
+    if ((rc = forward_groups(1, x1, y1))) return rc;
     if (opt.inject1 && (rc = inject(opt.inject1, y1, 16384 * 4))) return rc;
     hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(256), 0, st, d_det, y1, d_s1);
     HIP_TRY(hipGetLastError());
@@ -715,10 +738,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     // -- stage 2
     hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, x2);
     HIP_TRY(hipGetLastError());
-    for (const Group& g : groups) {
-        const Model& M = *reinterpret_cast<const Model*>(objects[g.obj].model);
-        if ((rc = forward_async(X, M, x2 + (size_t)g.begin * K * 16384 * 3, (g.end - g.begin) * K, y2 + (size_t)g.begin * K * 16384 * 4))) return rc;
-    }
+    if ((rc = forward_groups(K, x2, y2))) return rc;
     if (opt.inject2) {
         if (opt.inject_slots != K) { set_error("inject_slots (%d) must equal the largest n_outlier_th (%d)", opt.inject_slots, K); return P2P_ERR_INVALID_ARG; }
         if ((rc = inject(opt.inject2, y2, (size_t)K * 16384 * 4))) return rc;
