@@ -71,15 +71,26 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     }
     const int tile_n = t % tiles_n;
     const int tile_m = t / tiles_n;
-    const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
+    // grouped launch: this tile's object decides the weight panel and the row range
+    int m0 = tile_m * BM, m_end = p.M;
+    const float* gw = p.w;
+    const float* gscale = p.scale;
+    const float* gshift = p.shift;
+    if (p.n_groups > 1) {
+        int g = 0;
+        while (g + 1 < p.n_groups && tile_m >= p.grp[g + 1].tile0) ++g;
+        m0 = p.grp[g].row0 + (tile_m - p.grp[g].tile0) * BM;
+        m_end = p.grp[g + 1].row0;
+        gw = p.grp[g].w; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
+    }
 
     if (tid < p.ntaps) s_tap[tid] = (int)p.dy[tid] * p.Win + (int)p.dx[tid];
     const int HgWg = p.Hg * p.Wg;
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
         int base = -1, yx = 0, op = -1;
-        if (m < p.M) {
+        if (m < m_end) {
             const int n = m / HgWg;
             const int rem = m - n * HgWg;
             const int gy = rem / p.Wg;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     for (int j = 0; j < B_PASSES; ++j) b_off[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)p.K + (unsigned)lcol) * 4u;
     const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].ptr, 0, p.seg_bytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.seg[1].ptr ? p.seg[1].ptr : p.seg[0].ptr), 0, p.seg_bytes[1], 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)gw, 0, p.w_bytes, 0x00020000);
 
     // ---- split-K range
     const int ks_per = (p.ksteps + p.ksplit - 1) / p.ksplit;
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     const bool cok = col < p.Cout;         // Cout is a multiple of 4 on this path
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (cok && p.ksplit <= 1) {
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+        if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + col);
+        if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
     }
 #pragma unroll 1
     for (int h = 0; h < WGM; ++h) {
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
                 if (p.ksplit > 1) {
                     const int m = m0 + row;
-                    if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.y * p.M + m) * p.Cout + col) = v;
+                    if (m < m_end) *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.y * p.M + m) * p.Cout + col) = v;
                     continue;
                 }
                 const int op = row_out[row];
@@ -283,11 +294,14 @@ template <int WGM, int WGN, int TM, int TN>
 static hipError_t launch_cfg(const IgemmParams& p, hipStream_t s)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+    const int m_tiles = p.n_groups > 1 ? p.grp[p.n_groups].tile0 : (p.M + BM - 1) / BM;
+    const int tiles = m_tiles * ((p.Cout + BN - 1) / BN);
     dim3 grid(tiles, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
+
+int igemm_tile_m(int cfg) { (void)cfg; return 128; }
 
 hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s)
 {
@@ -323,6 +337,29 @@ hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cou
     const int blocks = (int)min((size_t)2048, (total + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, ksplit, M, Cout, scale,
                        shift, act, alpha, out);
+    return hipGetLastError();
+}
+
+__global__ void splitk_reduce_rows_kernel(const float* __restrict__ partial, int ksplit, int M, int Cout, int row0, int rows,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out)
+{
+    const size_t total = (size_t)rows * Cout, slab = (size_t)M * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = (size_t)row0 * Cout + i;
+        float s = 0.f;
+        for (int z = 0; z < ksplit; ++z) s += partial[(size_t)z * slab + o];
+        const int c = (int)(i % Cout);
+        out[o] = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+    }
+}
+
+hipError_t launch_splitk_reduce_rows(const float* partial, int ksplit, int M, int Cout, int row0, int rows, const float* scale,
+                                     const float* shift, float* out, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    const size_t total = (size_t)rows * Cout;
+    const int blocks = (int)min((size_t)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(blocks), dim3(256), 0, s, partial, ksplit, M, Cout, row0, rows, scale, shift, out);
     return hipGetLastError();
 }
 

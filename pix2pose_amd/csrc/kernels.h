@@ -9,7 +9,8 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum EpiMode { EPI_NORMAL = 0, EPI_HEAD = 1 };
 
 constexpr int IGEMM_MAX_TAPS = 25;
-constexpr int IGEMM_BK = 32;          // K-step (floats); every channel segment is a multiple of it
+constexpr int IGEMM_BK = 32;
+constexpr int IGEMM_MAX_GROUPS = 48;  // object models one launch can serve (mixed-object batches)          // K-step (floats); every channel segment is a multiple of it
 
 // One channel segment of the (virtually concatenated) NHWC input: channels
 // [coff, coff+C) of a tensor whose pixel stride is `cstride` floats.
@@ -18,6 +19,16 @@ struct IgemmSeg {
     int C;
     int cstride;
     int coff;
+};
+
+// One object's weight panel inside a grouped launch: GEMM rows [row0, next.row0) use it; its first
+// M-tile is tile0 (every group starts on a tile boundary, the last tile of a group may be partial).
+struct IgemmGroup {
+    const float* w;
+    const float* scale;
+    const float* shift;
+    int row0;
+    int tile0;
 };
 
 // Implicit-GEMM convolution  D[m, co] = sum_{tap, ci} X[pix(m) + tap][ci] * W[co][tap*Cin + ci]
@@ -51,14 +62,23 @@ struct IgemmParams {
     int Hout, Wout, os, oy, ox;
     int out_cstride, out_coff;
     int mode;
+    // grouped launch (n_groups > 1): detections of several objects in one batch, sorted by object;
+    // grp[n_groups] is a sentinel {row0 = M, tile0 = number of M-tiles}.  n_groups <= 1: w/scale/shift above.
+    int n_groups;
+    IgemmGroup grp[IGEMM_MAX_GROUPS + 1];
 };
 
 // tile configurations (BM x BN): 0 = 128x128, 1 = 128x64, 2 = 128x32
 hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s);
+int igemm_tile_m(int cfg);   // BM of a tile configuration
 
 // out[m][co] = act(sum_z partial[z][m][co] * scale + shift)
 hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cout, const float* scale,
                                 const float* shift, int act, float alpha, float* out, hipStream_t s);
+
+// same, rows [row0, row0+rows) only (grouped launches: per-object bias); no activation
+hipError_t launch_splitk_reduce_rows(const float* partial, int ksplit, int M, int Cout, int row0, int rows, const float* scale,
+                                     const float* shift, float* out, hipStream_t s);
 
 // First-layer direct convolution, Cin = 3 (conv1 7x7/2 of the ResNet front, conv1_x 5x5/2 of
 // the paper encoder), fused scale/shift + activation.  w_packed: [kh*kw*3][Cout].

@@ -20,6 +20,7 @@ struct ConvLayer {
     float* scale = nullptr;   // folded BatchNorm scale per cout
     float* shift = nullptr;   // bias / folded BatchNorm shift per cout
     int K = 0, Cout = 0, ntaps = 0;
+    std::string name;         // key in Model::L (grouped launches look the same layer up in every object)
     int8_t dy[IGEMM_MAX_TAPS + 3] = {0};
     int8_t dx[IGEMM_MAX_TAPS + 3] = {0};
 };
@@ -32,6 +33,13 @@ struct Model {
 };
 
 struct Pipeline;   // est_pose workspaces (pipeline.hip)
+
+// Objects sharing one generator pass (mixed batch, detections sorted by object): samples
+// [start[g], start[g+1]) of the pass belong to models[g].
+struct GroupCtx {
+    std::vector<const Model*> models;
+    std::vector<int> start;
+};
 
 struct Ctx {
     int device = 0;
@@ -48,6 +56,7 @@ struct Ctx {
     };
     Lane lane[N_LANES];
     Lane* cur = &lane[0];                 // lane the next forward_chunk() runs on
+    const GroupCtx* grp = nullptr;        // set while a grouped (multi-object) pass is being enqueued
     hipEvent_t fork = nullptr;
     int ensure_lane(int i);
     float* x_stage = nullptr;
@@ -70,5 +79,9 @@ struct Ctx {
 
 int forward_chunk(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp_dev);
 int forward_async(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp_dev);
+// one generator pass over the detections of several objects (same backbone), sorted by object:
+// every layer is ONE grouped launch in which each M-tile uses its object's weight panel
+int forward_grouped(Ctx& X, const std::vector<const Model*>& models, const std::vector<int>& counts, const float* x_dev,
+                    float* xyzp_dev);
 
 }  // namespace p2p

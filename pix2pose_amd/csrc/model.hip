@@ -407,6 +407,19 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     p.out_cstride = c.out_cstride; p.out_coff = c.out_coff;
     p.mode = c.mode;
     const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? 1 : 2);
+    if (X.grp && X.grp->models.size() > 1) {
+        const GroupCtx& G = *X.grp;
+        const int ng = (int)G.models.size(), BM = igemm_tile_m(cfg), rows_per_sample = c.Hg * c.Wg;
+        if (ng > IGEMM_MAX_GROUPS) { set_error("run_conv: %d object groups exceed IGEMM_MAX_GROUPS", ng); return P2P_ERR_CAPACITY; }
+        int tile0 = 0;
+        for (int g = 0; g < ng; ++g) {
+            const ConvLayer& Lg = G.models[g]->L.at(L.name);
+            p.grp[g] = {Lg.w, Lg.scale, Lg.shift, G.start[g] * rows_per_sample, tile0};
+            tile0 += ((G.start[g + 1] - G.start[g]) * rows_per_sample + BM - 1) / BM;
+        }
+        p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng] * rows_per_sample, tile0};
+        p.n_groups = ng;
+    }
     if (X.profiling) {
         Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), cfg,
                           2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
@@ -487,11 +500,17 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
     int rc;
     hipStream_t st = X.cur->stream;
     auto& A = X.cur->act;
+    const int n_grp = X.grp ? (int)X.grp->models.size() : 1;
+    auto grp_model = [&](int g) -> const Model& { return X.grp ? *X.grp->models[g] : M; };
+    auto g0 = [&](int g) -> int { return X.grp ? X.grp->start[g] : (g == 0 ? 0 : n); };
     const float *s1, *s2, *s3;      // skip tensors and their pixel strides / channel offsets
     int s1_stride, s1_off, s1_C, s2_stride, s2_off, s3_stride, s3_off;
     if (M.backbone == P2P_BACKBONE_RESNET50) {
-        const ConvLayer& c1 = M.L.at("conv1");
-        HIP_TRY(launch_conv_first(x, n, 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift, ACT_RELU, LEAKY, A["f1"], 64, 64, st));
+        for (int g = 0; g < n_grp; ++g) {      // VALU first layer: one launch per object (tiny)
+            const ConvLayer& c1 = grp_model(g).L.at("conv1");
+            HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift,
+                                      ACT_RELU, LEAKY, A["f1"] + (size_t)g0(g) * 64 * 64 * 64, 64, 64, st));
+        }
         HIP_TRY(launch_maxpool3s2(A["f1"], n, 64, 64, 64, A["p1"], st));
         if ((rc = res_block(M, X, "res2a", A["p1"], n, 32, 64, 64, 1, true, A["o_a"]))) return rc;
         if ((rc = res_block(M, X, "res2b", A["o_a"], n, 32, 256, 64, 1, false, A["o_b"]))) return rc;
@@ -508,8 +527,11 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
     } else {
         // ae_model.py:74-106: each level = two parallel 5x5/2 convs concatenated [_1 || _2];
         // the skip is the _2 half, i.e. the upper channels of the merged output.
-        const ConvLayer& c1 = M.L.at("conv1");
-        HIP_TRY(launch_conv_first(x, n, 128, 128, c1.w, 5, 2, 1, 128, c1.scale, c1.shift, ACT_LEAKY, LEAKY, A["f1"], 64, 64, st));
+        for (int g = 0; g < n_grp; ++g) {
+            const ConvLayer& c1 = grp_model(g).L.at("conv1");
+            HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 5, 2, 1, 128, c1.scale, c1.shift,
+                                      ACT_LEAKY, LEAKY, A["f1"] + (size_t)g0(g) * 64 * 64 * 128, 64, 64, st));
+        }
         if ((rc = conv_layer(X, M.L.at("conv2"), A["f1"], n, 64, 64, 128, 2, A["f2"], ACT_LEAKY))) return rc;
         if ((rc = conv_layer(X, M.L.at("conv3"), A["f2"], n, 32, 32, 256, 2, A["f3"], ACT_LEAKY))) return rc;
         if ((rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 256, 2, A["f4"], ACT_LEAKY))) return rc;
@@ -526,7 +548,16 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         c.out = A["enc"]; c.Hout = c.Wout = 1; c.out_cstride = 256;
         c.ksplit = 32; c.partial = A["part"];
         if ((rc = run_conv(X, L, c))) return rc;
-        HIP_TRY(launch_splitk_reduce(A["part"], 32, n, 256, L.scale, L.shift, ACT_NONE, LEAKY, A["enc"], st));
+        if (n_grp == 1) {
+            HIP_TRY(launch_splitk_reduce(A["part"], 32, n, 256, L.scale, L.shift, ACT_NONE, LEAKY, A["enc"], st));
+        } else {
+            // per-object bias: reduce each object's sample rows with its own shift.  The partial slabs are
+            // [z][n][256]; a row range is strided by n*256 between slabs, so reduce through a strided view
+            for (int g = 0; g < n_grp; ++g) {
+                const ConvLayer& Lg = grp_model(g).L.at("dense_enc");
+                HIP_TRY(launch_splitk_reduce_rows(A["part"], 32, n, 256, g0(g), g0(g + 1) - g0(g), Lg.scale, Lg.shift, A["enc"], st));
+            }
+        }
     }
     {
         const ConvLayer& L = M.L.at("dense_dec");     // Dense(8*8*256) + Reshape((8,8,-1))
@@ -587,6 +618,40 @@ int Ctx::prof_harvest()
         prof_pool.push_back(ev.b);
     }
     prof_pending.clear();
+    return P2P_OK;
+}
+
+int forward_grouped(Ctx& X, const std::vector<const Model*>& models, const std::vector<int>& counts, const float* x_dev,
+                    float* xyzp_dev)
+{
+    int rc = X.ensure_workspace();
+    if (rc) return rc;
+    for (const Model* m : models)
+        if (m->backbone != models[0]->backbone) { set_error("forward_grouped: mixed backbones"); return P2P_ERR_INVALID_ARG; }
+    // chunks of <= max_batch samples and <= IGEMM_MAX_GROUPS objects; an object may straddle two chunks
+    size_t g = 0;
+    int used = 0, done = 0;       // samples of group g already consumed; samples enqueued so far
+    while (g < models.size()) {
+        GroupCtx G;
+        G.start.push_back(0);
+        int n = 0;
+        while (g < models.size() && n < X.max_batch && (int)G.models.size() < IGEMM_MAX_GROUPS) {
+            const int take = std::min(counts[g] - used, X.max_batch - n);
+            if (take > 0) {
+                G.models.push_back(models[g]);
+                n += take;
+                G.start.push_back(n);
+            }
+            used += take;
+            if (used >= counts[g]) { ++g; used = 0; }
+        }
+        if (n == 0) break;
+        X.grp = &G;
+        rc = forward_chunk(X, *G.models[0], x_dev + (size_t)done * 128 * 128 * 3, n, xyzp_dev + (size_t)done * 128 * 128 * 4);
+        X.grp = nullptr;
+        if (rc) return rc;
+        done += n;
+    }
     return P2P_OK;
 }
 
@@ -707,6 +772,7 @@ int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int
     m->device = c->device;
     int rc = build_model(T, *m);
     if (rc) { delete m; return rc; }
+    for (auto& kv : m->L) kv.second.name = kv.first;
     *out = reinterpret_cast<p2p_model*>(m);
     return P2P_OK;
 }

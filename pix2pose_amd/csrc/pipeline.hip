@@ -696,6 +696,17 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     // batch): round-robin over the context's lanes (stream + private activation workspace) so that the
     // small per-object launch sequences overlap; fork/join with events around them.
     auto forward_groups = [&](int per_det, const float* xin, float* yout) -> int {
+        bool same_backbone = true;
+        for (const Group& g : groups)
+            same_backbone = same_backbone && reinterpret_cast<const Model*>(objects[g.obj].model)->backbone ==
+                                                 reinterpret_cast<const Model*>(objects[groups[0].obj].model)->backbone;
+        if (groups.size() > 1 && same_backbone) {
+            // one grouped pass: each layer is a single launch, every M-tile uses its object's weights
+            std::vector<const Model*> ms;
+            std::vector<int> cnt;
+            for (const Group& g : groups) { ms.push_back(reinterpret_cast<const Model*>(objects[g.obj].model)); cnt.push_back((g.end - g.begin) * per_det); }
+            return forward_grouped(X, ms, cnt, xin, yout);
+        }
         const int nl = groups.size() > 1 ? std::min<int>((int)groups.size(), Ctx::N_LANES) : 1;
         if (nl > 1) {
             for (int l = 1; l < nl; ++l) { int r = X.ensure_lane(l); if (r) return r; }
