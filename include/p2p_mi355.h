@@ -66,6 +66,18 @@ void* p2p_ctx_stream(p2p_ctx* ctx);
  * must be present. */
 int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone,
                      p2p_model** out);
+
+/* Arithmetic of the generator's dense contractions (the reference computes them in fp32 through
+ * TensorFlow).  P2P_PREC_F32: fp32 matrix instructions, bitwise an fmaf chain.  P2P_PREC_F16X3: fp32
+ * emulated on the f16 matrix pipe -- every operand is split into two f16 halves (22 significant
+ * bits), three MFMAs per product block, fp32 accumulation; ~2.7x faster on the large layers, output
+ * differs from the fp32 mode by ~1e-6 and is measured as close to a double-accumulating reference as
+ * the fp32 mode is (max 2.5e-5 vs 3.3e-5 on the tanh outputs).  Operand range: |activation| < 65504
+ * (f16 max); weights are pre-scaled per layer.  p2p_model_create uses P2P_PREC_DEFAULT. */
+typedef enum { P2P_PREC_F32 = 0, P2P_PREC_F16X3 = 1 } p2p_precision;
+#define P2P_PREC_DEFAULT P2P_PREC_F16X3
+int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone,
+                        int precision, p2p_model** out);
 void p2p_model_destroy(p2p_model* model);
 
 /* Replaces `self.generator_train.predict(x)` (reference recognition.py:84,129):

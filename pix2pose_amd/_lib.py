@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("P2P_LIB", os.path.join(_HERE, "libp2p_mi355.so"))    
 
 P2P_OK = 0
 BACKBONE = {"paper": 0, "resnet50": 1}
+PRECISION = {"f32": 0, "f16x3": 1}
 MEM_HOST, MEM_DEVICE = 0, 1
 
 
@@ -88,6 +89,7 @@ def lib():
     L.p2p_ctx_stream.argtypes = [vp]
     L.p2p_ctx_stream.restype = vp
     L.p2p_model_create.argtypes = [vp, C.POINTER(Tensor), ci, ci, C.POINTER(vp)]
+    L.p2p_model_create_ex.argtypes = [vp, C.POINTER(Tensor), ci, ci, ci, C.POINTER(vp)]
     L.p2p_model_destroy.argtypes = [vp]
     L.p2p_model_destroy.restype = None
     L.p2p_predict.argtypes = [vp, vp, vp, ci, vp, vp, ci]

@@ -21,16 +21,30 @@
 // contraction needs).  Global->LDS is register-staged (the padded LDS image rules out
 // global_load_lds); the global loads of step k+1 are issued before the 64 (128x128 tile) MFMAs
 // of step k and written to the single LDS buffer between two barriers.
+//
+// Precision modes (template PREC):
+//   PREC_F32   v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain (157 TFLOP/s peak).
+//   PREC_F16X3 fp32 emulated on the f16 matrix pipe: every fp32 value x is split as hi = f16(x),
+//              lo = f16(x - hi) (22 significant bits) and a*b ~= ah*bh + ah*bl + al*bh with fp32
+//              accumulation: three v_mfma_f32_32x32x16_f16 per 16-deep block, 16x the fp32 MFMA rate
+//              per instruction => ~5.3x per algorithmic MAC.  Activations stay fp32 in HBM and are
+//              split by the loader when it writes the LDS tile (measured free: the VALU work hides
+//              under the MFMAs); weights are split offline into the same [hi x32 | lo x32] row image,
+//              pre-scaled by 2^10 so their lo parts stay in the f16 normal range (the epilogue scale
+//              carries 2^-10).  Error vs exact fp32 products ~2^-22 relative: the network output moves
+//              by ~1e-6, the same size as fp32 summation-order noise (tests hold both modes to 1e-4).
 #include "kernels.h"
 
 namespace p2p {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int LDS_LD = IGEMM_BK + 4;  // padded row stride (floats)
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, int PREC>
 __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   // >= 3 waves per SIMD: <= 168 VGPR+AGPR
 {
     constexpr int BM = WGM * TM * 32;
@@ -172,11 +186,26 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     auto lstore = [&]() {
         float* As = smem;
         float* Bs = As + BM * LDS_LD;
+        if (PREC == PREC_F16X3) {
+            // row image [hi f16 x32 | lo f16 x32] (128 B): this thread owns k = lcol .. lcol+3
 #pragma unroll
-        for (int j = 0; j < A_PASSES; ++j)
-            *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_LD + lcol) = ra[j];
+            for (int j = 0; j < A_PASSES; ++j) {
+                const f32x4 v = ra[j];
+                const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                fp16x2 l01, l23;          // residuals are exact in fp32; round them to nearest
+                l01[0] = (__fp16)(v[0] - (float)h01[0]); l01[1] = (__fp16)(v[1] - (float)h01[1]);
+                l23[0] = (__fp16)(v[2] - (float)h23[0]); l23[1] = (__fp16)(v[3] - (float)h23[1]);
+                char* row = reinterpret_cast<char*>(As + (lrow + 32 * j) * LDS_LD);
+                *reinterpret_cast<uint2*>(row + lcol * 2) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                *reinterpret_cast<uint2*>(row + 64 + lcol * 2) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < B_PASSES; ++j)
+            for (int j = 0; j < A_PASSES; ++j)
+                *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_LD + lcol) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j)      // weights: fp32 panel, or the pre-split panel with the same row image
             *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_LD + lcol) = rb[j];
     };
 
@@ -193,6 +222,32 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
         const bool more = ks + 1 < ks1;
         if (++chunk == p.chunks_per_tap) { chunk = 0; ++tap; }
         if (more) gload(ks + 1, tap, chunk);   // global loads of the next K-step fly under this step's MFMAs
+        if (PREC == PREC_F16X3) {
+            // two 16-deep blocks; a lane's fragment = 8 consecutive k (16 B) of the hi or lo half-row:
+            // byte offset 32*kb + 16*(lane>>5) (+64 for lo); As/Bs already carry the 16*(lane>>5) part
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * LDS_LD + kb * 8);
+                    al[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * LDS_LD + kb * 8 + 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * LDS_LD + kb * 8);
+                    bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * LDS_LD + kb * 8 + 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < IGEMM_BK; kk += 8) {
             f32x4 a[TM], b[TN];
@@ -290,14 +345,14 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     }
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, int PREC>
 static hipError_t launch_cfg(const IgemmParams& p, hipStream_t s)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     const int m_tiles = p.n_groups > 1 ? p.grp[p.n_groups].tile0 : (p.M + BM - 1) / BM;
     const int tiles = m_tiles * ((p.Cout + BN - 1) / BN);
     dim3 grid(tiles, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN, PREC>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -306,9 +361,9 @@ int igemm_tile_m(int cfg) { (void)cfg; return 128; }
 hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s)
 {
     switch (cfg) {
-    case 0: return launch_cfg<2, 2, 2, 2>(p, s);   // 128 x 128
-    case 1: return launch_cfg<2, 2, 2, 1>(p, s);   // 128 x 64
-    case 2: return launch_cfg<4, 1, 1, 1>(p, s);   // 128 x 32
+    case 0: return p.prec == PREC_F16X3 ? launch_cfg<2, 2, 2, 2, PREC_F16X3>(p, s) : launch_cfg<2, 2, 2, 2, PREC_F32>(p, s);   // 128 x 128
+    case 1: return p.prec == PREC_F16X3 ? launch_cfg<2, 2, 2, 1, PREC_F16X3>(p, s) : launch_cfg<2, 2, 2, 1, PREC_F32>(p, s);   // 128 x 64
+    case 2: return p.prec == PREC_F16X3 ? launch_cfg<4, 1, 1, 1, PREC_F16X3>(p, s) : launch_cfg<4, 1, 1, 1, PREC_F32>(p, s);   // 128 x 32
     default: return hipErrorInvalidValue;
     }
 }

@@ -7,6 +7,7 @@ namespace p2p {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum EpiMode { EPI_NORMAL = 0, EPI_HEAD = 1 };
+enum Prec { PREC_F32 = 0, PREC_F16X3 = 1 };   // igemm arithmetic: fp32 MFMA, or fp32 emulated with 3 split-f16 MFMAs
 
 constexpr int IGEMM_MAX_TAPS = 25;
 constexpr int IGEMM_BK = 32;
@@ -62,6 +63,7 @@ struct IgemmParams {
     int Hout, Wout, os, oy, ox;
     int out_cstride, out_coff;
     int mode;
+    int prec;              // Prec; with PREC_F16X3 `w` (and grp[].w) is the split-f16 panel, scale carries 2^-10
     // grouped launch (n_groups > 1): detections of several objects in one batch, sorted by object;
     // grp[n_groups] is a sentinel {row0 = M, tile0 = number of M-tiles}.  n_groups <= 1: w/scale/shift above.
     int n_groups;

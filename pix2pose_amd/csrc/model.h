@@ -20,6 +20,7 @@ struct ConvLayer {
     float* scale = nullptr;   // folded BatchNorm scale per cout
     float* shift = nullptr;   // bias / folded BatchNorm shift per cout
     int K = 0, Cout = 0, ntaps = 0;
+    int prec = PREC_F32;      // arithmetic the panel `w` is packed for (Prec)
     std::string name;         // key in Model::L (grouped launches look the same layer up in every object)
     int8_t dy[IGEMM_MAX_TAPS + 3] = {0};
     int8_t dx[IGEMM_MAX_TAPS + 3] = {0};
@@ -27,6 +28,7 @@ struct ConvLayer {
 
 struct Model {
     int backbone = 0;
+    int prec = PREC_F32;
     int device = 0;
     std::map<std::string, ConvLayer> L;
     ~Model();

@@ -90,12 +90,86 @@ static int fold_bn(const TensorMap& T, const std::string& name, int C, bool has_
     return P2P_OK;
 }
 
+// IEEE binary16 <-> binary32 on the host (round to nearest even), for the offline weight split
+static uint16_t f32_to_f16(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));   // overflow -> inf, NaN
+    if (x < 0x38800000u) {                       // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 113 - (int)(x >> 23);
+        uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+        const uint32_t q = m >> (shift + 13), rem = m & ((1u << (shift + 13)) - 1), half = 1u << (shift + 12);
+        return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1))) ? 1u : 0u)));
+    }
+    const uint32_t q = (x - 0x38000000u) >> 13, rem = x & 0x1FFFu;
+    return (uint16_t)(sign | (q + ((rem > 0x1000u || (rem == 0x1000u && (q & 1))) ? 1u : 0u)));
+}
+static float f16_to_f32(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 0x3FFu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { float v = (float)m * 5.9604644775390625e-08f; memcpy(&x, &v, 4); x |= sign; }   // m * 2^-24
+    } else if (e == 31) x = sign | 0x7F800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+static thread_local int g_pack_prec = PREC_F32;   // precision of the model being packed (build_model)
+// Power-of-two pre-scale of a layer's weights for the split: the largest |w| lands in [2^13, 2^14)
+// (f16 max is 65504), so the lo parts of all but vanishing weights stay in the f16 normal range.
+static float f16x3_weight_scale(const std::vector<float>& w)
+{
+    float m = 0.f;
+    for (float v : w) m = std::max(m, std::fabs(v));
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+    int e = 0;
+    std::frexp(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.f, std::min(std::max(14 - e, -14), 24));
+}
+
+// fp32 panel [rows][K] -> split-f16 panel of the same byte size: per row and 32-wide K-step the image
+// [hi x32 | lo x32], hi = f16(w * s), lo = f16(w * s - hi), s = F16X3_WEIGHT_SCALE (a power of two).
+// The epilogue scale carries 1/s.
+static std::vector<float> split_panel(const std::vector<float>& w, int K, float F16X3_WEIGHT_SCALE)
+{
+    std::vector<float> out(w.size());
+    uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
+    const size_t rows = w.size() / K;
+    for (size_t r = 0; r < rows; ++r)
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            uint16_t* blk = o + (r * K + k0) * 2;
+            for (int k = 0; k < 32; ++k) {
+                const float v = w[r * K + k0 + k] * F16X3_WEIGHT_SCALE;
+                const uint16_t hi = f32_to_f16(v);
+                blk[k] = hi;
+                blk[32 + k] = f32_to_f16(v - f16_to_f32(hi));
+            }
+        }
+    return out;
+}
+
 static int finish_layer(ConvLayer& L, const std::vector<float>& w, const std::vector<float>& scale,
                         const std::vector<float>& shift)
 {
     int rc;
-    if ((rc = upload(w, &L.w))) return rc;
-    if ((rc = upload(scale, &L.scale))) return rc;
+    if (L.prec == PREC_F16X3) {
+        const float ws = f16x3_weight_scale(w);
+        std::vector<float> sc(scale);
+        for (float& v : sc) v *= 1.f / ws;          // exact: ws is a power of two
+        if ((rc = upload(split_panel(w, L.K, ws), &L.w))) return rc;
+        if ((rc = upload(sc, &L.scale))) return rc;
+    } else {
+        if ((rc = upload(w, &L.w))) return rc;
+        if ((rc = upload(scale, &L.scale))) return rc;
+    }
     if ((rc = upload(shift, &L.shift))) return rc;
     return P2P_OK;
 }
@@ -106,6 +180,7 @@ static int pack_conv(const TensorMap& T, const std::vector<std::string>& names, 
                      int pad, bool bn, ConvLayer& L)
 {
     const int nb = (int)names.size();
+    L.prec = g_pack_prec;
     L.Cout = cout_each * nb;
     L.ntaps = KH * KH;
     L.K = L.ntaps * Cin;
@@ -137,6 +212,7 @@ static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& n
                            ConvLayer& L)
 {
     const int nb = (int)names.size();
+    L.prec = PREC_F32;                 // VALU direct convolution: always fp32
     L.Cout = cout_each * nb;
     L.K = KH * KH * 3;
     std::vector<float> w((size_t)L.K * L.Cout), scale, shift;
@@ -159,6 +235,7 @@ static int pack_deconv_phase(const TensorMap& T, const std::string& name, int Ci
 {
     const float* k = T.get(name + ".kernel", (int64_t)25 * Cin * Cout);
     if (!k) return P2P_ERR_WEIGHTS;
+    L.prec = g_pack_prec;
     L.Cout = Cout;
     L.ntaps = 0;
     int khs[3], kws[3], nkh = 0, nkw = 0;
@@ -179,15 +256,11 @@ static int pack_deconv_phase(const TensorMap& T, const std::string& name, int Ci
                 for (int ci = 0; ci < Cin; ++ci)
                     w[(size_t)co * L.K + (size_t)t * Cin + ci] = k[(((size_t)kh * 5 + kw) * Cout + co) * Cin + ci];
         }
-    int rc = upload(w, &L.w);
+    std::vector<float> scale, shift;
+    int rc = fold_bn(T, name, Cout, true, scale, shift);
     if (rc) return rc;
-    if (with_epilogue) {
-        std::vector<float> scale, shift;
-        if ((rc = fold_bn(T, name, Cout, true, scale, shift))) return rc;
-        if ((rc = upload(scale, &L.scale))) return rc;
-        if ((rc = upload(shift, &L.shift))) return rc;
-    }
-    return P2P_OK;
+    (void)with_epilogue;
+    return finish_layer(L, w, scale, shift);
 }
 
 // Both heads (Conv2DTranspose 128->3 tanh, 128->1 sigmoid; ae_model.py:233-236) as ONE 3x3-tap
@@ -201,6 +274,7 @@ static int pack_heads(const TensorMap& T, ConvLayer& L)
     const float* bx = T.get("head_xyz.bias", 3);
     const float* bp = T.get("head_prob.bias", 1);
     if (!kx || !kp || !bx || !bp) return P2P_ERR_WEIGHTS;
+    L.prec = g_pack_prec;
     L.Cout = 16;
     L.ntaps = 9;
     L.K = 9 * Cin;
@@ -231,6 +305,7 @@ static int pack_dense(const TensorMap& T, const std::string& name, int In, int O
 {
     const float* k = T.get(name + ".kernel", (int64_t)In * Out);
     if (!k) return P2P_ERR_WEIGHTS;
+    L.prec = g_pack_prec;
     L.Cout = Out;
     L.ntaps = 1;
     L.K = In;
@@ -274,6 +349,7 @@ static int build_decoder(const TensorMap& T, Model& M, int skip3, int skip2, int
 static int build_model(const TensorMap& T, Model& M)
 {
     int rc;
+    g_pack_prec = M.prec;      // the igemm panels packed below take the model's precision
     if (M.backbone == P2P_BACKBONE_RESNET50) {
         if ((rc = pack_conv_first(T, {"conv1"}, 7, 64, M.L["conv1"]))) return rc;
         const struct { const char* n; int cin, f1, f3; bool sc; } blocks[7] = {
@@ -406,6 +482,7 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     p.out = c.out; p.Hout = c.Hout; p.Wout = c.Wout; p.os = c.os; p.oy = c.oy; p.ox = c.ox;
     p.out_cstride = c.out_cstride; p.out_coff = c.out_coff;
     p.mode = c.mode;
+    p.prec = L.prec;
     const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? 1 : 2);
     if (X.grp && X.grp->models.size() > 1) {
         const GroupCtx& G = *X.grp;
@@ -414,6 +491,7 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
         int tile0 = 0;
         for (int g = 0; g < ng; ++g) {
             const ConvLayer& Lg = G.models[g]->L.at(L.name);
+            if (Lg.prec != L.prec) { set_error("run_conv: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
             p.grp[g] = {Lg.w, Lg.scale, Lg.shift, G.start[g] * rows_per_sample, tile0};
             tile0 += ((G.start[g + 1] - G.start[g]) * rows_per_sample + BM - 1) / BM;
         }
@@ -753,7 +831,13 @@ int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset)
 
 int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone, p2p_model** out)
 {
+    return p2p_model_create_ex(ctx, tensors, n_tensors, backbone, P2P_PREC_DEFAULT, out);
+}
+
+int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone, int precision, p2p_model** out)
+{
     if (!ctx || !tensors || !out || n_tensors <= 0) { set_error("p2p_model_create: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    if (precision != P2P_PREC_F32 && precision != P2P_PREC_F16X3) { set_error("p2p_model_create: unknown precision %d", precision); return P2P_ERR_INVALID_ARG; }
     *out = nullptr;
     if (backbone != P2P_BACKBONE_PAPER && backbone != P2P_BACKBONE_RESNET50) {
         // the reference silently leaves generator_train undefined here (recognition.py:21-26)
@@ -769,6 +853,7 @@ int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int
     }
     Model* m = new Model();
     m->backbone = backbone;
+    m->prec = precision == P2P_PREC_F16X3 ? PREC_F16X3 : PREC_F32;
     m->device = c->device;
     int rc = build_model(T, *m);
     if (rc) { delete m; return rc; }

@@ -64,9 +64,14 @@ class Generator:
     """Drop-in for the Keras model held in ``pix2pose.generator_train``
     (reference recognition.py:21-26): ``predict(x) -> [decode, prob]`` (recognition.py:84,129)."""
 
-    def __init__(self, weights: dict, backbone: str, ctx: Context | None = None):
+    def __init__(self, weights: dict, backbone: str, ctx: Context | None = None, precision: str = "f16x3"):
+        """precision: 'f32' (fp32 matrix instructions) or 'f16x3' (fp32 emulated with three split-f16
+        MFMAs per product block, fp32 accumulate; see include/p2p_mi355.h)."""
         if backbone not in _lib.BACKBONE:
             raise ValueError("unknown backbone %r" % (backbone,))
+        if precision not in _lib.PRECISION:
+            raise ValueError("unknown precision %r" % (precision,))
+        self.precision = precision
         W.check_weights(backbone, weights)
         self.ctx = ctx or default_context()
         self.backbone = backbone
@@ -80,8 +85,8 @@ class Generator:
             arr[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
             arr[i].numel = a.size
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().p2p_model_create(self.ctx.handle, arr, len(specs), _lib.BACKBONE[backbone],
-                                               C.byref(self._h)), "p2p_model_create")
+        _lib.check(_lib.lib().p2p_model_create_ex(self.ctx.handle, arr, len(specs), _lib.BACKBONE[backbone],
+                                                  _lib.PRECISION[precision], C.byref(self._h)), "p2p_model_create_ex")
 
     @property
     def handle(self):

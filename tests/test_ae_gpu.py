@@ -16,12 +16,15 @@ def _inputs(n, seed=0):
     return (np.random.RandomState(seed).randint(0, 256, (n, 128, 128, 3)).astype(np.float32) - 128) / 128
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("backbone", ["resnet50", "paper"])
-def test_predict_matches_oracle(backbone):
+def test_predict_matches_oracle(backbone, precision):
+    """Both arithmetic modes -- fp32 MFMA and fp32 emulated with three split-f16 MFMAs -- are held to
+    the same bar against the double-accumulating oracle."""
     from oracle import ae_oracle as O
     from pix2pose_amd.runtime import Generator
     w = W.synthetic_weights(backbone, 1)
-    g = Generator(w, backbone)
+    g = Generator(w, backbone, precision=precision)
     x = _inputs(3)
     dec, prob = g.predict(x)
     d0, p0 = O.forward(w, x, backbone)
@@ -54,3 +57,21 @@ def test_predict_accepts_float64_like_keras():
     a = g.predict(x)[0]
     b = g.predict(x.astype(np.float32))[0]
     np.testing.assert_array_equal(a, b)
+
+
+def test_f16x3_tracks_f32_mode_and_large_magnitudes():
+    """The split-f16 mode differs from the fp32 mode by fp32-rounding-level amounts, also when the
+    weights are rescaled by large / small powers of two (per-layer pre-scale keeps the split exact)."""
+    from pix2pose_amd.runtime import Generator
+    w = W.synthetic_weights("paper", 5)
+    x = _inputs(2, seed=9)
+    a = Generator(w, "paper", precision="f32").predict(x)
+    b = Generator(w, "paper", precision="f16x3").predict(x)
+    assert np.abs(a[0] - b[0]).max() < 2e-5 and np.abs(a[1] - b[1]).max() < 2e-5
+    w2 = dict(w)
+    w2["conv2_1.kernel"] = w["conv2_1.kernel"] * 4096.0          # compensated by the following BN variance
+    w2["conv2_1.var"] = (w["conv2_1.var"] + 1e-3) * 4096.0 ** 2 - 1e-3
+    w2["conv2_1.mean"] = w["conv2_1.mean"] * 4096.0
+    w2["conv2_1.bias"] = w["conv2_1.bias"] * 4096.0
+    c = Generator(w2, "paper", precision="f16x3").predict(x)
+    assert np.abs(c[0] - a[0]).max() < 5e-5

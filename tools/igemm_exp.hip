@@ -12,6 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // BK: k-step; NBUF: LDS buffers; MID: store next tile to LDS in the middle of the MFMA block; PRIO: setprio
 __device__ unsigned long long g_clk[4];
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int BK, int NBUF, int MID, int PRIO, int EPI = 1, int ABL = 0>
 __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
 {
@@ -77,12 +78,44 @@ __global__ __launch_bounds__(256) void kexp(const IgemmParams p)
     };
     auto lstore = [&](int buf) {
         float* As = smem + buf * (BM + BN) * LD; float* Bs = As + BM * LD;
+        if (ABL & 16) {
+            // row image: [hi16 x 32 | lo16 x 32] (128 B); this thread owns k = lcol..lcol+3
+#pragma unroll
+            for (int j = 0; j < A_PASSES; ++j) {
+                typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+                const h2 h01 = __builtin_amdgcn_cvt_pkrtz(ra[j][0], ra[j][1]), h23 = __builtin_amdgcn_cvt_pkrtz(ra[j][2], ra[j][3]);
+                const h2 l01 = __builtin_amdgcn_cvt_pkrtz(ra[j][0] - (float)h01[0], ra[j][1] - (float)h01[1]);
+                const h2 l23 = __builtin_amdgcn_cvt_pkrtz(ra[j][2] - (float)h23[0], ra[j][3] - (float)h23[1]);
+                char* row = reinterpret_cast<char*>(As + (lrow + RPP * j) * LD);
+                *reinterpret_cast<uint2*>(row + lcol * 2) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                *reinterpret_cast<uint2*>(row + 64 + lcol * 2) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < A_PASSES; ++j) *reinterpret_cast<f32x4*>(As + (lrow + RPP * j) * LD + lcol) = ra[j];
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LD + lcol) = rb[j];
     };
     auto mma = [&](const float* As, const float* Bs, int kk) {
+        if (ABL & 8) {
+            // timing probe for a split-f16 (3 MFMA) path: one K-step of 32 = 2 k16 blocks; each block reads
+            // hi and lo fragments (16 B each) of both operands and issues 3 MFMAs per tile pair
+            if (kk >= 16) return;      // kk = 0, 8 stand for the two k16 blocks
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { ah[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * LD + kk); al[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * LD + kk + 16); }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * LD + kk); bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * LD + kk + 16); }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            return;
+        }
         f32x4 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LD + kk);
@@ -343,6 +376,10 @@ int main(int argc, char** argv)
     }
     ms = run<32, 2, 0, 0>(p, it); printf("BK32 NBUF2            %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2>(p, it); printf("BK32 NBUF1 EPI2 (38KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 8>(p, it); printf("  probe: f16x3 MFMA block, same loader %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 24>(p, it); printf("  probe: f16x3 + in-loader f32->f16 split of A %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 9>(p, it); printf("  probe: f16x3, no gload             %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
+    ms = run<32, 1, 0, 0, 2, 12>(p, it); printf("  probe: f16x3, hot-line loads       %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 4>(p, it); printf("  ablate: hot-line loads %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 1>(p, it); printf("  ablate: no gload      %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 2>(p, it); printf("  ablate: no lstore     %8.3f ms %7.1f TF\n", ms, gf / ms);
