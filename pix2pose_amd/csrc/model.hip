@@ -483,7 +483,10 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     p.out_cstride = c.out_cstride; p.out_coff = c.out_coff;
     p.mode = c.mode;
     p.prec = L.prec;
-    const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? 1 : 2);
+    // Cout = 64 layers: a 256x64 tile keeps the 2x2 register tiling per wave (same MFMA : LDS ratio as
+    // 128x128) when there are enough rows to fill the chip with it; else 128x64
+    const int m_rows = c.N * c.Hg * c.Wg;
+    const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? (m_rows >= 256 * 1024 ? 3 : 1) : 2);
     if (X.grp && X.grp->models.size() > 1) {
         const GroupCtx& G = *X.grp;
         const int ng = (int)G.models.size(), BM = igemm_tile_m(cfg), rows_per_sample = c.Hg * c.Wg;
@@ -825,7 +828,10 @@ int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset)
     int rc = c->prof_harvest();
     if (rc) return rc;
     for (int i = 0; i < 3; ++i) stats[i] = c->prof_stats[i];
-    if (reset) for (int i = 0; i < 3; ++i) c->prof_stats[i] = p2p_kernel_stats{};
+    stats[1].launches += c->prof_stats[3].launches;          // 256x64 tiles are reported with the 128x64 ones
+    stats[1].total_ms += c->prof_stats[3].total_ms;
+    stats[1].algo_flops += c->prof_stats[3].algo_flops;
+    if (reset) for (int i = 0; i < 4; ++i) c->prof_stats[i] = p2p_kernel_stats{};
     return P2P_OK;
 }
 

@@ -378,6 +378,10 @@ int main(int argc, char** argv)
     ms = run<32, 1, 0, 0, 2>(p, it); printf("BK32 NBUF1 EPI2 (38KB) %8.3f ms %7.1f TF\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 8>(p, it); printf("  probe: f16x3 MFMA block, same loader %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 24>(p, it); printf("  probe: f16x3 + in-loader f32->f16 split of A %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
+    ms = run<32, 2, 0, 0, 2, 24>(p, it); printf("  probe: f16x3 split, NBUF2 (1 barrier/step)    %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
+    ms = run<32, 2, 1, 0, 2, 24>(p, it); printf("  probe: f16x3 split, NBUF2 MID                 %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
+    ms = run<32, 2, 0, 1, 2, 24>(p, it); printf("  probe: f16x3 split, NBUF2 PRIO                %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
+    ms = run<32, 1, 0, 1, 2, 24>(p, it); printf("  probe: f16x3 split, NBUF1 PRIO                %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 9>(p, it); printf("  probe: f16x3, no gload             %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 12>(p, it); printf("  probe: f16x3, hot-line loads       %8.3f ms %7.1f TF-equivalent\n", ms, gf / ms);
     ms = run<32, 1, 0, 0, 2, 4>(p, it); printf("  ablate: hot-line loads %8.3f ms %7.1f TF\n", ms, gf / ms);
