@@ -74,6 +74,11 @@ struct IgemmParams {
 hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s);
 int igemm_tile_m(int cfg);   // BM of a tile configuration
 
+// Halo-tiled kernel for the merged output heads (heads.hip); takes the same parameter block as the
+// generic kernel when heads_halo_supported() says so (PREC_F16X3, 64-wide grid, 128 input channels).
+bool heads_halo_supported(const IgemmParams& p);
+hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s);
+
 // out[m][co] = act(sum_z partial[z][m][co] * scale + shift)
 hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cout, const float* scale,
                                 const float* shift, int act, float alpha, float* out, hipStream_t s);
