@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="detections per GPU per step")
     ap.add_argument("--backbone", default="resnet50")
-    ap.add_argument("--chunk", type=int, default=256, help="generator inputs per pass (activation workspace)")
+    ap.add_argument("--chunk", type=int, default=1024, help="generator inputs per pass (activation workspace: 13 MB per input; 1024 holds the 768 stage-2 inputs of a 256-detection batch in one pass)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="detections in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-inject", action="store_true", help="let PnP consume the random-weight generator output")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
@@ -186,7 +186,7 @@ def main():
                    "generator_chunk": args.chunk, "objects": args.objects, "mode": "stream (submit/collect, 2 in flight)" if args.overlap else "blocking"},
         "ae_inputs_per_s": 4 * value,
         "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
-        "poses_ok": n_ok, "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,
+        "poses_ok": n_ok, "ransac_iters_mean_of_selected": float(np.mean([p.ransac_iters for p in poses])), "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,
         "roofline": {"bound": "mfma", "kernel": "igemm_kernel<2,2,2,2,%s> (128x128 tile implicit-GEMM conv)" % ("PREC_F16X3" if args.precision == "f16x3" else "PREC_F32"),
                      "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                      "note": ("algorithmic FLOPs; the split-f16 path issues 3 MFMA FLOPs per algorithmic FLOP, so the matrix pipe runs at "

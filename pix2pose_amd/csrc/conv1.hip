@@ -1,0 +1,171 @@
+// First layer of the ResNet-50 front (ZeroPadding2D(3) + Conv2D 7x7/2, 3 -> 64, BatchNorm, ReLU;
+// reference pix2pose_model/resnet50_mod.py:200-203) on the f16 matrix cores, PREC_F16X3 models only.
+//
+// Cin = 3 makes the layer useless for the generic implicit-GEMM kernel (K = 147, 12-byte pixels), and the
+// VALU kernel (misc_kernels.hip, still used by PREC_F32 models and the paper backbone) spends its time
+// re-reading weights.  Here the contraction is laid out per kernel ROW: for one kh the 7 taps x 3
+// channels of an output pixel are 7 consecutive input pixels, staged in LDS as 4-channel f16 pixels
+// (r, g, b, 0) so the run is 28 (+4 zero-weighted) contiguous halves = one K = 32 MFMA block that a lane
+// reads with a single aligned ds_read_b128.  K = 7 blocks of 32 (34 % padding — irrelevant, the layer is
+// bound by its 268 MB output).  A workgroup keeps the whole split weight panel (56 KB) in LDS and walks
+// 16 output rows of one image, two rows (nine input rows) at a time.
+//
+// GEMM orientation: rows = 16 output channels, columns = 16 consecutive output pixels, so a lane ends
+// up with 4 consecutive channels of one pixel (float4 store).
+#include "kernels.h"
+
+namespace p2p {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int C1_KH = 7, C1_PAD = 3, C1_COUT = 64;
+constexpr int C1_HIN = 128, C1_HOUT = 64;
+constexpr int C1_ROWS_OUT = 2;                                   // output rows per tile
+constexpr int C1_ROWS_IN = (C1_ROWS_OUT - 1) * 2 + C1_KH;        // 9 input rows
+constexpr int C1_ROW_PX = C1_HIN + 2 * C1_PAD;                   // 134 staged pixels per row (pixel -3 first)
+constexpr int C1_ROW_BYTES = C1_ROW_PX * 8;                      // 4 halves per pixel; 1072 B, 16-B aligned
+constexpr int C1_PLANE = C1_ROWS_IN * C1_ROW_BYTES;              // hi plane, then lo plane
+constexpr int C1_W_BYTES = C1_KH * 2 * 4 * C1_COUT * 16;         // [kh][hi,lo][k-group][cout][8 halves] = 57344
+constexpr int C1_TILES_PER_WG = 8;                               // 16 output rows per workgroup
+constexpr int C1_PASSES = (C1_ROWS_IN * C1_HIN + 255) / 256;     // pixel loads per thread per tile (5)
+
+__global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __restrict__ x, int N, const float* __restrict__ w_alt,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int act, float alpha, float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) char smem[C1_W_BYTES + 2 * C1_PLANE];
+    char* ws = smem;
+    char* xs = smem + C1_W_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wgs_per_img = C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG);
+    const int n = blockIdx.x / wgs_per_img;
+    const int oy_base = (blockIdx.x - n * wgs_per_img) * C1_ROWS_OUT * C1_TILES_PER_WG;
+
+    // weights -> LDS (linear copy), zero the staging planes once (the padding pixels stay zero)
+    for (int i = tid; i < C1_W_BYTES / 16; i += 256)
+        reinterpret_cast<uint4*>(ws)[i] = reinterpret_cast<const uint4*>(w_alt)[i];
+    for (int i = tid; i < 2 * C1_PLANE / 16; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((size_t)N * C1_HIN * C1_HIN * 12), 0x00020000);
+
+    float rx[C1_PASSES][3];
+    auto gload = [&](int oy0) {
+        const int iy0 = 2 * oy0 - C1_PAD;
+#pragma unroll
+        for (int j = 0; j < C1_PASSES; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx >> 7, px = idx & 127;
+            const int iy = iy0 + r;
+            const bool ok = r < C1_ROWS_IN && iy >= 0 && iy < C1_HIN;
+            const unsigned off = ok ? (unsigned)((((size_t)n * C1_HIN + iy) * C1_HIN + px) * 12) : 0xFFFFFFF0u;
+            // three dword loads: hipcc (ROCm 7.2) lowers __builtin_amdgcn_raw_buffer_load_b96 to ONE dword
+#pragma unroll
+            for (int e = 0; e < 3; ++e) rx[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, e * 4, 0));
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < C1_PASSES; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx >> 7, px = idx & 127;
+            if (r >= C1_ROWS_IN) continue;
+            const float* v = rx[j];
+            const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h2 = __builtin_amdgcn_cvt_pkrtz(v[2], 0.f);
+            fp16x2 l01, l2;
+            l01[0] = (__fp16)(v[0] - (float)h01[0]); l01[1] = (__fp16)(v[1] - (float)h01[1]);
+            l2[0] = (__fp16)(v[2] - (float)h2[0]); l2[1] = (__fp16)0.f;
+            char* d = xs + r * C1_ROW_BYTES + (px + C1_PAD) * 8;
+            *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h2));
+            *reinterpret_cast<uint2*>(d + C1_PLANE) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l2));
+        }
+    };
+
+    // wave -> output row (wave >> 1) of the tile, pixels 32 (wave & 1) .. +31 (two 16-pixel column tiles)
+    const int li = lane & 15, lg = lane >> 4;
+    const int orow = wave >> 1, ox0 = (wave & 1) * 32;
+    // pixel operand: the run of output pixel ox starts at staged pixel 2 ox (= input pixel 2 ox - 3): byte 16 ox
+    const char* xb = xs + (2 * orow) * C1_ROW_BYTES + (ox0 + li) * 16 + lg * 16;
+    const char* wb = ws + lg * (C1_COUT * 16) + li * 16;
+
+    gload(oy_base);
+    for (int t = 0; t < C1_TILES_PER_WG; ++t) {
+        const int oy0 = oy_base + t * C1_ROWS_OUT;
+        __syncthreads();                     // previous tile's reads (and the initial fills) are done
+        lstore();
+        __syncthreads();
+        if (t + 1 < C1_TILES_PER_WG) gload(oy0 + C1_ROWS_OUT);
+
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < C1_KH; ++kh) {
+            f16x8 xh[2], xl[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                xh[m] = *reinterpret_cast<const f16x8*>(xb + kh * C1_ROW_BYTES + m * 256);
+                xl[m] = *reinterpret_cast<const f16x8*>(xb + kh * C1_ROW_BYTES + m * 256 + C1_PLANE);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(wb + (kh * 2 + 0) * (4 * C1_COUT * 16) + q * 256);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(wb + (kh * 2 + 1) * (4 * C1_COUT * 16) + q * 256);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[m], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[m], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][q], 0, 0, 0);
+                }
+            }
+        }
+        // lane: channels 16 q + 4 lg .. +3 of output pixel (oy0 + orow, ox0 + 16 m + li)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float* op = out + (((size_t)n * C1_HOUT + oy0 + orow) * C1_HOUT + ox0 + 16 * m + li) * C1_COUT + lg * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 16 + lg * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 16 + lg * 4);
+                f32x4 v = acc[m][q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u = fmaf(v[e], sc[e], sh[e]);
+                    if (act == ACT_RELU) u = fmaxf(u, 0.f);
+                    else if (act == ACT_LEAKY) u = u > 0.f ? u : u * alpha;
+                    v[e] = u;
+                }
+                *reinterpret_cast<f32x4*>(op + q * 16) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t conv1_f16x3_panel_floats() { return C1_W_BYTES / 4; }
+
+// k within a kernel row: kk = kw * 4 + c (c < 3), group = kk / 8; layout [kh][hi,lo][group][cout][8 halves]
+size_t conv1_f16x3_panel_index(int kh, int plane, int kw, int c, int cout)
+{
+    const int kk = kw * 4 + c;
+    return ((((size_t)kh * 2 + plane) * 4 + (kk >> 3)) * C1_COUT + cout) * 8 + (kk & 7);
+}
+
+hipError_t launch_conv1_f16x3(const float* x, int N, const float* w_alt, const float* scale, const float* shift, int act,
+                              float alpha, float* out, hipStream_t s)
+{
+    if (N <= 0) return hipSuccess;
+    if ((size_t)N * C1_HIN * C1_HIN * 12 >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG));
+    hipLaunchKernelGGL(conv1_f16x3_kernel, dim3(wgs), dim3(256), 0, s, x, N, w_alt, scale, shift, act, alpha, out);
+    return hipGetLastError();
+}
+
+}  // namespace p2p

@@ -93,6 +93,14 @@ hipError_t launch_conv_first(const float* x, int N, int H, int W, const float* w
                              int stride, int pad, int Cout, const float* scale, const float* shift,
                              int act, float alpha, float* out, int Ho, int Wo, hipStream_t s);
 
+// The same layer for PREC_F16X3 ResNet-50 models on the f16 matrix cores (conv1.hip): 7x7/2, pad 3, 3 -> 64,
+// 128x128 input.  w_alt: split-f16 panel, conv1_f16x3_panel_floats() floats, element (kh, hi/lo plane, kw, c, cout)
+// at half index conv1_f16x3_panel_index().
+size_t conv1_f16x3_panel_floats();
+size_t conv1_f16x3_panel_index(int kh, int plane, int kw, int c, int cout);
+hipError_t launch_conv1_f16x3(const float* x, int N, const float* w_alt, const float* scale, const float* shift, int act,
+                              float alpha, float* out, hipStream_t s);
+
 // MaxPooling2D 3x3 stride 2, TF 'SAME' (pad 0 before / 1 after), NHWC, C % 4 == 0.
 hipError_t launch_maxpool3s2(const float* x, int N, int H, int W, int C, float* out, hipStream_t s);
 

@@ -224,6 +224,27 @@ static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& n
         int rc = fold_bn(T, names[b], cout_each, true, scale, shift);
         if (rc) return rc;
     }
+    if (g_pack_prec == PREC_F16X3 && KH == 7 && L.Cout == 64) {
+        // matrix-core variant (conv1.hip): split-f16 panel in that kernel's own layout; L.prec marks it
+        const float ws = f16x3_weight_scale(w);
+        std::vector<float> panel(conv1_f16x3_panel_floats(), 0.f), sc(scale);
+        uint16_t* o = reinterpret_cast<uint16_t*>(panel.data());
+        for (int kh = 0; kh < 7; ++kh)
+            for (int kw = 0; kw < 7; ++kw)
+                for (int c = 0; c < 3; ++c)
+                    for (int co = 0; co < 64; ++co) {
+                        const float v = w[(size_t)((kh * 7 + kw) * 3 + c) * L.Cout + co] * ws;
+                        const uint16_t hi = f32_to_f16(v);
+                        o[conv1_f16x3_panel_index(kh, 0, kw, c, co)] = hi;
+                        o[conv1_f16x3_panel_index(kh, 1, kw, c, co)] = f32_to_f16(v - f16_to_f32(hi));
+                    }
+        for (float& v : sc) v *= 1.f / ws;
+        L.prec = PREC_F16X3;
+        int rc;
+        if ((rc = upload(panel, &L.w))) return rc;
+        if ((rc = upload(sc, &L.scale))) return rc;
+        return upload(shift, &L.shift);
+    }
     return finish_layer(L, w, scale, shift);
 }
 
@@ -588,10 +609,14 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
     const float *s1, *s2, *s3;      // skip tensors and their pixel strides / channel offsets
     int s1_stride, s1_off, s1_C, s2_stride, s2_off, s3_stride, s3_off;
     if (M.backbone == P2P_BACKBONE_RESNET50) {
-        for (int g = 0; g < n_grp; ++g) {      // VALU first layer: one launch per object (tiny)
+        for (int g = 0; g < n_grp; ++g) {      // first layer: one launch per object (tiny)
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
-            HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift,
-                                      ACT_RELU, LEAKY, A["f1"] + (size_t)g0(g) * 64 * 64 * 64, 64, 64, st));
+            if (c1.prec == PREC_F16X3)
+                HIP_TRY(launch_conv1_f16x3(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), c1.w, c1.scale, c1.shift, ACT_RELU, LEAKY,
+                                           A["f1"] + (size_t)g0(g) * 64 * 64 * 64, st));
+            else
+                HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift,
+                                          ACT_RELU, LEAKY, A["f1"] + (size_t)g0(g) * 64 * 64 * 64, 64, 64, st));
         }
         HIP_TRY(launch_maxpool3s2(A["f1"], n, 64, 64, 64, A["p1"], st));
         if ((rc = res_block(M, X, "res2a", A["p1"], n, 32, 64, 64, 1, true, A["o_a"]))) return rc;
