@@ -4,8 +4,8 @@
 // The heads are a 3x3-tap convolution over the 64x64 grid with 16 outputs (4 sub-pixel phases x
 // (x, y, z, prob)), K = 9 x 128.  As an implicit GEMM with only 16 output columns the layer is pure
 // operand traffic: every input pixel is gathered nine times (once per tap) and the generic kernel
-// (igemm.hip) moved 3.6 GB per launch for a 0.54 GB tensor.  Here a workgroup owns TH full-width rows
-// of one sample, brings the (TH+2) x 66 halo of a 32-channel slice into LDS ONCE (split into f16
+// (igemm.hip) moved 3.6 GB per launch for a 0.54 GB tensor.  Here a workgroup walks full-width row tiles
+// (TH rows each) of one sample, brings the (TH+2) x 66 halo of a 32-channel slice into LDS ONCE (split into f16
 // hi / lo halves on the way, like the igemm loader), and all nine taps read their operands from that
 // image.  HBM traffic = the tensor once (+ halo rows out of L2) + the output.
 //
@@ -23,7 +23,8 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int HEADS_TH = 4;                 // grid rows per workgroup (one per wave)
+constexpr int HEADS_TH = 4;                 // grid rows per tile (one per wave)
+constexpr int HEADS_TILES = 4;              // row tiles a workgroup walks
 constexpr int HEADS_W = 64;                 // grid width (full rows: the x halo is the zero padding)
 constexpr int HEADS_WP = HEADS_W + 2;
 constexpr int HEADS_HP = HEADS_TH + 2;
@@ -40,15 +41,16 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of row tiles so
-    // the halo rows two neighbouring tiles share come out of the same L2
-    const int tiles_per_sample = p.Hg / HEADS_TH;
-    const int n_tiles = p.N * tiles_per_sample;
-    const int per_xcd = (n_tiles + 7) / 8;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    const int n = tile / tiles_per_sample;
-    const int gy0 = (tile - n * tiles_per_sample) * HEADS_TH;
+    // a workgroup walks HEADS_TILES consecutive row tiles of one sample (the load pipeline keeps running
+    // across tiles).  XCD-aware order: block b runs on XCD b % 8; every XCD gets a contiguous run of
+    // workgroups so the halo rows two neighbours share come out of the same L2
+    const int wgs_per_sample = p.Hg / (HEADS_TH * HEADS_TILES);
+    const int n_wgs = p.N * wgs_per_sample;
+    const int per_xcd = (n_wgs + 7) / 8;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wg >= n_wgs) return;
+    const int n = wg / wgs_per_sample;
+    const int gy_first = (wg - n * wgs_per_sample) * HEADS_TH * HEADS_TILES;
 
     // per-object panels of a grouped launch (groups are runs of samples)
     const float* w = p.w;
@@ -72,22 +74,28 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)p.w_bytes, 0x00020000);
 
     // halo gather: float4 idx = tid + 256 j -> pixel idx/8 (row-major over HP x 64), quad idx%8
-    unsigned x_off[HEADS_LOADS];
+    unsigned x_off[HEADS_LOADS];      // byte offset of the element in row gy_first - 1 + r (may be "negative": only used when valid)
     int s_off[HEADS_LOADS];
 #pragma unroll
     for (int j = 0; j < HEADS_LOADS; ++j) {
         const int idx = tid + 256 * j;
         const int pix = idx >> 3, q = idx & 7;
         const int r = pix / HEADS_W, x = pix - r * HEADS_W;
-        const int gy = gy0 - 1 + r;
-        x_off[j] = (gy >= 0 && gy < p.Hg) ? (unsigned)((((size_t)n * p.Hg + gy) * HEADS_W + x) * HEADS_CIN + q * 4) * 4u : 0xFFFFFFF0u;
+        x_off[j] = (unsigned)(((((long long)n * p.Hg + gy_first - 1 + r) * HEADS_W + x) * HEADS_CIN + q * 4) * 4);
         s_off[j] = (r * HEADS_WP + x + 1) * HEADS_REC + q * 8;
     }
     f32x4 rx[HEADS_LOADS];
-    auto gload = [&](int chunk) {
+    auto gload = [&](int it) {                    // it = tile * HEADS_CHUNKS + chunk
+        const int tile = it / HEADS_CHUNKS, chunk = it - tile * HEADS_CHUNKS;
+        const int gy_top = gy_first + tile * HEADS_TH - 1;
+        const unsigned tile_off = (unsigned)(tile * HEADS_TH * HEADS_W * HEADS_CIN * 4);
 #pragma unroll
-        for (int j = 0; j < HEADS_LOADS; ++j)
-            rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[j], chunk * 128, 0));
+        for (int j = 0; j < HEADS_LOADS; ++j) {
+            const int r = (tid + 256 * j) / (8 * HEADS_W);
+            const int gy = gy_top + r;
+            const unsigned off = (gy >= 0 && gy < p.Hg) ? x_off[j] + tile_off : 0xFFFFFFF0u;
+            rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, chunk * 128, 0));
+        }
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -108,11 +116,16 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
     const char* xs = smem + ((wave + 1) * HEADS_WP + li + 1) * HEADS_REC + lg * 16;
 
     f32x4 acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + lg * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + lg * 4);
 
     gload(0);
-    for (int chunk = 0; chunk < HEADS_CHUNKS; ++chunk) {
+    for (int it = 0; it < HEADS_TILES * HEADS_CHUNKS; ++it) {
+        const int tile = it / HEADS_CHUNKS, chunk = it - tile * HEADS_CHUNKS;
+        if (chunk == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // weight fragments of this chunk: 9 taps x (hi, lo); K order is (tap, cin), 128 B per 32-deep block
         f16x8 wh[9], wl[9];
 #pragma unroll
@@ -121,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
             wh[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, kb * 128, 0));
             wl[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, kb * 128 + 64, 0));
         }
-        if (chunk) __syncthreads();          // every wave is done reading the previous slice
+        if (it) __syncthreads();             // every wave is done reading the previous slice
         lstore();
         __syncthreads();
-        if (chunk + 1 < HEADS_CHUNKS) gload(chunk + 1);     // flies under this slice's MFMAs
+        if (it + 1 < HEADS_TILES * HEADS_CHUNKS) gload(it + 1);     // flies under this slice's MFMAs (and the epilogue)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -138,21 +151,20 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xh, acc[m], 0, 0, 0);
             }
         }
-    }
-
-    // lane: outputs 4 lg .. 4 lg + 3 = (x, y, z, prob) of phase lg for grid pixel (gy0 + wave, 16 m + li)
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + lg * 4);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + lg * 4);
-    const int oy = 2 * (gy0 + wave) + (lg >> 1);
+        if (chunk == HEADS_CHUNKS - 1) {
+            // lane: outputs 4 lg .. 4 lg + 3 = (x, y, z, prob) of phase lg for grid pixel (gy0 + wave, 16 m + li)
+            const int oy = 2 * (gy_first + tile * HEADS_TH + wave) + (lg >> 1);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int ox = 2 * (16 * m + li) + (lg & 1);
-        f32x4 v = acc[m], o;
+            for (int m = 0; m < 4; ++m) {
+                const int ox = 2 * (16 * m + li) + (lg & 1);
+                f32x4 v = acc[m], o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-        o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
-        o[3] = 1.f / (1.f + __expf(-v[3]));
-        *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Hout + oy) * p.Wout + ox) * 4) = o;
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
+                o[3] = 1.f / (1.f + __expf(-v[3]));
+                *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Hout + oy) * p.Wout + ox) * 4) = o;
+            }
+        }
     }
 }
 
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
 
 bool heads_halo_supported(const IgemmParams& p)
 {
-    return p.prec == PREC_F16X3 && p.mode == EPI_HEAD && p.ntaps == 9 && p.Cout == 16 && p.Wg == HEADS_W && p.Hg % HEADS_TH == 0 &&
+    return p.prec == PREC_F16X3 && p.mode == EPI_HEAD && p.ntaps == 9 && p.Cout == 16 && p.Wg == HEADS_W && p.Hg % (HEADS_TH * HEADS_TILES) == 0 &&
            p.Hin == p.Hg && p.Win == p.Wg && p.in_stride == 1 && p.os == 2 && p.Hout == 2 * p.Hg && p.Wout == 2 * p.Wg &&
            p.seg[0].C == HEADS_CIN && p.seg[0].cstride == HEADS_CIN && p.seg[0].coff == 0 && p.seg[1].C == 0 && p.ksplit <= 1 &&
            p.dy[0] == -1 && p.dx[0] == -1 && p.dy[8] == 1 && p.dx[8] == 1;
@@ -168,8 +180,8 @@ bool heads_halo_supported(const IgemmParams& p)
 
 hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s)
 {
-    const int n_tiles = p.N * (p.Hg / HEADS_TH);
-    const int per_xcd = (n_tiles + 7) / 8;
+    const int n_wgs = p.N * (p.Hg / (HEADS_TH * HEADS_TILES));
+    const int per_xcd = (n_wgs + 7) / 8;
     hipLaunchKernelGGL(heads_halo_kernel, dim3(per_xcd * 8), dim3(256), 0, s, p);
     return hipGetLastError();
 }
