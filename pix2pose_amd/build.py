@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libp2p_mi355.so")
-SOURCES = ["igemm.hip", "heads.hip", "conv1.hip", "misc_kernels.hip", "model.hip", "pipeline.hip", "pnp.hip"]
+SOURCES = ["igemm.hip", "igemm_halo.hip", "heads.hip", "conv1.hip", "misc_kernels.hip", "model.hip", "pipeline.hip", "pnp.hip"]
 HEADERS = ["kernels.h", "model.h", "pipeline.h", os.path.join("..", "..", "include", "p2p_mi355.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

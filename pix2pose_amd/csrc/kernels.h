@@ -74,6 +74,11 @@ struct IgemmParams {
 hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s);
 int igemm_tile_m(int cfg);   // BM of a tile configuration
 
+// Halo-tiled variant for stride-1 multi-tap layers (igemm_halo.hip): the input patch of a channel slice is staged
+// once for all taps.  Same parameter block; PREC_F16X3, grid a multiple of 8x16, no split-K.
+bool igemm_halo_supported(const IgemmParams& p);
+hipError_t launch_igemm_halo(const IgemmParams& p, hipStream_t s);
+
 // Halo-tiled kernel for the merged output heads (heads.hip); takes the same parameter block as the
 // generic kernel when heads_halo_supported() says so (PREC_F16X3, 64-wide grid, 128 input channels).
 bool heads_halo_supported(const IgemmParams& p);

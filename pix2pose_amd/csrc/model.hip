@@ -523,17 +523,19 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
         p.n_groups = ng;
     }
     const bool halo = heads_halo_supported(p);     // the output heads have their own kernel (heads.hip)
+    static const bool no_halo = getenv("P2P_NO_HALO") != nullptr;
+    const bool halo_conv = !halo && !no_halo && igemm_halo_supported(p);   // stride-1 multi-tap layers (igemm_halo.hip)
     if (X.profiling) {
         Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), cfg,
                           2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
         if (!ev.a || !ev.b) return P2P_ERR_HIP;
         HIP_TRY(hipEventRecord(ev.a, st));
-        HIP_TRY(halo ? launch_heads_halo(p, st) : launch_igemm(p, cfg, st));
+        HIP_TRY(halo ? launch_heads_halo(p, st) : halo_conv ? launch_igemm_halo(p, st) : launch_igemm(p, cfg, st));
         HIP_TRY(hipEventRecord(ev.b, st));
         X.prof_pending.push_back(ev);
         return P2P_OK;
     }
-    HIP_TRY(halo ? launch_heads_halo(p, st) : launch_igemm(p, cfg, st));
+    HIP_TRY(halo ? launch_heads_halo(p, st) : halo_conv ? launch_igemm_halo(p, st) : launch_igemm(p, cfg, st));
     return P2P_OK;
 }
 
