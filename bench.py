@@ -99,7 +99,7 @@ def main():
             dist.init_process_group(args.backend)
     coll_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
-    from pix2pose_amd import synthetic, weights as W
+    from pix2pose_amd import _lib, synthetic, weights as W
     from pix2pose_amd.parallel import gather_poses, poses_to_records
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch, est_pose_submit
 
@@ -169,7 +169,12 @@ def main():
             for i, p in enumerate(poses) if p.status == 0]
     total = world * args.batch * args.steps
     value = total / dt
-    s0 = stats[0]
+    dom = max(range(len(stats)), key=lambda i: stats[i]["total_ms"])     # dominant kernel family of the timed region
+    s0 = stats[dom]
+    prec_id = 1 if args.precision == "f16x3" else 0
+    dom_label, dom_name = _lib.PROFILE_KERNELS[dom]
+    if "%d" in dom_name:
+        dom_name = dom_name % prec_id
     ach = s0["algo_flops"] / (s0["total_ms"] * 1e-3) / 1e12 if s0["total_ms"] > 0 else 0.0
     all_ms = sum(s["total_ms"] for s in stats)
     peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
@@ -187,14 +192,17 @@ def main():
         "ae_inputs_per_s": 4 * value,
         "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
         "poses_ok": n_ok, "ransac_iters_mean_of_selected": float(np.mean([p.ransac_iters for p in poses])), "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,
-        "roofline": {"bound": "mfma", "kernel": "igemm_kernel<2,2,2,2,%s> (128x128 tile implicit-GEMM conv)" % ("PREC_F16X3" if args.precision == "f16x3" else "PREC_F32"),
+        "roofline": {"bound": "mfma", "kernel": "%s: %s" % (dom_name, dom_label),
                      "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                     "note": ("algorithmic FLOPs; the split-f16 path issues 3 MFMA FLOPs per algorithmic FLOP, so the matrix pipe runs at "
-                              "%.2f of its f16 peak and the kernel delivers %.2fx the fp32-MFMA peak (157.3)" % (3 * ach / peak, ach / PEAK_F32_MFMA_TFLOPS))
+                     "note": ("achieved = algorithmic FLOPs (2 x MACs of the layers) / launch time; the split-f16 arithmetic issues 3 MFMA FLOPs "
+                              "per algorithmic FLOP, so the matrix pipe sustains %.0f TFLOP/s = %.2f of its 2500 dense f16 peak (the power-limited "
+                              "ceiling of dense f16 MFMA on random operands is ~1330, cdna_hip_programming.md 5.4 rule 25) and the kernel "
+                              "delivers %.2fx the fp32-MFMA peak (157.3)" % (3 * ach, 3 * ach / peak, ach / PEAK_F32_MFMA_TFLOPS))
                              if args.precision == "f16x3" else "fp32 MFMA",
                      "avg_launch_ms": s0["total_ms"] / max(s0["launches"], 1), "launches": s0["launches"],
                      "algo_gflop_per_launch": s0["algo_flops"] / max(s0["launches"], 1) / 1e9,
-                     "share_of_step_time": s0["total_ms"] * 1e-3 / dt, "all_igemm_share_of_step_time": all_ms * 1e-3 / dt,
+                     "share_of_step_time": s0["total_ms"] * 1e-3 / dt, "all_conv_kernels_share_of_step_time": all_ms * 1e-3 / dt,
+                     "families": {_lib.PROFILE_KERNELS[i][0]: {"launches": st["launches"], "total_ms": st["total_ms"], "algo_tflops": (st["algo_flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] > 0 else 0.0)} for i, st in enumerate(stats) if st["launches"]},
                      "traffic": None},
     }
     # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes of this same
@@ -203,7 +211,7 @@ def main():
     if os.path.exists(tfn):
         tr = json.load(open(tfn))
         for k, v in tr.items():
-            if "igemm_kernel<2, 2, 2, 2, %d>" % (1 if args.precision == "f16x3" else 0) in k:
+            if dom_name in k:
                 out["roofline"]["traffic"] = v["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 PMC (FETCH_SIZE*2 + WRITE_SIZE), profiles/r01_traffic.json"
     if rank == 0 and world == 1 and args.cpu_sample > 0:

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define P2P_ABI_VERSION 1
+#define P2P_ABI_VERSION 2
 
 typedef enum {
     P2P_OK = 0,
@@ -216,11 +216,15 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
                          unsigned char* inlier_mask);
 
 /* ------------------------------------------------------------------------------------------
- * Measurement hooks (bench.py): when enabled, every launch of the implicit-GEMM convolution
- * kernel is bracketed by HIP events on the context stream; stats are per tile configuration
- * (0: 128x128, 1: 128x64, 2: 128x32).  algo_flops counts the layers' algorithmic FLOPs
- * (2 x MACs of the reference layer), not padded work.
+ * Measurement hooks (bench.py): when enabled, every launch of a convolution kernel of the generator is
+ * bracketed by HIP events on the stream it is launched on; stats are per kernel family:
+ *   0  igemm_kernel 128x128 tiles     1  igemm_kernel 128x64 / 256x64 tiles     2  igemm_kernel 128x32 tiles
+ *   3  igemm_halo_kernel<2> (halo-tiled stride-1 multi-tap layers, 128x128 tiles)     4  igemm_halo_kernel<1> (128x64 tiles)
+ *   5  heads_halo_kernel (merged output heads)
+ * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md
+ * section 8a-L), not padded work and not the 3 MFMA products per MAC of the split-f16 arithmetic.
  * ---------------------------------------------------------------------------------------- */
+#define P2P_PROFILE_SLOTS 6
 typedef struct {
     int64_t launches;
     double total_ms;
@@ -229,7 +233,7 @@ typedef struct {
 
 int p2p_profile_enable(p2p_ctx* ctx, int on);
 /* Harvest finished events (synchronises the stream) and return the accumulated stats; reset
- * clears the accumulators afterwards.  stats must hold 3 entries. */
+ * clears the accumulators afterwards.  stats must hold P2P_PROFILE_SLOTS entries. */
 int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset);
 
 #ifdef __cplusplus

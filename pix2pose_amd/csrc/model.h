@@ -71,7 +71,7 @@ struct Ctx {
     struct ProfEvent { hipEvent_t a, b; int cfg; double flops; };
     std::vector<ProfEvent> prof_pending;
     std::vector<hipEvent_t> prof_pool;
-    p2p_kernel_stats prof_stats[4] = {};   // per tile configuration; the 256x64 one is folded into slot 1 when read
+    p2p_kernel_stats prof_stats[P2P_PROFILE_SLOTS] = {};   // per kernel family (p2p_mi355.h)
     hipEvent_t prof_get_event();
     int prof_harvest();
     int ensure_workspace();

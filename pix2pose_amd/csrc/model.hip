@@ -122,6 +122,10 @@ static float f16_to_f32(uint16_t h)
     return f;
 }
 
+// Development switch: P2P_NO_HALO=1 routes every layer through the generic kernels (igemm.hip, the VALU first layer);
+// tests/test_halo_gpu.py compares the two paths.
+static bool specialised_kernels() { static const bool on = getenv("P2P_NO_HALO") == nullptr; return on; }
+
 static thread_local int g_pack_prec = PREC_F32;   // precision of the model being packed (build_model)
 // Power-of-two pre-scale of a layer's weights for the split: the largest |w| lands in [2^13, 2^14)
 // (f16 max is 65504), so the lo parts of all but vanishing weights stay in the f16 normal range.
@@ -224,7 +228,7 @@ static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& n
         int rc = fold_bn(T, names[b], cout_each, true, scale, shift);
         if (rc) return rc;
     }
-    if (g_pack_prec == PREC_F16X3 && KH == 7 && L.Cout == 64) {
+    if (g_pack_prec == PREC_F16X3 && KH == 7 && L.Cout == 64 && specialised_kernels()) {
         // matrix-core variant (conv1.hip): split-f16 panel in that kernel's own layout; L.prec marks it
         const float ws = f16x3_weight_scale(w);
         std::vector<float> panel(conv1_f16x3_panel_floats(), 0.f), sc(scale);
@@ -522,11 +526,10 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
         p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng] * rows_per_sample, tile0};
         p.n_groups = ng;
     }
-    const bool halo = heads_halo_supported(p);     // the output heads have their own kernel (heads.hip)
-    static const bool no_halo = getenv("P2P_NO_HALO") != nullptr;
-    const bool halo_conv = !halo && !no_halo && igemm_halo_supported(p);   // stride-1 multi-tap layers (igemm_halo.hip)
+    const bool halo = specialised_kernels() && heads_halo_supported(p);            // the output heads have their own kernel (heads.hip)
+    const bool halo_conv = !halo && specialised_kernels() && igemm_halo_supported(p);   // stride-1 multi-tap layers (igemm_halo.hip)
     if (X.profiling) {
-        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), cfg,
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : (cfg == 3 ? 1 : cfg),
                           2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
         if (!ev.a || !ev.b) return P2P_ERR_HIP;
         HIP_TRY(hipEventRecord(ev.a, st));
@@ -855,11 +858,8 @@ int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset)
     HIP_TRY(hipSetDevice(c->device));
     int rc = c->prof_harvest();
     if (rc) return rc;
-    for (int i = 0; i < 3; ++i) stats[i] = c->prof_stats[i];
-    stats[1].launches += c->prof_stats[3].launches;          // 256x64 tiles are reported with the 128x64 ones
-    stats[1].total_ms += c->prof_stats[3].total_ms;
-    stats[1].algo_flops += c->prof_stats[3].algo_flops;
-    if (reset) for (int i = 0; i < 4; ++i) c->prof_stats[i] = p2p_kernel_stats{};
+    for (int i = 0; i < P2P_PROFILE_SLOTS; ++i) stats[i] = c->prof_stats[i];
+    if (reset) for (int i = 0; i < P2P_PROFILE_SLOTS; ++i) c->prof_stats[i] = p2p_kernel_stats{};
     return P2P_OK;
 }
 

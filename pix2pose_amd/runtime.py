@@ -34,8 +34,8 @@ class Context:
         _lib.check(_lib.lib().p2p_profile_enable(self._h, 1 if on else 0), "p2p_profile_enable")
 
     def profile_read(self, reset=True):
-        """-> list of 3 dicts (tile configs 128x128, 128x64, 128x32): launches, total_ms, algo_flops."""
-        st = (_lib.KernelStats * 3)()
+        """-> list of PROFILE_SLOTS dicts (kernel families, see PROFILE_KERNELS): launches, total_ms, algo_flops."""
+        st = (_lib.KernelStats * _lib.PROFILE_SLOTS)()
         _lib.check(_lib.lib().p2p_profile_read(self._h, st, 1 if reset else 0), "p2p_profile_read")
         return [{"launches": int(s.launches), "total_ms": float(s.total_ms), "algo_flops": float(s.algo_flops)} for s in st]
 

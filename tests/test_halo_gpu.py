@@ -1,0 +1,57 @@
+"""The specialised F16X3 kernels (halo-tiled igemm, heads, first layer) against the generic implicit-GEMM
+path they replace: same layers, same split-f16 arithmetic, different tiling and summation order, so the
+network outputs agree to fp32 summation noise.  The generic path is selected per process with
+P2P_NO_HALO=1 (a development switch read once by the library), hence the subprocesses."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from pix2pose_amd import weights as W
+from pix2pose_amd.runtime import Generator
+backbone, precision, out = sys.argv[1], sys.argv[2], sys.argv[3]
+x = (np.random.RandomState(11).randint(0, 256, (5, 128, 128, 3)).astype(np.float32) - 128) / 128
+x[3] *= 40.0            # activations far outside [-1, 1]
+g = Generator(W.synthetic_weights(backbone, 4), backbone, precision=precision)
+dec, prob = g.predict(x)
+np.savez(out, dec=dec, prob=prob)
+""" % ROOT
+
+
+def _run(tmp_path, backbone, precision, tag, env_extra):
+    out = str(tmp_path / ("%s_%s_%s.npz" % (backbone, precision, tag)))
+    env = dict(os.environ)
+    env.update(env_extra)
+    subprocess.run([sys.executable, "-c", _SCRIPT, backbone, precision, out], check=True, env=env, cwd=ROOT, timeout=600)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("backbone", ["resnet50", "paper"])
+def test_specialised_kernels_match_generic_path(tmp_path, backbone):
+    a = _run(tmp_path, backbone, "f16x3", "halo", {})
+    b = _run(tmp_path, backbone, "f16x3", "generic", {"P2P_NO_HALO": "1"})
+    assert np.isfinite(a["dec"]).all() and np.isfinite(a["prob"]).all()
+    big = 3                                     # the x40 sample: every pre-activation, and so every rounding difference, is 40x larger
+    rest = [0, 1, 2, 4]
+    assert np.abs(a["dec"][rest] - b["dec"][rest]).max() < 5e-5
+    assert np.abs(a["prob"][rest] - b["prob"][rest]).max() < 5e-5
+    assert np.abs(a["dec"][big] - b["dec"][big]).max() < 40 * 5e-5
+    assert np.abs(a["prob"][big] - b["prob"][big]).max() < 40 * 5e-5
+
+
+def test_specialised_kernels_track_fp32_mode(tmp_path):
+    a = _run(tmp_path, "resnet50", "f16x3", "halo", {})
+    c = _run(tmp_path, "resnet50", "f32", "f32", {})
+    rest = [0, 1, 2, 4]
+    assert np.abs(a["dec"][rest] - c["dec"][rest]).max() < 1e-4
+    assert np.abs(a["prob"][rest] - c["prob"][rest]).max() < 1e-4
+    assert np.abs(a["dec"][3] - c["dec"][3]).max() < 40 * 1e-4
