@@ -207,13 +207,14 @@ def main():
     }
     # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes of this same
     # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py), committed under profiles/
-    tfn = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfn):
-        tr = json.load(open(tfn))
+    import glob
+    tfns = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if tfns:
+        tr = json.load(open(tfns[-1]))
         for k, v in tr.items():
             if dom_name in k:
                 out["roofline"]["traffic"] = v["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 PMC (FETCH_SIZE*2 + WRITE_SIZE), profiles/r01_traffic.json"
+                out["roofline"]["traffic_note"] = ("bytes/launch, rocprofv3 PMC (FETCH_SIZE*2 + WRITE_SIZE), profiles/%s" % os.path.basename(tfns[-1]))
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.backbone, wts, args.cpu_sample)
     elif rank == 0:

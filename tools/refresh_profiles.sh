@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --stats -d $G/prof_final -o bench -- python $GRAFT_REPO
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $G/pmc_fetch2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $G/pmc_write2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
+python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/'"$R"'_traffic.json > /dev/null   # bench.py reads it
 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --objects 30 --cpu-sample 0 > gpurun_out/bench_objects30.json 2>> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --precision f32 --cpu-sample 0 > gpurun_out/bench_f32.json 2>> gpurun_out/bench_final.err
