@@ -252,6 +252,34 @@ static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& n
     return finish_layer(L, w, scale, shift);
 }
 
+// Projection-shortcut block tail as ONE 1x1 convolution over the channel concatenation [t (f1) || x (cin)]:
+//   relu(BN2c(W2c t) + BN1(W1 x)) = relu([s2c W2c | s1 W1] [t ; x] + (shift2c + shift1))
+// (resnet50_mod.py:81-91: conv 2c + BN, shortcut conv + BN, add, relu).  Saves writing the shortcut
+// tensor and reading it back as a residual.  Only for stride-1 shortcuts (both inputs on one grid).
+static int pack_merged_shortcut(const TensorMap& T, const std::string& n, int f1, int cin, int f3, ConvLayer& L)
+{
+    const float* k2 = T.get(n + "_2c.kernel", (int64_t)f1 * f3);
+    const float* k1 = T.get(n + "_1.kernel", (int64_t)cin * f3);
+    if (!k2 || !k1) return P2P_ERR_WEIGHTS;
+    std::vector<float> s2, h2, s1, h1;
+    int rc;
+    if ((rc = fold_bn(T, n + "_2c", f3, true, s2, h2))) return rc;
+    if ((rc = fold_bn(T, n + "_1", f3, true, s1, h1))) return rc;
+    L.prec = g_pack_prec;
+    L.Cout = f3;
+    L.ntaps = 1;
+    L.K = f1 + cin;
+    L.dy[0] = L.dx[0] = 0;
+    if (f1 % IGEMM_BK || cin % IGEMM_BK) { set_error("pack_merged_shortcut(%s): unsupported shape", n.c_str()); return P2P_ERR_INVALID_ARG; }
+    std::vector<float> w((size_t)round_up(f3, 128) * L.K, 0.f), scale(f3, 1.f), shift(f3);
+    for (int co = 0; co < f3; ++co) {
+        for (int k = 0; k < f1; ++k) w[(size_t)co * L.K + k] = (float)((double)s2[co] * (double)k2[(size_t)k * f3 + co]);
+        for (int k = 0; k < cin; ++k) w[(size_t)co * L.K + f1 + k] = (float)((double)s1[co] * (double)k1[(size_t)k * f3 + co]);
+        shift[co] = h2[co] + h1[co];
+    }
+    return finish_layer(L, w, scale, shift);
+}
+
 // Conv2DTranspose 5x5 stride 2 'SAME' (kernel (kh,kw,Cout,Cin)); y[o] = sum x[i] w[k] with
 // o = 2i + k - 1.  Output phase (py,px): o = 2m+p uses k = p+1-2d at i = m+d,
 //   p=0: (d,k) in {(0,1), (-1,3)};  p=1: (d,k) in {(+1,0), (0,2), (-1,4)}   (SURVEY 8a-N5).
@@ -385,6 +413,10 @@ static int build_model(const TensorMap& T, Model& M)
             const std::string n = b.n;
             if ((rc = pack_conv(T, {n + "_2a"}, 1, b.cin, b.f1, 0, true, M.L[n + "_2a"]))) return rc;
             if ((rc = pack_conv(T, {n + "_2b"}, 3, b.f1, b.f1, 1, true, M.L[n + "_2b"]))) return rc;
+            if (b.sc && n == "res2a") {          // stride-1 projection shortcut: folded into the last convolution
+                if ((rc = pack_merged_shortcut(T, n, b.f1, b.cin, b.f3, M.L[n + "_2c1"]))) return rc;
+                continue;
+            }
             if ((rc = pack_conv(T, {n + "_2c"}, 1, b.f1, b.f3, 0, true, M.L[n + "_2c"]))) return rc;
             if (b.sc && (rc = pack_conv(T, {n + "_1"}, 1, b.cin, b.f3, 0, true, M.L[n + "_1"]))) return rc;
         }
@@ -595,6 +627,17 @@ static int res_block(const Model& M, Ctx& X, const std::string& n, const float* 
     if ((rc = conv_layer(X, M.L.at(n + "_2a"), in, N, H, H, Cin, stride, ta, ACT_RELU))) return rc;
     if ((rc = conv_layer(X, M.L.at(n + "_2b"), ta, N, Ho, Ho, f1, 1, tb, ACT_RELU))) return rc;
     const float* res = in;
+    if (shortcut && stride == 1 && M.L.count(n + "_2c1")) {
+        // projection shortcut folded into the block's last convolution (pack_merged_shortcut)
+        const ConvLayer& L = M.L.at(n + "_2c1");
+        ConvCall c;
+        c.s0 = {tb, f1, f1, 0};
+        c.s1 = {in, Cin, Cin, 0};
+        c.N = N; c.Hin = c.Win = c.Hg = c.Wg = Ho;
+        c.out = out; c.Hout = c.Wout = Ho; c.out_cstride = L.Cout;
+        c.act = ACT_RELU;
+        return run_conv(X, L, c);
+    }
     if (shortcut) {
         if ((rc = conv_layer(X, M.L.at(n + "_1"), in, N, H, H, Cin, stride, X.cur->act["sc"], ACT_NONE))) return rc;
         res = X.cur->act["sc"];

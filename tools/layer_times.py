@@ -4,7 +4,7 @@ import sqlite3
 import sys
 
 LAYERS = [  # (name, MMAC per sample) in launch order for the resnet50 backbone
-    ("conv1", 38.5), ("maxpool", 0), ("res2a_2a", 4.2), ("res2a_2b", 37.7), ("res2a_1", 16.8), ("res2a_2c", 16.8),
+    ("conv1", 38.5), ("maxpool", 0), ("res2a_2a", 4.2), ("res2a_2b", 37.7), ("res2a_2c+1", 33.6),
     ("res2b_2a", 16.8), ("res2b_2b", 37.7), ("res2b_2c", 16.8), ("res2c_2a", 16.8), ("res2c_2b", 37.7), ("res2c_2c", 16.8),
     ("res3a_2a", 8.4), ("res3a_2b", 37.7), ("res3a_1", 33.6), ("res3a_2c", 16.8),
     ("res3b_2a", 16.8), ("res3b_2b", 37.7), ("res3b_2c", 16.8), ("res3c_2a", 16.8), ("res3c_2b", 37.7), ("res3c_2c", 16.8),
