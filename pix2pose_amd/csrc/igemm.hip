@@ -304,40 +304,56 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
         }
         __syncthreads();
         if (cok) {
+            constexpr int NIT = PROWS / RPP;
+            if (p.ksplit > 1) {
 #pragma unroll 2
-            for (int r = r0; r < PROWS; r += RPP) {
-                const int row = h * PROWS + r;
-                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
-                if (p.ksplit > 1) {
-                    const int m = m0 + row;
-                    if (m < m_end) *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.y * p.M + m) * p.Cout + col) = v;
-                    continue;
+                for (int it = 0; it < NIT; ++it) {
+                    const int r = r0 + it * RPP;
+                    const int m = m0 + h * PROWS + r;
+                    if (m < m_end)
+                        *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.y * p.M + m) * p.Cout + col) = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
                 }
-                const int op = row_out[row];
-                if (op < 0) continue;
+            } else {
+                // all residual loads of the pass are issued before the first store: the 1x1 residual layers are
+                // HBM-bound and a load -> add -> store chain per row left only two loads in flight per thread
+                int ops[NIT];
+                f32x4 rs[NIT];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-                if (p.mode == EPI_HEAD) {
-                    // col = phase*4 + ch: this thread holds (x, y, z, prob) of output pixel (2gy+py, 2gx+px)
-                    const int ph = col >> 2;
-                    f32x4 o;
-                    o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
-                    o[3] = 1.f / (1.f + __expf(-v[3]));
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)(op + (ph >> 1) * p.Wout + (ph & 1)) * 4) = o;
-                } else {
-                    if (p.residual) {
-                        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)op * p.res_cstride + col);
+                for (int it = 0; it < NIT; ++it) {
+                    ops[it] = row_out[h * PROWS + r0 + it * RPP];
+                    rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (p.residual) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rs[e];
+                    for (int it = 0; it < NIT; ++it)
+                        if (ops[it] >= 0) rs[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ops[it] * p.res_cstride + col);
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int op = ops[it];
+                    if (op < 0) continue;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + it * RPP) * CLD + c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                    if (p.mode == EPI_HEAD) {
+                        // col = phase*4 + ch: this thread holds (x, y, z, prob) of output pixel (2gy+py, 2gx+px)
+                        const int ph = col >> 2;
+                        f32x4 o;
+                        o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
+                        o[3] = 1.f / (1.f + __expf(-v[3]));
+                        *reinterpret_cast<f32x4*>(p.out + (size_t)(op + (ph >> 1) * p.Wout + (ph & 1)) * 4) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rs[it][e];
+                        if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
                     }
-                    if (p.act == ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (p.act == ACT_LEAKY) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
-                    }
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
                 }
             }
         }

@@ -238,19 +238,25 @@ __global__ __launch_bounds__(256, 3) void igemm_halo_kernel(const IgemmParams p)
         }
         __syncthreads();
         if (cok) {
-#pragma unroll 2
-            for (int r = r0; r < 64; r += RPP) {
-                const int row = h * 64 + r;
+            constexpr int NIT = 64 / RPP;
+            int ops[NIT];
+            f32x4 rs[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = h * 64 + r0 + it * RPP;
                 const int gy = ty0 + (row >> 4), gx = tx0 + (row & 15);
-                const int op = (n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox;
-                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+                ops[it] = (n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox;
+                rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.residual) {          // all residual loads before the first store
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-                if (p.residual) {
-                    const f32x4 rs = *reinterpret_cast<const f32x4*>(p.residual + (size_t)op * p.res_cstride + col);
+                for (int it = 0; it < NIT; ++it) rs[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ops[it] * p.res_cstride + col);
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rs[e];
-                }
+            for (int it = 0; it < NIT; ++it) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + it * RPP) * CLD + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]) + rs[it][e];
                 if (p.act == ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo_kernel(const IgemmParams p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
                 }
-                *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
+                *reinterpret_cast<f32x4*>(p.out + (size_t)ops[it] * p.out_cstride + p.out_coff + col) = v;
             }
         }
         if (h == 0) __syncthreads();
