@@ -748,15 +748,28 @@ __device__ __forceinline__ bool is_inlier(const double* R, const double* t, cons
 
 constexpr int MAX_ITERS = 128;
 
+// State handed from the scoring kernel to the refit kernels (one record per problem).
+struct PnpFit {
+    double cws[12];      // control points of the inlier set
+    double ci[9];        // inverse of the control-point basis
+    double g[56];        // Gram sums (see pass B)
+    double a_first[4];   // barycentric coordinates of the first inlier (sign disambiguation)
+    double cand[36];     // three (R, t) candidates from the refit solve
+    int best, max_good, iters, state;   // state: 0 = refit pending, 1 = result already final, 2 = needs the lazy second hypothesis batch
+};
+
 // Kernel 1 of 2 -- hypotheses.  One workgroup (128 lanes) per problem: lane 0 replays the sampler,
 // then one lane per minimal set solves the 5-point EPnP and stores the model (R from rvec, t) to
 // `hyp`.  A separate kernel because the register footprint of the inlined fp64 solver (it takes the
 // whole 512-entry file) must not be imposed on the scoring / refit phases, and so that the models of
 // ALL problems are solved in one resident round.
-__global__ __launch_bounds__(128, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
-                                                             int iterations, int min_points)
+constexpr int HYP_BATCH = 64;   // hypotheses per launch: RANSAC's adaptive bound stops long before 100 on good data (mean ~12 here),
+                                // so [0, 64) are solved first and [64, iterations) only for problems whose scoring ran past 63
+__global__ __launch_bounds__(64, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
+                                                            const PnpFit* __restrict__ fits, int iterations, int min_points, int h_begin)
 {
     __shared__ int s_idx[MAX_ITERS][5];
+    if (h_begin > 0 && fits[blockIdx.x].state != 2) return;
     const PnpProblem pb = probs[blockIdx.x];
     const int tid = threadIdx.x;
     const int n = pb.n;
@@ -771,12 +784,14 @@ __global__ __launch_bounds__(128, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
 
     // ---- 1. replay the sampler
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
+    const int h_end = min(n_hyp, h_begin + HYP_BATCH);
+    if (h_begin >= h_end) return;
     if (tid == 0) {
         if (n == 5) {
             for (int i = 0; i < 5; i++) s_idx[0][i] = i;
         } else {
             Rng rng(~0ULL);
-            for (int it = 0; it < n_hyp; it++)
+            for (int it = 0; it < h_end; it++)       // the generator state of sample `it` depends on all earlier samples
                 for (int i = 0; i < 5;) {
                     int idx_i, j;
                     for (;;) {
@@ -792,10 +807,11 @@ __global__ __launch_bounds__(128, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
 
     // ---- 2. hypotheses: one lane each
     const double ifx = 1. / pb.K[0], ify = 1. / pb.K[4];
-    if (tid < n_hyp) {
+    const int hi = h_begin + tid;
+    if (hi < h_end) {
         double pws[15], us[10];
         for (int i = 0; i < 5; i++) {
-            const int id = s_idx[tid][i];
+            const int id = s_idx[hi][i];
             pws[3 * i] = PX[id]; pws[3 * i + 1] = PY[id]; pws[3 * i + 2] = PZ[id];
             // undistortPoints (identity distortion) stores float32 normalised coordinates; epnp re-applies fu, uc
             const double xn = (double)(float)(((double)PU[id] - pb.K[2]) * ifx);
@@ -807,30 +823,21 @@ __global__ __launch_bounds__(128, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
         epnp5(cam, pws, us, R, t);
         rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
         rodrigues_v2r(rvec, R);
-        double* h = hyp + ((size_t)blockIdx.x * MAX_ITERS + tid) * 12;
+        double* h = hyp + ((size_t)blockIdx.x * MAX_ITERS + hi) * 12;
         for (int k = 0; k < 9; k++) h[k] = R[k];
         for (int k = 0; k < 3; k++) h[9 + k] = t[k];
     }
 }
-
-// State handed from the scoring kernel to the refit kernels (one record per problem).
-struct PnpFit {
-    double cws[12];      // control points of the inlier set
-    double ci[9];        // inverse of the control-point basis
-    double g[56];        // Gram sums (see pass B)
-    double a_first[4];   // barycentric coordinates of the first inlier (sign disambiguation)
-    double cand[36];     // three (R, t) candidates from the refit solve
-    int best, max_good, iters, state;   // state: 0 = refit pending, 1 = result already final
-};
 
 // Kernel 2 of 4 -- scoring in OpenCV's order with the adaptive bound, then the two reduction passes
 // of the EPnP refit over the inliers of the winning hypothesis (centroid/covariance -> control
 // points; Gram sums).  One workgroup (256 threads) per problem.
 __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
                                                               PnpResult* __restrict__ results, PnpFit* __restrict__ fits, int iterations,
-                                                              double reproj_err, double confidence, int min_points)
+                                                              double reproj_err, double confidence, int min_points, int pass)
 {
     PnpFit& fit = fits[blockIdx.x];
+    if (pass == 2 && fit.state != 2) return;     // second pass: only problems whose first pass ran out of hypotheses
     __shared__ double s_R[MAX_ITERS][9];
     __shared__ double s_t[MAX_ITERS][3];
     __shared__ double s_red[4 * 56];
@@ -860,7 +867,8 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
         return;
     }
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
-    for (int i = tid; i < n_hyp * 12; i += 256) {
+    const int n_avail = pass == 1 ? min(n_hyp, HYP_BATCH) : n_hyp;     // hypotheses solved so far
+    for (int i = tid; i < n_avail * 12; i += 256) {
         const int h = i / 12, k = i - h * 12;
         const double v = hyp[((size_t)blockIdx.x * MAX_ITERS + h) * 12 + k];
         if (k < 9) s_R[h][k] = v; else s_t[h][k - 9] = v;
@@ -876,6 +884,10 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     } else {
         for (int it = 0;; ++it) {
             if (it >= s_ctl[0]) break;           // uniform: s_ctl[0] is read after the barrier below
+            if (it >= n_avail) {                 // (pass 1 only) the bound still asks for more: solve the rest, score again from 0
+                if (tid == 0) fit.state = 2;
+                return;
+            }
             double R[9], t[3];
             for (int k = 0; k < 9; k++) R[k] = s_R[it][k];
             for (int k = 0; k < 3; k++) t[k] = s_t[it][k];
@@ -1142,13 +1154,22 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
                              double reproj_err, double confidence, int min_points, double* workspace, hipStream_t s)
 {
     if (n_problems <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(n_problems), dim3(128), 0, s, probs, workspace, iterations, min_points);
+    pnp::PnpFit* fits = reinterpret_cast<pnp::PnpFit*>(workspace + (size_t)n_problems * pnp::MAX_ITERS * 12);
+    hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(n_problems), dim3(64), 0, s, probs, workspace, fits, iterations, min_points, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    pnp::PnpFit* fits = reinterpret_cast<pnp::PnpFit*>(workspace + (size_t)n_problems * pnp::MAX_ITERS * 12);
     hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
-                       reproj_err, confidence, min_points);
+                       reproj_err, confidence, min_points, 1);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (iterations > pnp::HYP_BATCH) {
+        // lazy tail: problems flagged by pass 1 get hypotheses [64, iterations) and are scored again in full;
+        // everything else leaves these two launches at once
+        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(n_problems), dim3(64), 0, s, probs, workspace, fits, iterations, min_points, pnp::HYP_BATCH);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
+                           reproj_err, confidence, min_points, 2);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);
