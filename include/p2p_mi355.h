@@ -218,7 +218,7 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): when enabled, every launch of a convolution kernel of the generator is
  * bracketed by HIP events on the stream it is launched on; stats are per kernel family:
- *   0  igemm_kernel 128x128 tiles     1  igemm_kernel 128x64 / 256x64 tiles     2  igemm_kernel 128x32 tiles
+ *   0  igemm_kernel 128x128 tiles     1  igemm_kernel 128x64 tiles     2  igemm_kernel 128x32 tiles
  *   3  igemm_halo_kernel<2> (halo-tiled stride-1 multi-tap layers, 128x128 tiles)     4  igemm_halo_kernel<1> (128x64 tiles)
  *   5  heads_halo_kernel (merged output heads)
  * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md

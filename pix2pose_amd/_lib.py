@@ -59,7 +59,7 @@ class EstPoseOpts(C.Structure):
 PROFILE_SLOTS = 6      # P2P_PROFILE_SLOTS
 # kernel family of each slot: (label, substring of the rocprofv3 kernel name; %d = precision template argument)
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
-                   ("igemm_kernel 128x64 / 256x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
+                   ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
                    ("igemm_kernel 128x32 tiles", "igemm_kernel<4, 1, 1, 1, %d>"),
                    ("igemm_halo_kernel 128x128 tiles (halo-tiled stride-1 multi-tap layers)", "igemm_halo_kernel<2>"),
                    ("igemm_halo_kernel 128x64 tiles", "igemm_halo_kernel<1>"),

@@ -372,7 +372,7 @@ static hipError_t launch_cfg(const IgemmParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-int igemm_tile_m(int cfg) { return cfg >= 3 ? 256 : 128; }
+int igemm_tile_m(int) { return 128; }
 
 hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s)
 {
@@ -380,7 +380,6 @@ hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s)
     case 0: return p.prec == PREC_F16X3 ? launch_cfg<2, 2, 2, 2, PREC_F16X3>(p, s) : launch_cfg<2, 2, 2, 2, PREC_F32>(p, s);   // 128 x 128
     case 1: return p.prec == PREC_F16X3 ? launch_cfg<2, 2, 2, 1, PREC_F16X3>(p, s) : launch_cfg<2, 2, 2, 1, PREC_F32>(p, s);   // 128 x 64
     case 2: return p.prec == PREC_F16X3 ? launch_cfg<4, 1, 1, 1, PREC_F16X3>(p, s) : launch_cfg<4, 1, 1, 1, PREC_F32>(p, s);   // 128 x 32
-    case 3: return p.prec == PREC_F16X3 ? launch_cfg<4, 1, 2, 2, PREC_F16X3>(p, s) : launch_cfg<4, 1, 2, 2, PREC_F32>(p, s);   // 256 x 64
     default: return hipErrorInvalidValue;
     }
 }

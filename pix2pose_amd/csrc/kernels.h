@@ -70,7 +70,7 @@ struct IgemmParams {
     IgemmGroup grp[IGEMM_MAX_GROUPS + 1];
 };
 
-// tile configurations (BM x BN): 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x64
+// tile configurations (BM x BN): 0 = 128x128, 1 = 128x64, 2 = 128x32
 hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s);
 int igemm_tile_m(int cfg);   // BM of a tile configuration
 

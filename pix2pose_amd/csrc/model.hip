@@ -540,10 +540,7 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     p.out_cstride = c.out_cstride; p.out_coff = c.out_coff;
     p.mode = c.mode;
     p.prec = L.prec;
-    // Cout = 64 layers: a 256x64 tile keeps the 2x2 register tiling per wave (same MFMA : LDS ratio as
-    // 128x128) when there are enough rows to fill the chip with it; else 128x64
-    const int m_rows = c.N * c.Hg * c.Wg;
-    const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? (m_rows >= 256 * 1024 ? 3 : 1) : 2);
+    const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? 1 : 2);      // 128x128 / 128x64 / 128x32 tiles
     if (X.grp && X.grp->models.size() > 1) {
         const GroupCtx& G = *X.grp;
         const int ng = (int)G.models.size(), BM = igemm_tile_m(cfg), rows_per_sample = c.Hg * c.Wg;
@@ -561,7 +558,7 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     const bool halo = specialised_kernels() && heads_halo_supported(p);            // the output heads have their own kernel (heads.hip)
     const bool halo_conv = !halo && specialised_kernels() && igemm_halo_supported(p);   // stride-1 multi-tap layers (igemm_halo.hip)
     if (X.profiling) {
-        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : (cfg == 3 ? 1 : cfg),
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : cfg,
                           2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
         if (!ev.a || !ev.b) return P2P_ERR_HIP;
         HIP_TRY(hipEventRecord(ev.a, st));
