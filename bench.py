@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="detections per GPU per step")
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--chunk", type=int, default=1024, help="generator inputs per pass (activation workspace: 13 MB per input; 1024 holds the 768 stage-2 inputs of a 256-detection batch in one pass)")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="detections in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="detections in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-inject", action="store_true", help="let PnP consume the random-weight generator output")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="generator arithmetic: fp32 emulated with 3 split-f16 MFMAs (default) or fp32 MFMA")
