@@ -33,8 +33,7 @@ constexpr int C1_W_BYTES = C1_KH * 2 * 4 * C1_COUT * 16;         // [kh][hi,lo][
 constexpr int C1_TILES_PER_WG = 8;                               // 16 output rows per workgroup
 constexpr int C1_PASSES = (C1_ROWS_IN * C1_HIN + 255) / 256;     // pixel loads per thread per tile (5)
 
-__global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __restrict__ x, int N, const float* __restrict__ w_alt,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+__global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __restrict__ x, int N, const Conv1Groups G,
                                                              int act, float alpha, float* __restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) char smem[C1_W_BYTES + 2 * C1_PLANE];
@@ -45,6 +44,11 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
     const int wgs_per_img = C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG);
     const int n = blockIdx.x / wgs_per_img;
     const int oy_base = (blockIdx.x - n * wgs_per_img) * C1_ROWS_OUT * C1_TILES_PER_WG;
+    int g = 0;                                  // object of this sample (mixed batches: groups are runs of samples)
+    while (g + 1 < G.n_groups && G.start[g + 1] <= n) ++g;
+    const float* __restrict__ w_alt = G.w[g];
+    const float* __restrict__ scale = G.scale[g];
+    const float* __restrict__ shift = G.shift[g];
 
     // weights -> LDS (linear copy), zero the staging planes once (the padding pixels stay zero)
     for (int i = tid; i < C1_W_BYTES / 16; i += 256)
@@ -158,13 +162,13 @@ size_t conv1_f16x3_panel_index(int kh, int plane, int kw, int c, int cout)
     return ((((size_t)kh * 2 + plane) * 4 + (kk >> 3)) * C1_COUT + cout) * 8 + (kk & 7);
 }
 
-hipError_t launch_conv1_f16x3(const float* x, int N, const float* w_alt, const float* scale, const float* shift, int act,
-                              float alpha, float* out, hipStream_t s)
+hipError_t launch_conv1_f16x3(const float* x, int N, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s)
 {
     if (N <= 0) return hipSuccess;
+    if (G.n_groups < 1 || G.n_groups > IGEMM_MAX_GROUPS) return hipErrorInvalidValue;
     if ((size_t)N * C1_HIN * C1_HIN * 12 >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG));
-    hipLaunchKernelGGL(conv1_f16x3_kernel, dim3(wgs), dim3(256), 0, s, x, N, w_alt, scale, shift, act, alpha, out);
+    hipLaunchKernelGGL(conv1_f16x3_kernel, dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out);
     return hipGetLastError();
 }
 

@@ -103,8 +103,15 @@ hipError_t launch_conv_first(const float* x, int N, int H, int W, const float* w
 // at half index conv1_f16x3_panel_index().
 size_t conv1_f16x3_panel_floats();
 size_t conv1_f16x3_panel_index(int kh, int plane, int kw, int c, int cout);
-hipError_t launch_conv1_f16x3(const float* x, int N, const float* w_alt, const float* scale, const float* shift, int act,
-                              float alpha, float* out, hipStream_t s);
+// Mixed-object batches: samples [start[g], start[g+1]) use panel g (one launch for the whole batch).
+struct Conv1Groups {
+    int n_groups;
+    int start[IGEMM_MAX_GROUPS + 1];
+    const float* w[IGEMM_MAX_GROUPS];
+    const float* scale[IGEMM_MAX_GROUPS];
+    const float* shift[IGEMM_MAX_GROUPS];
+};
+hipError_t launch_conv1_f16x3(const float* x, int N, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s);
 
 // MaxPooling2D 3x3 stride 2, TF 'SAME' (pad 0 before / 1 after), NHWC, C % 4 == 0.
 hipError_t launch_maxpool3s2(const float* x, int N, int H, int W, int C, float* out, hipStream_t s);

@@ -654,14 +654,22 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
     const float *s1, *s2, *s3;      // skip tensors and their pixel strides / channel offsets
     int s1_stride, s1_off, s1_C, s2_stride, s2_off, s3_stride, s3_off;
     if (M.backbone == P2P_BACKBONE_RESNET50) {
-        for (int g = 0; g < n_grp; ++g) {      // first layer: one launch per object (tiny)
+        if (M.L.at("conv1").prec == PREC_F16X3) {       // matrix-core first layer: one launch, per-sample panel lookup
+            if (n_grp > IGEMM_MAX_GROUPS) { set_error("forward: %d object groups exceed IGEMM_MAX_GROUPS", n_grp); return P2P_ERR_CAPACITY; }
+            Conv1Groups G;
+            G.n_groups = n_grp;
+            for (int g = 0; g < n_grp; ++g) {
+                const ConvLayer& c1 = grp_model(g).L.at("conv1");
+                if (c1.prec != PREC_F16X3) { set_error("forward: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
+                G.start[g] = g0(g); G.w[g] = c1.w; G.scale[g] = c1.scale; G.shift[g] = c1.shift;
+            }
+            G.start[n_grp] = n;
+            HIP_TRY(launch_conv1_f16x3(x, n, G, ACT_RELU, LEAKY, A["f1"], st));
+        } else
+        for (int g = 0; g < n_grp; ++g) {      // VALU first layer: one launch per object (tiny)
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
-            if (c1.prec == PREC_F16X3)
-                HIP_TRY(launch_conv1_f16x3(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), c1.w, c1.scale, c1.shift, ACT_RELU, LEAKY,
-                                           A["f1"] + (size_t)g0(g) * 64 * 64 * 64, st));
-            else
-                HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift,
-                                          ACT_RELU, LEAKY, A["f1"] + (size_t)g0(g) * 64 * 64 * 64, 64, 64, st));
+            HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift,
+                                      ACT_RELU, LEAKY, A["f1"] + (size_t)g0(g) * 64 * 64 * 64, 64, 64, st));
         }
         HIP_TRY(launch_maxpool3s2(A["f1"], n, 64, 64, 64, A["p1"], st));
         if ((rc = res_block(M, X, "res2a", A["p1"], n, 32, 64, 64, 1, true, A["o_a"]))) return rc;

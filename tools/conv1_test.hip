@@ -32,7 +32,8 @@ int main()
     hipMemcpy(dsc, sc.data(), 256, hipMemcpyHostToDevice); hipMemcpy(dsh, sh.data(), 256, hipMemcpyHostToDevice);
     hipMemset(o2, 0xFF, on * 4);
     launch_conv_first(dx, N, 128, 128, dw, 7, 2, 3, 64, dsc, dsh, ACT_NONE, 0.3f, o1, 64, 64, 0);
-    hipError_t e = launch_conv1_f16x3(dx, N, dp, dsc, dsh, ACT_NONE, 0.3f, o2, 0);
+    Conv1Groups G; G.n_groups = 1; G.start[0] = 0; G.start[1] = N; G.w[0] = dp; G.scale[0] = dsc; G.shift[0] = dsh;
+    hipError_t e = launch_conv1_f16x3(dx, N, G, ACT_NONE, 0.3f, o2, 0);
     hipDeviceSynchronize();
     printf("launch: %s / %s\n", hipGetErrorString(e), hipGetErrorString(hipGetLastError()));
     std::vector<float> a(on), b(on);
