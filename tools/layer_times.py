@@ -1,5 +1,6 @@
-"""Per-layer kernel durations of the stage-1 generator pass from a rocprofv3 rocpd database,
-annotated with algorithmic GFLOP and TFLOP/s (development aid)."""
+"""Per-layer kernel durations of the stage-1 generator pass from a rocprofv3 rocpd database, annotated with
+algorithmic GFLOP, TFLOP/s (2 x MACs; against 833 = dense f16 MFMA peak / 3 for the split-f16 arithmetic) and the
+algorithmic activation traffic (input + residual + output tensors once, fp32) as TB/s against ~6.3 achievable / 8 peak."""
 import sqlite3
 import sys
 
@@ -14,6 +15,19 @@ LAYERS = [  # (name, MMAC per sample) in launch order for the resnet50 backbone
     ("up3_p0", 67.1), ("up3_p1", 100.7), ("up3_p2", 100.7), ("up3_p3", 151.0), ("deconv3", 1258.3), ("heads", 52.4)]
 
 
+# algorithmic activation traffic per sample in kilo-floats: tensors a layer must read (input, skip / residual) + write
+KF = {"conv1": 49 + 262, "maxpool": 262 + 66, "res2a_2a": 66 + 66, "res2a_2b": 66 + 66, "res2a_2c+1": 66 + 66 + 262,
+      "res3a_2a": 66 + 33, "res3a_2b": 33 + 33, "res3a_1": 66 + 131, "res3a_2c": 33 + 131 + 131,
+      "conv4": 131 + 33, "dense_enc": 33, "dense_dec": 16, "deconv1": 66 + 33 + 66, "deconv2": 131 + 131 + 262,
+      "deconv3": 262 + 131 + 524, "heads": 524 + 66}
+for _b in ("res2b", "res2c"):
+    KF.update({_b + "_2a": 262 + 66, _b + "_2b": 66 + 66, _b + "_2c": 66 + 262 + 262})
+for _b in ("res3b", "res3c", "res3d"):
+    KF.update({_b + "_2a": 131 + 33, _b + "_2b": 33 + 33, _b + "_2c": 33 + 131 + 131})
+for _p in range(4):
+    KF.update({"up1_p%d" % _p: 16 + 16, "up2_p%d" % _p: 66 + 33, "up3_p%d" % _p: 262 + 66})
+
+
 def main(path, batch=256):
     db = sqlite3.connect(path)
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
@@ -24,7 +38,9 @@ def main(path, batch=256):
         us = (r[2] - r[1]) / 1e3
         tot += us
         gf = 2 * mmac * batch / 1e3
-        print("%-14s %-28s %9.1f us %9.1f GFLOP %7.1f TFLOP/s" % (nm, r[0].replace("void p2p::", "").replace("p2p::", "")[:28], us, gf, gf / us * 1e3 / 1e3 * 1e3 if us else 0))
+        tb = KF.get(nm, 0) * 1e3 * 4 * batch / (us * 1e-6) / 1e12 if us else 0
+        print("%-14s %-28s %9.1f us %9.1f GFLOP %7.1f TFLOP/s %6.2f TB/s" % (nm, r[0].replace("void p2p::", "").replace("p2p::", "").replace("(anonymous namespace)::", "")[:28],
+                                                                         us, gf, gf / us * 1e3 if us else 0, tb))
     print("total %.1f us -> %.0f inputs/s" % (tot, batch / tot * 1e6))
 
 
