@@ -11,9 +11,10 @@ quirks listed in SURVEY.md section 8a-Q.  Third-party pieces are replaced by res
   * ``generator_train.predict``            -> any callable (oracle/ae_oracle.forward, or injected
     decoder outputs for the synthetic PnP scenes)
 
-PARITY UNPINNED: none of keras / cv2 / skimage is installable here and the reference has no
-tests; this file follows the reference source line by line (cited below) and the published
-semantics of those libraries.
+PINNING: tests/golden/reference_est_pose.json holds outputs of the reference's own recognition.py
+(est_pose / get_boxes / pnp_ransac executed unmodified in the build container, tests/golden/
+make_reference_vectors.py) and this file reproduces them bit for bit (tests/test_reference_vectors_cpu.py).
+The three library restatements above stay UNPINNED: none of keras / cv2 / skimage is installable here.
 """
 from __future__ import annotations
 
