@@ -109,6 +109,31 @@ SCENES = [dict(seed=501, n_det=3, bbox_side=(86, 86)),            # 128-px stage
 EXTRA_BOXES = [[100, 100, 102, 103], [-40, -30, 60, 90], [470, 600, 520, 700]]     # < 5 px early exit; frame corners
 
 
+def bop_io_vectors():
+    """tools/bop_io.py get_target_list / get_model_params of the reference (its bop_toolkit imports shimmed:
+    inout.load_json is json.load), for pix2pose_amd.eval_bop.group_targets / model_params_to_obj_param."""
+    import tempfile
+    bt = types.ModuleType("bop_toolkit_lib")
+    bt.inout = types.ModuleType("bop_toolkit_lib.inout")
+    bt.inout.load_json = lambda path: json.load(open(path))
+    bt.renderer = types.ModuleType("bop_toolkit_lib.renderer")
+    sys.modules.update({"bop_toolkit_lib": bt, "bop_toolkit_lib.inout": bt.inout, "bop_toolkit_lib.renderer": bt.renderer})
+    sys.path.insert(0, os.path.join(REF, "tools"))
+    import bop_io as ref_io
+    rs = np.random.RandomState(3)
+    targets = []
+    for scene in (2, 5):
+        for im in sorted(rs.choice(50, 6, replace=False).tolist()):
+            for obj in sorted(rs.choice(30, int(rs.randint(1, 5)), replace=False).tolist()):
+                targets.append({"scene_id": scene, "im_id": int(im), "obj_id": int(obj) + 1, "inst_count": int(rs.randint(1, 4))})
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(targets, f)
+    grouped = ref_io.get_target_list(f.name)
+    os.unlink(f.name)
+    mp = {"x_scale": 37.9, "y_scale": 38.7, "z_scale": 45.8, "x_ct": -0.5, "y_ct": 1.25, "z_ct": -3.0, "diameter": 102.1}
+    return {"targets": targets, "grouped": grouped, "model_param": mp, "obj_param": ref_io.get_model_params(mp).tolist()}
+
+
 def main():
     install_shims()
     sys.path.insert(0, REF)
@@ -166,6 +191,7 @@ def main():
         mw = 9999 if rs.rand() < 0.5 else int(rs.randint(20, 300))
         gb.append({"bbox": b, "ct": ct, "max_w": mw, "out": [int(v) for v in p.get_boxes(np.asarray(b), 480, 640, ct=np.asarray(ct), max_w=mw)]})
     out["get_boxes"] = gb
+    out["bop_io"] = bop_io_vectors()
     fn = os.path.join(HERE, "reference_est_pose.json")
     with open(fn, "w") as f:
         json.dump(out, f)

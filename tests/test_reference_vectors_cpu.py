@@ -77,3 +77,11 @@ def test_degenerate_boxes_match_reference():
         r = O.est_pose(sc["images"][0], c["bbox"], predict, synthetic.LM_K, sc["obj_param"], G["th_outlier"], G["th_inlier"])
         assert (not (isinstance(r[1], (int, np.integer)) and r[1] == -1)) == c["ok"]
         assert [int(v) for v in r[5]] == c["bbox_t"]
+
+
+def test_eval_harness_helpers_match_reference_bop_io():
+    """tools/bop_io.py get_target_list / get_model_params of the reference (row f-1)."""
+    from pix2pose_amd import eval_bop
+    b = G["bop_io"]
+    assert eval_bop.group_targets(b["targets"]) == b["grouped"]
+    assert eval_bop.model_params_to_obj_param(b["model_param"]).tolist() == b["obj_param"]
