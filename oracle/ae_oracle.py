@@ -9,9 +9,12 @@ CPU restatement of the Pix2Pose generator forward pass (what
 
 The graph wiring is here; the arithmetic is in oracle/ae_layers.c (double accumulation).
 
-PARITY UNPINNED: Keras/TensorFlow are not installable here and the reference ships no
-tests or golden vectors; tests pin this file against an independent
-torch-CPU formulation and against micro-fixtures of TF "SAME" conv/deconv semantics.
+PINNING: the graph WIRING is pinned to the reference -- tests/golden/reference_graph.json holds outputs of the
+graphs built by the reference's own ae_model.py / resnet50_mod.py (executed against a stand-in Keras API,
+tests/golden/make_reference_graph_vectors.py) and forward() reproduces them to 1e-6.  The layer SEMANTICS
+(oracle/ae_layers.c: TF "SAME" padding, Conv2DTranspose, BatchNormalization, LeakyReLU defaults) stay UNPINNED:
+Keras/TensorFlow are not installable here and the reference ships no tests; they are
+checked against an independent torch-CPU formulation and micro-fixtures of TF "SAME" conv/deconv semantics.
 """
 from __future__ import annotations
 

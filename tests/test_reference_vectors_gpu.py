@@ -69,3 +69,20 @@ def test_degenerate_boxes_match_reference_vectors():
     for p, c in zip(poses, G["degenerate"]):
         assert (p.status == 0) == c["ok"]
         assert list(p.bbox_t) == c["bbox_t"]
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("backbone", ["paper", "resnet50"])
+def test_generator_matches_reference_builder_vectors(backbone, precision):
+    """HIP generator vs the outputs of the graphs built by the reference's own ae_model.py / resnet50_mod.py
+    (tests/golden/reference_graph.json; weights drawn per Keras layer name and converted with convert_keras)."""
+    from pix2pose_amd import convert_keras
+    from pix2pose_amd.runtime import Generator
+    from tests.test_reference_graph_cpu import G as GG, inputs, keras_weights
+    w = convert_keras.convert_named(keras_weights(backbone), backbone)
+    d, p = Generator(w, backbone, precision=precision).predict(inputs())
+    pr = GG["graphs"][backbone]["probes"]
+    idx = np.array(pr["pixel_index"])
+    assert np.abs(d.reshape(-1, 3)[idx] - np.array(pr["decode"])).max() < 1e-4          # north_star: 1e-3 abs
+    assert np.abs(p.reshape(-1)[idx] - np.array(pr["prob"])).max() < 1e-4
+    assert abs(float(np.abs(d).astype(np.float64).mean()) - pr["decode_abs_mean"]) < 1e-5
