@@ -82,10 +82,12 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// Per-batch buffers that outlive the generator passes (read by PnP / selection): double buffered so
-// that the PnP-RANSAC tail of batch i (second stream) overlaps the generator passes of batch i+1.
+// Per-batch buffers: double buffered.  Asynchronous batches alternate between two generator lanes (stream +
+// activation workspace, Ctx::lane[0/1]) so that the passes of batch i+1 fill the launch tails of batch i, and
+// their PnP-RANSAC tails run on a third stream.
 struct Slot {
     DevBuf det, s1, cand, probs, results, poses, corr, hyp;
+    DevBuf x1, y1, x2, y2, images;      // network inputs / outputs of both stages, uploaded frames
     p2p_pose* host_poses = nullptr;     // pinned
     size_t host_cap = 0;
     std::vector<int> perm;
@@ -96,7 +98,7 @@ struct Slot {
 
 struct Pipeline {
     Slot slot[2];
-    DevBuf x1, y1, x2, y2, images, mask, pred, dmask, mstat;
+    DevBuf mask, pred, dmask, mstat;
     hipStream_t tail_stream = nullptr;  // PnP + selection + D2H of async batches
     hipEvent_t corr_ready = nullptr;
     int next_ticket = 0;

@@ -51,11 +51,11 @@ void DevBuf::release()
 Pipeline::~Pipeline()
 {
     for (Slot& s : slot) {
-        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp}) b->release();
+        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    for (DevBuf* b : {&x1, &y1, &x2, &y2, &images, &mask, &pred, &dmask, &mstat}) b->release();
+    for (DevBuf* b : {&mask, &pred, &dmask, &mstat}) b->release();
     if (corr_ready) (void)hipEventDestroy(corr_ready);
     if (tail_stream) (void)hipStreamDestroy(tail_stream);
 }
@@ -574,11 +574,19 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
                         const p2p_detection* dets, int n, p2p_pose* poses, const p2p_est_pose_opts& opt, int* async_ticket)
 {
     int rc;
-    hipStream_t st = X.stream;
     if (!X.pipe) X.pipe = new Pipeline();
     Pipeline& P = *X.pipe;
     if ((rc = X.ensure_workspace())) return rc;
     const bool async = async_ticket != nullptr;
+    // generator lane of this batch: asynchronous batches alternate between lanes 0 and 1
+    static const bool two_lanes = getenv("P2P_ONE_LANE") == nullptr;
+    bool one_backbone = true;            // (mixed-backbone batches spread over the lanes themselves)
+    for (int o = 1; o < n_obj; ++o)
+        one_backbone = one_backbone && objects[o].model && objects[0].model &&
+                       reinterpret_cast<const Model*>(objects[o].model)->backbone == reinterpret_cast<const Model*>(objects[0].model)->backbone;
+    const int bl = async && two_lanes && one_backbone ? (P.next_ticket & 1) : 0;
+    if (bl && (rc = X.ensure_lane(bl))) return rc;
+    hipStream_t st = X.lane[bl].stream;
     if (!P.tail_stream) {
         HIP_TRY(hipStreamCreate(&P.tail_stream));
         HIP_TRY(hipEventCreateWithFlags(&P.corr_ready, hipEventDisableTiming));
@@ -624,13 +632,13 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
             if (!images[i].data || images[i].height <= 0 || images[i].width <= 0) { set_error("image %d is empty", i); return P2P_ERR_INVALID_ARG; }
             if (images[i].mem == P2P_MEM_HOST) need += ((size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1) + 255) / 256 * 256;
         }
-        if ((rc = P.images.reserve(need))) return rc;
+        if ((rc = SL.images.reserve(need))) return rc;
         size_t off = 0;
         for (int i = 0; i < n_img; ++i) {
             const size_t bytes = (size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1);
             if (images[i].mem == P2P_MEM_HOST) {
-                HIP_TRY(hipMemcpyAsync(P.images.as<char>() + off, images[i].data, bytes, hipMemcpyHostToDevice, st));
-                img_dev[i] = P.images.as<char>() + off;
+                HIP_TRY(hipMemcpyAsync(SL.images.as<char>() + off, images[i].data, bytes, hipMemcpyHostToDevice, st));
+                img_dev[i] = SL.images.as<char>() + off;
                 off += (bytes + 255) / 256 * 256;
             } else
                 img_dev[i] = images[i].data;
@@ -672,16 +680,16 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     if ((rc = SL.results.reserve(sizeof(PnpResult) * n * K))) return rc;
     if ((rc = SL.hyp.reserve(pnp_workspace_bytes(n * K)))) return rc;
     if ((rc = SL.poses.reserve(sizeof(p2p_pose) * n))) return rc;
-    if ((rc = P.x1.reserve(sizeof(float) * 16384 * 3 * (size_t)n))) return rc;
-    if ((rc = P.y1.reserve(sizeof(float) * 16384 * 4 * (size_t)n))) return rc;
-    if ((rc = P.x2.reserve(sizeof(float) * 16384 * 3 * (size_t)n * K))) return rc;
-    if ((rc = P.y2.reserve(sizeof(float) * 16384 * 4 * (size_t)n * K))) return rc;
+    if ((rc = SL.x1.reserve(sizeof(float) * 16384 * 3 * (size_t)n))) return rc;
+    if ((rc = SL.y1.reserve(sizeof(float) * 16384 * 4 * (size_t)n))) return rc;
+    if ((rc = SL.x2.reserve(sizeof(float) * 16384 * 3 * (size_t)n * K))) return rc;
+    if ((rc = SL.y2.reserve(sizeof(float) * 16384 * 4 * (size_t)n * K))) return rc;
     if ((rc = SL.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
     HIP_TRY(hipMemcpyAsync(SL.det.p, hd.data(), sizeof(DetInfo) * n, hipMemcpyHostToDevice, st));
 
     const DetInfo* d_det = SL.det.as<DetInfo>();
     Stage1* d_s1 = SL.s1.as<Stage1>();
-    float *x1 = P.x1.as<float>(), *y1 = P.y1.as<float>(), *x2 = P.x2.as<float>(), *y2 = P.y2.as<float>();
+    float *x1 = SL.x1.as<float>(), *y1 = SL.y1.as<float>(), *x2 = SL.x2.as<float>(), *y2 = SL.y2.as<float>();
 
     // object groups (contiguous in the sorted order)
     struct Group { int obj, begin, end; };
@@ -705,7 +713,10 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
             std::vector<const Model*> ms;
             std::vector<int> cnt;
             for (const Group& g : groups) { ms.push_back(reinterpret_cast<const Model*>(objects[g.obj].model)); cnt.push_back((g.end - g.begin) * per_det); }
-            return forward_grouped(X, ms, cnt, xin, yout);
+            X.cur = &X.lane[bl];
+            const int r = forward_grouped(X, ms, cnt, xin, yout);
+            X.cur = &X.lane[0];
+            return r;
         }
         const int nl = groups.size() > 1 ? std::min<int>((int)groups.size(), Ctx::N_LANES) : 1;
         if (nl > 1) {
@@ -717,7 +728,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         for (size_t gi = 0; gi < groups.size() && !r; ++gi) {
             const Group& g = groups[gi];
             const Model& M = *reinterpret_cast<const Model*>(objects[g.obj].model);
-            X.cur = &X.lane[gi % nl];
+            X.cur = &X.lane[nl > 1 ? gi % nl : bl];
             r = forward_async(X, M, xin + (size_t)g.begin * per_det * 16384 * 3, (g.end - g.begin) * per_det,
                               yout + (size_t)g.begin * per_det * 16384 * 4);
         }
