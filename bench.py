@@ -153,15 +153,36 @@ def main():
 
     if args.warmup:
         run_steps(args.warmup)
-    ctx.profile(True)
-    ctx.profile_read(reset=True)
+    if args.blocking:
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
     poses, rec = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    stats = ctx.profile_read(reset=True)
-    ctx.profile(False)
+    if args.blocking:
+        stats = ctx.profile_read(reset=True)
+        ctx.profile(False)
+        prof_dt, prof_note = dt, "HIP events around every launch of the timed region"
+    else:
+        # Stream mode keeps kernels of two batches on the GPU at once, so a launch's event-to-event time there is not the
+        # kernel's own duration.  The per-kernel figures come from PROF_STEPS extra blocking steps right after the timed region
+        # (same data, same kernels, one batch at a time); `python bench.py --blocking` measures them inside the timed region.
+        PROF_STEPS = 2
+        args.overlap = False
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(PROF_STEPS)
+        torch.cuda.synchronize()
+        prof_dt = time.perf_counter() - t1
+        stats = ctx.profile_read(reset=True)
+        ctx.profile(False)
+        args.overlap = True
+        prof_note = ("HIP events around every launch of %d extra blocking steps after the timed region (in stream mode kernels of two "
+                     "batches overlap, which inflates per-launch times); shares are of those steps' time" % PROF_STEPS)
     if world > 1:
         tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -209,7 +230,7 @@ def main():
                              if args.precision == "f16x3" else "fp32 MFMA",
                      "avg_launch_ms": s0["total_ms"] / max(s0["launches"], 1), "launches": s0["launches"],
                      "algo_gflop_per_launch": s0["algo_flops"] / max(s0["launches"], 1) / 1e9,
-                     "share_of_step_time": s0["total_ms"] * 1e-3 / dt, "all_conv_kernels_share_of_step_time": all_ms * 1e-3 / dt,
+                     "measured_over": prof_note, "share_of_step_time": s0["total_ms"] * 1e-3 / prof_dt, "all_conv_kernels_share_of_step_time": all_ms * 1e-3 / prof_dt,
                      "families": {_lib.PROFILE_KERNELS[i][0]: {"launches": st["launches"], "total_ms": st["total_ms"], "algo_tflops": (st["algo_flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] > 0 else 0.0)} for i, st in enumerate(stats) if st["launches"]},
                      "traffic": None},
     }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ (run from the repo root in the build container).
-#   1. on the GPU box: full GPU test suite, rocprofv3 kernel trace of bench.py, two PMC passes
+#   1. on the GPU box: full GPU test suite, rocprofv3 kernel trace of `bench.py --blocking` (one batch on the GPU at a time,
+#      so kernel durations are the kernels' own; the default stream mode overlaps two batches), two PMC passes
 #      (FETCH_SIZE / WRITE_SIZE separately, MI355X_MICROARCH.md), and a plain bench run
 #   2. here: summarise the rocpd databases into profiles/
 set -e
@@ -10,9 +11,9 @@ python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/gpu_tests.log
 cd /tmp && export TMPDIR=/tmp
 G=$GRAFT_REPO_ROOT/gpurun_out
 rm -rf $G/prof_final $G/pmc_fetch2 $G/pmc_write2
-rocprofv3 --kernel-trace --stats -d $G/prof_final -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $G/bench_final_prof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $G/pmc_fetch2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $G/pmc_write2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $G/prof_final -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --blocking > $G/bench_final_prof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $G/pmc_fetch2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 --blocking > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $G/pmc_write2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 --blocking > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/'"$R"'_traffic.json > /dev/null   # bench.py reads it
 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
