@@ -80,10 +80,12 @@ def main():
                     "mode (p2p_est_pose_submit / collect, two batches in flight: the PnP-RANSAC tail, the D2H copy and the pose gather "
                     "of step i run on a second HIP stream under the generator passes of step i+1; all K steps complete inside the timed region)")
     ap.add_argument("--overlap", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--inflight", type=int, default=2, help="stream mode: batches in flight before the oldest is collected (the library holds 2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="debug: all ranks share cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
     args.overlap = not args.blocking
+    args.inflight = max(1, min(args.inflight, 2))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -138,13 +140,14 @@ def main():
             for _ in range(k):
                 out = finish(est_pose_batch(ctx, specs, images, sc["dets"], **kw)[0])
             return out
-        pending = None
+        pending = []
         for _ in range(k):
-            nxt = est_pose_submit(ctx, specs, images, sc["dets"], **kw)
-            if pending is not None:
-                out = finish(pending.collect())
-            pending = nxt
-        return finish(pending.collect()) if pending is not None else out
+            pending.append(est_pose_submit(ctx, specs, images, sc["dets"], **kw))
+            if len(pending) >= args.inflight:
+                out = finish(pending.pop(0).collect())
+        while pending:
+            out = finish(pending.pop(0).collect())
+        return out
 
     def barrier():
         if world > 1:
@@ -214,7 +217,7 @@ def main():
                                "(1 stage-1 + 3 stage-2 forwards per detection) + 3 EPnP-RANSAC solves per detection, "
                                "outlier_th=[0.2,0.3,0.35], injected ellipsoid-NOCS decoder maps" % (args.batch, args.backbone),
                    "detections_per_gpu": args.batch, "backbone": args.backbone, "precision": args.precision, "parallelism": "dp%d" % world,
-                   "generator_chunk": args.chunk, "objects": args.objects, "mode": "stream (submit/collect, 2 in flight)" if args.overlap else "blocking"},
+                   "generator_chunk": args.chunk, "objects": args.objects, "mode": ("stream (submit/collect, %d in flight)" % args.inflight) if args.overlap else "blocking"},
         "ae_inputs_per_s": 4 * value,
         "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
         "poses_ok": n_ok, "ransac_iters_mean_of_selected": float(np.mean([p.ransac_iters for p in poses])), "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,

@@ -97,7 +97,8 @@ struct Slot {
 };
 
 struct Pipeline {
-    Slot slot[2];
+    static constexpr int N_SLOTS = 2;   // asynchronous batches in flight (each on its own generator lane)
+    Slot slot[N_SLOTS];
     DevBuf mask, pred, dmask, mstat;
     hipStream_t tail_stream = nullptr;  // PnP + selection + D2H of async batches
     hipEvent_t corr_ready = nullptr;

@@ -584,7 +584,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     for (int o = 1; o < n_obj; ++o)
         one_backbone = one_backbone && objects[o].model && objects[0].model &&
                        reinterpret_cast<const Model*>(objects[o].model)->backbone == reinterpret_cast<const Model*>(objects[0].model)->backbone;
-    const int bl = async && two_lanes && one_backbone ? (P.next_ticket & 1) : 0;
+    const int bl = async && two_lanes && one_backbone ? (P.next_ticket % Pipeline::N_SLOTS) : 0;
     if (bl && (rc = X.ensure_lane(bl))) return rc;
     hipStream_t st = X.lane[bl].stream;
     if (!P.tail_stream) {
@@ -592,9 +592,9 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         HIP_TRY(hipEventCreateWithFlags(&P.corr_ready, hipEventDisableTiming));
         for (Slot& s : P.slot) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
-    Slot& SL = P.slot[async ? (P.next_ticket & 1) : 0];
+    Slot& SL = P.slot[async ? (P.next_ticket % Pipeline::N_SLOTS) : 0];
     if (SL.ticket >= 0) {
-        if (async) { set_error("two batches are already in flight: collect ticket %d first", SL.ticket); return P2P_ERR_CAPACITY; }
+        if (async) { set_error("%d batches are already in flight: collect ticket %d first", Pipeline::N_SLOTS, SL.ticket); return P2P_ERR_CAPACITY; }
         set_error("an asynchronous batch (ticket %d) is in flight: collect it before a blocking call", SL.ticket);
         return P2P_ERR_CAPACITY;
     }
