@@ -37,7 +37,9 @@ TH_O, TH_I = [0.2, 0.3, 0.35], 0.2                     # cfg/cfg_bop2020.json:8-
 def cpu_baseline(backbone, weights, n_sample):
     """The oracle (CPU restatement of the reference path) timed on this host's cores, on a bounded
     sample of the same workload: n_sample detections = 4*n_sample generator forwards (C, OpenMP
-    over all cores) + 3*n_sample sequential OpenCV-style PnP-RANSAC solves + the numpy glue."""
+    over all cores) + 3*n_sample sequential OpenCV-style PnP-RANSAC solves + the numpy glue.
+    (The torch-CPU formulation of the network, oracle/ae_torch.py, was tried as the network leg: on the 256-thread host of
+    the GPU box oneDNN at batch 8-24 took 2.5 s per input -- 25x slower than this C/OpenMP restatement -- so it is not used.)"""
     from oracle import ae_oracle, est_pose_oracle
     from pix2pose_amd import synthetic
     sc = synthetic.make_scene(n_sample, seed=12345)
