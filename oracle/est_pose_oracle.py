@@ -104,7 +104,7 @@ class Boxes:
 def get_boxes(bbox, v_max, u_max, box_size=1.5, ct=None, max_w=9999) -> Boxes:
     """Square crop of side 2*int(w/2), w = min(max_w, box_size*max(width,height)), centred on the
     bbox centre (or ``ct``), clipped to the image; plus paste offsets into a zero canvas."""
-    if ct is None:                                           # :29-31
+    if ct is None or ct[0] == -1:                            # :29-31 (the sentinel is ct[0] == -1: a genuine centre row of -1 also lands here)
         ct_v = int((bbox[0] + bbox[2]) / 2)
         ct_u = int((bbox[1] + bbox[3]) / 2)
     else:                                                    # :32-34

@@ -71,7 +71,8 @@ void Ctx::free_pipeline()
 __host__ __device__ inline Boxes get_boxes(const double bbox[4], int v_max, int u_max, double box_size, bool has_ct,
                                            int ct_v, int ct_u, double max_w)
 {
-    if (!has_ct) {
+    if (!has_ct || ct_v == -1) {      // the reference's "no centre given" sentinel is ct[0] == -1 (recognition.py:28-34): a genuine
+                                      // centre row of -1 falls back to the box centre there too
         ct_v = (int)((bbox[0] + bbox[2]) / 2);
         ct_u = (int)((bbox[1] + bbox[3]) / 2);
     }
