@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > CTILE_FLOATS ? STAGE_FLOATS : CTILE_FLOATS];
     __shared__ int row_base[BM];   // n*Hin*Win, or -1 for rows past M
     __shared__ int row_yx[BM];     // (iy0 << 16) | ix0
+    __shared__ int row_pix1[BM];   // pixel index into segment 1 when it lives on its own grid (seg1_stride != 0)
     __shared__ int row_out[BM];    // output pixel index, or -1
     __shared__ int s_tap[IGEMM_MAX_TAPS + 3];   // dy * Win + dx (pixels): read from LDS in the K loop --
                                                 // indexing the kernarg arrays there costs a dependent
@@ -115,6 +116,16 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
         }
         row_base[r] = base;
         row_yx[r] = yx;
+        if (p.seg1_stride) {
+            int px1 = 0;
+            if (m < m_end) {
+                const int n = m / HgWg;
+                const int rem = m - n * HgWg;
+                const int gy = rem / p.Wg;
+                px1 = (n * p.seg1_Hin + gy * p.seg1_stride) * p.seg1_Win + (rem - gy * p.Wg) * p.seg1_stride;
+            }
+            row_pix1[r] = px1;
+        }
         row_out[r] = op;
     }
     __syncthreads();
@@ -136,7 +147,8 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
         const int iy0 = yx >> 16, ix0 = yx & 0xffff;
         const unsigned pix = (unsigned)(base + iy0 * p.Win + ix0);
         a_off0[j] = (pix * (unsigned)p.seg[0].cstride + (unsigned)(p.seg[0].coff + lcol)) * 4u;
-        a_off1[j] = (pix * (unsigned)p.seg[1].cstride + (unsigned)(p.seg[1].coff + lcol)) * 4u;
+        const unsigned pix1 = p.seg1_stride ? (unsigned)row_pix1[lrow + 32 * j] : pix;
+        a_off1[j] = (pix1 * (unsigned)p.seg[1].cstride + (unsigned)(p.seg[1].coff + lcol)) * 4u;
         unsigned m = 0;
         if (base >= 0)
             for (int t = 0; t < p.ntaps; ++t) {

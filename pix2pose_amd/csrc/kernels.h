@@ -37,6 +37,8 @@ struct IgemmGroup {
 //   output pixel = (gy*os + oy, gx*os + ox) of an Hout x Wout image (os=2 for transposed-conv phases).
 struct IgemmParams {
     IgemmSeg seg[2];
+    int seg1_Hin, seg1_Win, seg1_stride;   // 1-tap layers only: segment 1 lives on its own grid (pixel (gy, gx) * seg1_stride of an
+                           // seg1_Hin x seg1_Win tensor) -- a strided projection shortcut folded in as extra K; 0 = same grid as segment 0
     int seg0_chunks;       // seg[0].C / 32
     int chunks_per_tap;    // (seg[0].C + seg[1].C) / 32
     int N, Hin, Win;

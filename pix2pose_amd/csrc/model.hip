@@ -255,7 +255,7 @@ static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& n
 // Projection-shortcut block tail as ONE 1x1 convolution over the channel concatenation [t (f1) || x (cin)]:
 //   relu(BN2c(W2c t) + BN1(W1 x)) = relu([s2c W2c | s1 W1] [t ; x] + (shift2c + shift1))
 // (resnet50_mod.py:81-91: conv 2c + BN, shortcut conv + BN, add, relu).  Saves writing the shortcut
-// tensor and reading it back as a residual.  Only for stride-1 shortcuts (both inputs on one grid).
+// tensor and reading it back as a residual.  x may live on a finer grid (stride-2 blocks: IgemmParams::seg1_stride).
 static int pack_merged_shortcut(const TensorMap& T, const std::string& n, int f1, int cin, int f3, ConvLayer& L)
 {
     const float* k2 = T.get(n + "_2c.kernel", (int64_t)f1 * f3);
@@ -413,7 +413,7 @@ static int build_model(const TensorMap& T, Model& M)
             const std::string n = b.n;
             if ((rc = pack_conv(T, {n + "_2a"}, 1, b.cin, b.f1, 0, true, M.L[n + "_2a"]))) return rc;
             if ((rc = pack_conv(T, {n + "_2b"}, 3, b.f1, b.f1, 1, true, M.L[n + "_2b"]))) return rc;
-            if (b.sc && n == "res2a") {          // stride-1 projection shortcut: folded into the last convolution
+            if (b.sc) {                          // projection shortcut: folded into the block's last convolution
                 if ((rc = pack_merged_shortcut(T, n, b.f1, b.cin, b.f3, M.L[n + "_2c1"]))) return rc;
                 continue;
             }
@@ -497,6 +497,7 @@ struct ConvCall {
     int ksplit = 1;
     float* partial = nullptr;
     double algo_macs = -1;   // algorithmic MACs of this launch; < 0 => M * Cout * K (no padded work)
+    int s1_Hin = 0, s1_Win = 0, s1_stride = 0;   // segment 1 on its own (strided) grid; 1-tap layers only
 };
 
 static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
@@ -511,6 +512,8 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
         set_error("run_conv: channel segments (%d+%d) x %d taps do not match packed K=%d", c.s0.C, c.s1.C, L.ntaps, L.K);
         return P2P_ERR_INVALID_ARG;
     }
+    p.seg1_Hin = c.s1_Hin; p.seg1_Win = c.s1_Win; p.seg1_stride = c.s1_stride;
+    if (c.s1_stride && L.ntaps != 1) { set_error("run_conv: a strided second segment needs a 1-tap layer"); return P2P_ERR_INVALID_ARG; }
     p.seg0_chunks = c.s0.C / IGEMM_BK;
     p.chunks_per_tap = cin / IGEMM_BK;
     p.N = c.N; p.Hin = c.Hin; p.Win = c.Win; p.Hg = c.Hg; p.Wg = c.Wg;
@@ -522,7 +525,8 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     {
         // buffer-descriptor ranges (32-bit): tensors are < 4 GB for max_batch <= 1024
         const size_t px = (size_t)c.N * c.Hin * c.Win;
-        const size_t b0 = px * c.s0.cstride * sizeof(float), b1 = px * c.s1.cstride * sizeof(float);
+        const size_t px1 = c.s1_stride ? (size_t)c.N * c.s1_Hin * c.s1_Win : px;
+        const size_t b0 = px * c.s0.cstride * sizeof(float), b1 = px1 * c.s1.cstride * sizeof(float);
         const size_t bw = (size_t)((L.Cout + 127) / 128 * 128) * L.K * sizeof(float);
         if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) {
             set_error("run_conv: tensor exceeds the 4 GB buffer-descriptor range (lower max_batch)");
@@ -624,12 +628,14 @@ static int res_block(const Model& M, Ctx& X, const std::string& n, const float* 
     if ((rc = conv_layer(X, M.L.at(n + "_2a"), in, N, H, H, Cin, stride, ta, ACT_RELU))) return rc;
     if ((rc = conv_layer(X, M.L.at(n + "_2b"), ta, N, Ho, Ho, f1, 1, tb, ACT_RELU))) return rc;
     const float* res = in;
-    if (shortcut && stride == 1 && M.L.count(n + "_2c1")) {
-        // projection shortcut folded into the block's last convolution (pack_merged_shortcut)
+    if (shortcut && M.L.count(n + "_2c1")) {
+        // projection shortcut folded into the block's last convolution (pack_merged_shortcut): K = [t_b || x], x read on
+        // its own grid at the block's stride
         const ConvLayer& L = M.L.at(n + "_2c1");
         ConvCall c;
         c.s0 = {tb, f1, f1, 0};
         c.s1 = {in, Cin, Cin, 0};
+        if (stride != 1) { c.s1_Hin = H; c.s1_Win = H; c.s1_stride = stride; }
         c.N = N; c.Hin = c.Win = c.Hg = c.Wg = Ho;
         c.out = out; c.Hout = c.Wout = Ho; c.out_cstride = L.Cout;
         c.act = ACT_RELU;

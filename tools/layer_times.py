@@ -7,7 +7,7 @@ import sys
 LAYERS = [  # (name, MMAC per sample) in launch order for the resnet50 backbone
     ("conv1", 38.5), ("maxpool", 0), ("res2a_2a", 4.2), ("res2a_2b", 37.7), ("res2a_2c+1", 33.6),
     ("res2b_2a", 16.8), ("res2b_2b", 37.7), ("res2b_2c", 16.8), ("res2c_2a", 16.8), ("res2c_2b", 37.7), ("res2c_2c", 16.8),
-    ("res3a_2a", 8.4), ("res3a_2b", 37.7), ("res3a_1", 33.6), ("res3a_2c", 16.8),
+    ("res3a_2a", 8.4), ("res3a_2b", 37.7), ("res3a_2c+1", 50.4),
     ("res3b_2a", 16.8), ("res3b_2b", 37.7), ("res3b_2c", 16.8), ("res3c_2a", 16.8), ("res3c_2b", 37.7), ("res3c_2c", 16.8),
     ("res3d_2a", 16.8), ("res3d_2b", 37.7), ("res3d_2c", 16.8), ("conv4", 419.4), ("dense_enc", 8.4), ("splitk_reduce", 0),
     ("dense_dec", 4.2), ("up1_p0", 16.8), ("up1_p1", 25.2), ("up1_p2", 25.2), ("up1_p3", 37.7), ("deconv1", 629.1),
@@ -17,7 +17,7 @@ LAYERS = [  # (name, MMAC per sample) in launch order for the resnet50 backbone
 
 # algorithmic activation traffic per sample in kilo-floats: tensors a layer must read (input, skip / residual) + write
 KF = {"conv1": 49 + 262, "maxpool": 262 + 66, "res2a_2a": 66 + 66, "res2a_2b": 66 + 66, "res2a_2c+1": 66 + 66 + 262,
-      "res3a_2a": 66 + 33, "res3a_2b": 33 + 33, "res3a_1": 66 + 131, "res3a_2c": 33 + 131 + 131,
+      "res3a_2a": 66 + 33, "res3a_2b": 33 + 33, "res3a_2c+1": 33 + 66 + 131,
       "conv4": 131 + 33, "dense_enc": 33, "dense_dec": 16, "deconv1": 66 + 33 + 66, "deconv2": 131 + 131 + 262,
       "deconv3": 262 + 131 + 524, "heads": 524 + 66}
 for _b in ("res2b", "res2c"):
