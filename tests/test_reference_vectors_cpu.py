@@ -8,6 +8,7 @@ import os
 import zlib
 
 import numpy as np
+import pytest
 
 from oracle import est_pose_oracle as O
 from pix2pose_amd import synthetic
@@ -85,3 +86,53 @@ def test_eval_harness_helpers_match_reference_bop_io():
     b = G["bop_io"]
     assert eval_bop.group_targets(b["targets"]) == b["grouped"]
     assert eval_bop.model_params_to_obj_param(b["model_param"]).tolist() == b["obj_param"]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tools/5_evaluation_bop_basic.py (row f-1): the reference script itself was run on a synthetic dataset with the detector,
+# the pose estimator and bop_toolkit stood in (tests/golden/make_reference_eval_vectors.py); the rows it handed to
+# save_bop_results are replayed here through the pure per-image functions of pix2pose_amd.eval_bop.
+GE = json.load(open(os.path.join(HERE, "golden", "reference_eval.json")))
+
+
+def _rect(r, shape):
+    m = np.zeros(shape, bool)
+    m[max(r[0], 0):max(r[2], 0), max(r[1], 0):max(r[3], 0)] = True
+    return m
+
+
+@pytest.mark.parametrize("run_idx", range(len(GE["runs"])))
+def test_eval_harness_logic_matches_reference_script(run_idx):
+    from pix2pose_amd import eval_bop
+    run = GE["runs"][run_idx]
+    cfg = {"score_type": 2, "task_type": 2, "cand_factor": 2, "outlier_th": [0.2, 0.3, 0.35], "inlier_th": 0.2}
+    cfg.update(run["cfg"])
+    model_ids = np.array(sorted(GE["model_ids"]))
+    shape = tuple(GE["frame"])
+    # per-object thresholds as handed to the pix2pose constructors (5_evaluation_bop_basic.py:164-169,217-219)
+    ths = eval_bop.outlier_thresholds(cfg, len(model_ids))
+    assert [c["th_outlier"] for c in run["ctor"]] == ths
+    assert [c["obj_param"] for c in run["ctor"]] == [[30.0 + m, 31.0 + m, 32.0 + m, 0.5 * m, -0.25 * m, 1.0] for m in model_ids]
+    assert eval_bop.output_name("lmo") == run["output_name"]
+    rows = []
+    for scene_id, im_id, obj_id_targets, inst_counts in eval_bop.group_targets(GE["targets"]):
+        dets = GE["images"]["%d/%d" % (scene_id, im_id)]
+        rois = [d["roi"] for d in dets]
+        obj_ids = [int(model_ids[d["class_id"] - 1]) for d in dets]
+        results = []
+        for r_id in eval_bop.select_detections(rois, obj_ids, obj_id_targets, inst_counts, float(cfg["cand_factor"])):
+            d = dets[r_id]
+            p = d["pose"]
+            if p["fail"]:
+                continue
+            dm, pmask = _rect(d["det_mask"], shape), _rect(p["pred_mask"], shape)
+            stats = (int(np.sum(dm & pmask)), int(np.sum(dm | pmask)))
+            results.append({"obj_id": obj_ids[r_id], "score": eval_bop.detection_score(d["score"], p["frac_inlier"], stats, cfg["score_type"], "rcnn"),
+                            "R": p["R"], "t": p["t"]})
+        rows += eval_bop.rank_image_results(results, obj_id_targets, inst_counts, cfg["task_type"], scene_id, im_id, 0.0)
+    assert len(rows) == len(run["rows"])
+    for a, b in zip(rows, run["rows"]):
+        assert (a["scene_id"], a["im_id"], a["obj_id"]) == (b["scene_id"], b["im_id"], b["obj_id"])
+        assert abs(float(a["score"]) - b["score"]) < 1e-12
+        assert np.array_equal(np.asarray(a["R"], float).flatten(), np.asarray(b["R"], float).flatten())
+        assert np.array_equal(np.asarray(a["t"], float).flatten(), np.asarray(b["t"], float).flatten())
