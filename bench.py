@@ -10,10 +10,19 @@ decoder outputs are injected: no trained weights exist offline; the generator pa
 and are timed).  `value` = detections ("crops") per second over all ranks; each costs 4 generator
 forwards (10.70 GFLOP each) + 3 PnP-RANSAC solves.
 
-Multi-GPU: one process per GPU (torchrun), detections sharded with no data-path collective; the
-final (R, t, score) records are all-gathered with RCCL inside the timed step.  Weak scaling.
+Multi-GPU: one process per GPU, detections sharded with no data-path collective; the final
+(R, t, score) records are all-gathered with RCCL inside the timed step.  Weak scaling.
+`python bench.py --gpus N` launches its own ranks (torch.distributed.run on 127.0.0.1) when it is
+not already running under a launcher; rank 0 prints the one JSON line.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+
+Extra legs (N=1, after the timed region; none of them changes `value`):
+  f32_mode          the same steps with the strict-fp32 generator (fp32 MFMA), its own roofline
+  host_frames_value frames handed over as HOST uint8 arrays, different frames every step, H2D inside the timed region
+                    (the reference's boundary: est_pose(rgb, bbox) takes a numpy frame, recognition.py:70)
+  single_det_ms     latency of ONE shim est_pose() call (batch of 1, masks returned), median of 100
+  cpu_baseline      the CPU restatement on the host cores (tuned torch/oneDNN fp32 network + numpy/C glue and PnP)
 """
 from __future__ import annotations
 
@@ -34,34 +43,101 @@ PEAK_F16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: de
 TH_O, TH_I = [0.2, 0.3, 0.35], 0.2                     # cfg/cfg_bop2020.json:8-9
 
 
+# ------------------------------------------------------------------------------------------ CPU baseline
+def _usable_cpus():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (a container that sees 256
+    CPUs but owns a quota of 32 runs 256 threads 8x oversubscribed -- round 1's 2.5 s per input)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for fn in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(fn).read().split()[:2]
+            if q != "max":
+                n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = max(1, min(n, int(q / p + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(backbone, weights, n_sample):
-    """The oracle (CPU restatement of the reference path) timed on this host's cores, on a bounded
-    sample of the same workload: n_sample detections = 4*n_sample generator forwards (C, OpenMP
-    over all cores) + 3*n_sample sequential OpenCV-style PnP-RANSAC solves + the numpy glue.
-    (The torch-CPU formulation of the network, oracle/ae_torch.py, was tried as the network leg: on the 256-thread host of
-    the GPU box oneDNN at batch 8-24 took 2.5 s per input -- 25x slower than this C/OpenMP restatement -- so it is not used.)"""
-    from oracle import ae_oracle, est_pose_oracle
+    """The CPU restatement of the reference path timed on this host, on a bounded sample of the same workload:
+    n_sample detections = 4*n_sample generator forwards + 3*n_sample PnP-RANSAC solves + the numpy glue.
+    Network leg: oracle/ae_torch.py (torch-CPU = oneDNN, fp32, batch 64 -- the closest thing here to Keras-on-CPU), with
+    the thread count tuned on this host (all SMT threads is rarely the best, and a cgroup quota makes it pathological).
+    Glue + PnP leg: oracle/est_pose_oracle.py + pnp_oracle.c, one detection after the other like the reference
+    (tools/5_evaluation_bop_basic.py:289-304).  value = n_sample / (network time + glue time)."""
+    import torch
+    from oracle import ae_torch, est_pose_oracle
     from pix2pose_amd import synthetic
     sc = synthetic.make_scene(n_sample, seed=12345)
 
-    def run():
-        n_ok = 0
-        for i in range(n_sample):
-            def predict(x, stage, slots=None, i=i):
-                ae_oracle.forward(weights, np.asarray(x, np.float32), backbone)      # the timed network pass
-                m = sc["inject1"][i][None] if stage == 1 else sc["inject2"][i][slots]
-                return [m[..., :3].copy(), m[..., 3:].copy()]
-            img_i, _, bbox, K = sc["dets"][i]
-            out = est_pose_oracle.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], TH_O, TH_I)
-            n_ok += not (isinstance(out[4], int) and out[4] == -1)
-        return n_ok
-    ae_oracle.forward(weights, np.zeros((1, 128, 128, 3), np.float32), backbone)      # warm up / build
+    # -- glue + PnP leg (also records the network inputs the reference would have fed to predict())
+    recorded = []
     t0 = time.time()
-    run()
-    dt = time.time() - t0
-    return {"value": n_sample / dt, "unit": "crops/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d detections (= %d generator forwards + %d PnP-RANSAC solves) of the same synthetic workload, "
-                      "oracle C/numpy restatement, OpenMP over all host cores, %.1f s" % (n_sample, 4 * n_sample, 3 * n_sample, dt)}
+    for i in range(n_sample):
+        def predict(x, stage, slots=None, i=i):
+            recorded.append(np.asarray(x, np.float32))
+            m = sc["inject1"][i][None] if stage == 1 else sc["inject2"][i][slots]
+            return [m[..., :3].copy(), m[..., 3:].copy()]
+        img_i, _, bbox, K = sc["dets"][i]
+        est_pose_oracle.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], TH_O, TH_I)
+    t_glue = time.time() - t0
+    x_all = np.concatenate(recorded, 0)
+
+    # -- network leg: pick the thread count on a small batch, then time the recorded inputs in batches of 64
+    ncpu = _usable_cpus()
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu // 2, ncpu) if 1 <= c <= ncpu} | {min(ncpu, 8)})
+    probe = x_all[:8]
+    best, best_t, tuning = cands[0], float("inf"), {}
+    with torch.no_grad():
+        for c in cands:                      # ascending; stop once more threads make it clearly slower
+            torch.set_num_threads(c)
+            ae_torch.forward(weights, probe[:2], backbone, dtype=torch.float32)           # warm up (oneDNN primitive cache)
+            dt = float("inf")
+            for _ in range(2):
+                t1 = time.time()
+                ae_torch.forward(weights, probe, backbone, dtype=torch.float32)
+                dt = min(dt, time.time() - t1)
+            tuning[c] = round(dt, 3)
+            if dt < best_t:
+                best, best_t = c, dt
+            elif dt > 1.5 * best_t:
+                break
+        torch.set_num_threads(best)
+        ae_torch.forward(weights, x_all[:64], backbone, dtype=torch.float32)              # warm up at the timed batch size
+        t1 = time.time()
+        for b0 in range(0, len(x_all), 64):
+            ae_torch.forward(weights, x_all[b0:b0 + 64], backbone, dtype=torch.float32)
+        t_net = time.time() - t1
+    return {"value": n_sample / (t_net + t_glue), "unit": "crops/s", "cores": best, "kind": "port",
+            "host_cpus_visible": os.cpu_count(), "host_cpus_usable": ncpu, "thread_tuning_s_per_8_inputs": tuning,
+            "network_inputs_per_s": len(x_all) / t_net, "glue_pnp_detections_per_s": n_sample / t_glue,
+            "sample": "%d detections of the same synthetic workload = %d generator forwards (torch-CPU/oneDNN fp32, batch 64, %d threads "
+                      "chosen by a probe over %s: %.1f s) + the sequential numpy/C glue with %d OpenCV-style EPnP-RANSAC solves (1 thread: %.1f s)"
+                      % (n_sample, len(x_all), best, sorted(tuning), t_net, 3 * n_sample, t_glue)}
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def _self_launch(n):
+    """`python bench.py --gpus N` from a plain shell: start N ranks of this script under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) and become that launcher."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execve(sys.executable, cmd, env)
 
 
 def main():
@@ -72,7 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="detections per GPU per step")
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--chunk", type=int, default=1024, help="generator inputs per pass (activation workspace: 13 MB per input; 1024 holds the 768 stage-2 inputs of a 256-detection batch in one pass)")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="detections in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="detections in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-inject", action="store_true", help="let PnP consume the random-weight generator output")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="generator arithmetic: fp32 emulated with 3 split-f16 MFMAs (default) or fp32 MFMA")
@@ -85,16 +161,23 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="stream mode: batches in flight before the oldest is collected (the library holds 2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="debug: all ranks share cuda:0 (needs --backend gloo)")
+    ap.add_argument("--masks", action="store_true", help="also return valid_mask / img_pred of every detection (the full reference tuple) inside the timed region")
+    ap.add_argument("--f32-steps", type=int, default=3, help="steps of the strict-fp32 leg (N=1, single object; 0 = skip)")
+    ap.add_argument("--host-frames", type=int, default=3, help="steps of the host-frame leg (N=1; 0 = skip)")
+    ap.add_argument("--latency", type=int, default=100, help="calls of the single-detection latency leg (N=1; 0 = skip)")
     args = ap.parse_args()
     args.overlap = not args.blocking
     args.inflight = max(1, min(args.inflight, 2))
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args.gpus)                                   # does not return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -112,10 +195,13 @@ def main():
 
     ctx = Context(local_rank, max_batch=args.chunk)
     wts = W.synthetic_weights(args.backbone, 1)
-    gen = Generator(wts, args.backbone, ctx, precision=args.precision)
-    spec = ObjectSpec(gen, synthetic.OBJ_PARAM, TH_O, TH_I)
-    specs = [spec] + [ObjectSpec(Generator(W.synthetic_weights(args.backbone, 1 + k), args.backbone, ctx, precision=args.precision), synthetic.OBJ_PARAM, TH_O, TH_I)
-                      for k in range(1, args.objects)]
+
+    def make_specs(precision):
+        gen = Generator(wts, args.backbone, ctx, precision=precision)
+        return [ObjectSpec(gen, synthetic.OBJ_PARAM, TH_O, TH_I)] + \
+               [ObjectSpec(Generator(W.synthetic_weights(args.backbone, 1 + k), args.backbone, ctx, precision=precision), synthetic.OBJ_PARAM, TH_O, TH_I)
+                for k in range(1, args.objects)]
+    specs = make_specs(args.precision)
     sc = synthetic.make_scene(args.batch, seed=1000 + rank)
     if args.objects > 1:
         sc["dets"] = [(d[0], i % args.objects, d[2], d[3]) for i, d in enumerate(sc["dets"])]
@@ -132,19 +218,21 @@ def main():
             rec = gather_poses(rec, device=coll_dev, pad_to=args.batch)          # RCCL all-gather of (R,t,score)
         return poses, rec
 
-    def run_steps(k):
-        """k steps.  --blocking: one blocking p2p_est_pose_batch per step.  Default: detection-stream mode --
-        step i+1 is enqueued before step i is collected, so the PnP-RANSAC tail (second HIP stream), the
-        D2H and the pose gather overlap the next step's generator passes; every step's work still
-        completes inside the call."""
+    def run_steps(k, specs=specs, images_of_step=None, blocking=None, masks=None):
+        """k steps.  Blocking: one p2p_est_pose_batch per step.  Default: detection-stream mode -- step i+1 is enqueued
+        before step i is collected, so the PnP-RANSAC tail (second HIP stream), the D2H and the pose gather overlap the
+        next step's generator passes; every step's work still completes inside the call."""
+        blocking = (not args.overlap) if blocking is None else blocking
+        masks = args.masks if masks is None else masks
+        imgs = (lambda i: images) if images_of_step is None else images_of_step
         out = None
-        if not args.overlap:
-            for _ in range(k):
-                out = finish(est_pose_batch(ctx, specs, images, sc["dets"], **kw)[0])
+        if blocking:
+            for i in range(k):
+                out = finish(est_pose_batch(ctx, specs, imgs(i), sc["dets"], want_masks=masks, **kw)[0])
             return out
         pending = []
-        for _ in range(k):
-            pending.append(est_pose_submit(ctx, specs, images, sc["dets"], **kw))
+        for i in range(k):
+            pending.append(est_pose_submit(ctx, specs, imgs(i), sc["dets"], want_masks=masks, **kw))
             if len(pending) >= args.inflight:
                 out = finish(pending.pop(0).collect())
         while pending:
@@ -155,6 +243,19 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def profiled_blocking_steps(k, specs=specs):
+        """Per-kernel figures: HIP events around every launch of k blocking steps (one batch on the GPU at a time)."""
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(k, specs=specs, blocking=True, masks=False)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t1
+        st = ctx.profile_read(reset=True)
+        ctx.profile(False)
+        return st, dtp
 
     if args.warmup:
         run_steps(args.warmup)
@@ -175,17 +276,7 @@ def main():
         # kernel's own duration.  The per-kernel figures come from PROF_STEPS extra blocking steps right after the timed region
         # (same data, same kernels, one batch at a time); `python bench.py --blocking` measures them inside the timed region.
         PROF_STEPS = 2
-        args.overlap = False
-        ctx.profile(True)
-        ctx.profile_read(reset=True)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(PROF_STEPS)
-        torch.cuda.synchronize()
-        prof_dt = time.perf_counter() - t1
-        stats = ctx.profile_read(reset=True)
-        ctx.profile(False)
-        args.overlap = True
+        stats, prof_dt = profiled_blocking_steps(PROF_STEPS)
         prof_note = ("HIP events around every launch of %d extra blocking steps after the timed region (in stream mode kernels of two "
                      "batches overlap, which inflates per-launch times); shares are of those steps' time" % PROF_STEPS)
     if world > 1:
@@ -198,46 +289,60 @@ def main():
             for i, p in enumerate(poses) if p.status == 0]
     total = world * args.batch * args.steps
     value = total / dt
-    dom = max(range(len(stats)), key=lambda i: stats[i]["total_ms"])     # dominant kernel family of the timed region
-    s0 = stats[dom]
-    prec_id = 1 if args.precision == "f16x3" else 0
-    dom_label, dom_name = _lib.PROFILE_KERNELS[dom]
-    if "%d" in dom_name:
-        dom_name = dom_name % prec_id
-    ach = s0["algo_flops"] / (s0["total_ms"] * 1e-3) / 1e12 if s0["total_ms"] > 0 else 0.0
-    all_ms = sum(s["total_ms"] for s in stats)
-    # peak in the same unit as `achieved` (ALGORITHMIC FLOPs): the f16x3 arithmetic spends three dense-f16 MFMA products per
-    # algorithmic MAC, so its ceiling is the dense f16 peak / 3; the fp32 mode is priced against the fp32-MFMA peak
-    peak = PEAK_F16_MFMA_TFLOPS / 3.0 if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+
+    def roofline_of(stats, prof_dt, precision, note):
+        dom = max(range(len(stats)), key=lambda i: stats[i]["total_ms"])     # dominant kernel family
+        s0 = stats[dom]
+        prec_id = 1 if precision == "f16x3" else 0
+        dom_label, dom_name = _lib.PROFILE_KERNELS[dom]
+        if "%d" in dom_name:
+            dom_name = dom_name % prec_id
+        ach = s0["algo_flops"] / (s0["total_ms"] * 1e-3) / 1e12 if s0["total_ms"] > 0 else 0.0
+        all_ms = sum(s["total_ms"] for s in stats)
+        # peak in the same unit as `achieved` (ALGORITHMIC FLOPs): the f16x3 arithmetic spends three dense-f16 MFMA products per
+        # algorithmic MAC, so its ceiling is the dense f16 peak / 3; the fp32 mode is priced against the fp32-MFMA peak
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+        r = {"bound": "mfma", "kernel": "%s: %s" % (dom_name, dom_label),
+             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+             "frac_algorithmic": ach / (PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS),
+             "peak_dense_f16_mfma": PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else None,
+             "mfma_flops_per_algorithmic_flop": 3 if precision == "f16x3" else 1,
+             "note": ("achieved = algorithmic FLOPs (2 x MACs of the layers) / launch time.  frac = utilisation of the f16 matrix pipe: the split-f16 "
+                      "arithmetic (fp32-equivalent results) issues 3 MFMA products per algorithmic MAC, so peak = 2500 / 3 and the pipe sustains "
+                      "%.0f of its 2500 TFLOP/s.  frac_algorithmic = achieved / 2500 (no credit for the emulation overhead).  The power-limited "
+                      "ceiling of dense f16 MFMA on random operands is ~1330 TFLOP/s (cdna_hip_programming.md 5.4 rule 25); the kernel "
+                      "delivers %.2fx the fp32-MFMA peak (157.3)" % (3 * ach, ach / PEAK_F32_MFMA_TFLOPS))
+                     if precision == "f16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s",
+             "avg_launch_ms": s0["total_ms"] / max(s0["launches"], 1), "launches": s0["launches"],
+             "algo_gflop_per_launch": s0["algo_flops"] / max(s0["launches"], 1) / 1e9,
+             "measured_over": note, "share_of_step_time": s0["total_ms"] * 1e-3 / prof_dt, "all_conv_kernels_share_of_step_time": all_ms * 1e-3 / prof_dt,
+             "families": {_lib.PROFILE_KERNELS[i][0]: {"launches": st["launches"], "total_ms": st["total_ms"],
+                                                       "algo_tflops": (st["algo_flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] > 0 else 0.0)}
+                          for i, st in enumerate(stats) if st["launches"]},
+             "traffic": None}
+        return r, dom_name
+
+    roof, dom_name = roofline_of(stats, prof_dt, args.precision, prof_note)
     out = {
         "metric": "crops/sec (AE fwd + PnP-RANSAC) at 128x128", "value": value, "unit": "crops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16x3 (fp32 operands split into two f16 halves, 3 MFMAs per product block, fp32 accumulate)" if args.precision == "f16x3" else "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[2]: %d detections/GPU/step, 128x128 crops, %s generator "
+        "config": {"workload": "BASELINE.json configs[%d]: %d detections/GPU/step, 128x128 crops, %s generator "
                                "(1 stage-1 + 3 stage-2 forwards per detection) + 3 EPnP-RANSAC solves per detection, "
-                               "outlier_th=[0.2,0.3,0.35], injected ellipsoid-NOCS decoder maps" % (args.batch, args.backbone),
+                               "outlier_th=[0.2,0.3,0.35], injected ellipsoid-NOCS decoder maps%s"
+                               % (3 if args.objects > 1 else 2, args.batch, args.backbone,
+                                  ", %d object models (grouped generator passes)" % args.objects if args.objects > 1 else ""),
                    "detections_per_gpu": args.batch, "backbone": args.backbone, "precision": args.precision, "parallelism": "dp%d" % world,
-                   "generator_chunk": args.chunk, "objects": args.objects, "mode": ("stream (submit/collect, %d in flight)" % args.inflight) if args.overlap else "blocking"},
+                   "generator_chunk": args.chunk, "objects": args.objects, "returns_masks": bool(args.masks),
+                   "mode": ("stream (submit/collect, %d in flight)" % args.inflight) if args.overlap else "blocking"},
         "ae_inputs_per_s": 4 * value,
         "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
-        "poses_ok": n_ok, "ransac_iters_mean_of_selected": float(np.mean([p.ransac_iters for p in poses])), "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,
-        "roofline": {"bound": "mfma", "kernel": "%s: %s" % (dom_name, dom_label),
-                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                     "peak_dense_f16_mfma": PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else None,
-                     "mfma_flops_per_algorithmic_flop": 3 if args.precision == "f16x3" else 1,
-                     "note": ("achieved = algorithmic FLOPs (2 x MACs of the layers) / launch time; peak = dense f16 MFMA peak 2500 / 3, because the "
-                              "split-f16 arithmetic (fp32-equivalent results) issues 3 MFMA products per algorithmic MAC: the matrix pipe sustains "
-                              "%.0f of its 2500 TFLOP/s (frac %.3f either way; against the raw 2500 the algorithmic rate is %.3f). The power-limited "
-                              "ceiling of dense f16 MFMA on random operands is ~1330 TFLOP/s (cdna_hip_programming.md 5.4 rule 25); the kernel "
-                              "delivers %.2fx the fp32-MFMA peak (157.3)" % (3 * ach, ach / peak, ach / PEAK_F16_MFMA_TFLOPS, ach / PEAK_F32_MFMA_TFLOPS))
-                             if args.precision == "f16x3" else "fp32 MFMA",
-                     "avg_launch_ms": s0["total_ms"] / max(s0["launches"], 1), "launches": s0["launches"],
-                     "algo_gflop_per_launch": s0["algo_flops"] / max(s0["launches"], 1) / 1e9,
-                     "measured_over": prof_note, "share_of_step_time": s0["total_ms"] * 1e-3 / prof_dt, "all_conv_kernels_share_of_step_time": all_ms * 1e-3 / prof_dt,
-                     "families": {_lib.PROFILE_KERNELS[i][0]: {"launches": st["launches"], "total_ms": st["total_ms"], "algo_tflops": (st["algo_flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] > 0 else 0.0)} for i, st in enumerate(stats) if st["launches"]},
-                     "traffic": None},
+        "gathered_records": int(len(rec)),
+        "poses_ok": n_ok, "ransac_iters_mean_of_selected": float(np.mean([p.ransac_iters for p in poses])),
+        "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,
+        "roofline": roof,
     }
     # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes of this same
     # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py), committed under profiles/
@@ -249,12 +354,70 @@ def main():
             if dom_name in k:
                 out["roofline"]["traffic"] = v["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = ("bytes/launch, rocprofv3 PMC (FETCH_SIZE*2 + WRITE_SIZE), profiles/%s" % os.path.basename(tfns[-1]))
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+
+    solo = rank == 0 and world == 1
+    # -- strict-fp32 leg: the same steps on generators built with P2P_PREC_F32 (fp32 matrix instructions, bitwise an fmaf chain)
+    if solo and args.f32_steps > 0 and args.objects == 1 and args.precision == "f16x3":
+        specs32 = make_specs("f32")
+        run_steps(1, specs=specs32)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.f32_steps, specs=specs32)
+        torch.cuda.synchronize()
+        d32 = time.perf_counter() - t1
+        st32, pdt32 = profiled_blocking_steps(1, specs=specs32)
+        r32, _ = roofline_of(st32, pdt32, "f32", "HIP events around every launch of 1 blocking step")
+        out["f32_mode"] = {"value": args.batch * args.f32_steps / d32, "unit": "crops/s", "steps": args.f32_steps,
+                           "ms_per_step": d32 / args.f32_steps * 1e3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                           "roofline": {k: r32[k] for k in ("kernel", "achieved", "peak", "frac", "unit", "avg_launch_ms", "launches", "share_of_step_time")}}
+        del specs32
+    # -- host-frame leg: the reference's boundary hands over numpy frames (recognition.py:70; caller
+    #    tools/5_evaluation_bop_basic.py:272,303-304): 32 frames of 640x480x3 uint8 per step (8 detections each), new frames
+    #    every step, pageable host memory, H2D inside the timed region
+    if solo and args.host_frames > 0:
+        n_fr = 32
+        pool = [np.random.RandomState(77 + s).randint(0, 256, (n_fr,) + sc["images"].shape[1:], dtype=np.uint8) for s in range(args.host_frames + 1)]
+        dets_backup = sc["dets"]
+        sc["dets"] = [(i % n_fr, d[1], d[2], d[3]) for i, d in enumerate(dets_backup)]
+        run_steps(1, images_of_step=lambda i: list(pool[-1]))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.host_frames, images_of_step=lambda i: list(pool[i]))
+        torch.cuda.synchronize()
+        dh = time.perf_counter() - t1
+        out["host_frames_value"] = args.batch * args.host_frames / dh
+        out["host_frames"] = {"value": out["host_frames_value"], "unit": "crops/s", "steps": args.host_frames, "ms_per_step": dh / args.host_frames * 1e3,
+                              "frames_per_step": n_fr, "h2d_bytes_per_step": int(pool[0].nbytes),
+                              "note": "frames are host uint8 numpy arrays (pageable), different every step; upload inside the timed region"}
+        sc["dets"] = dets_backup
+        del pool
+    # -- latency leg: ONE detection through the drop-in shim, masks and image returned like the reference's est_pose
+    if solo and args.latency > 0:
+        from pix2pose_amd.recognition import pix2pose
+        shim = pix2pose({k: v for k, v in wts.items()}, synthetic.LM_K, 640, 480, synthetic.OBJ_PARAM, th_outlier=TH_O, th_inlier=TH_I,
+                        backbone=args.backbone, ctx=ctx)
+        lat, n_ret = [], 0
+        for i in range(args.latency + 5):
+            j = i % args.batch
+            if not args.no_inject:
+                shim._inject = (inj1[j:j + 1].data_ptr(), inj2[j:j + 1].data_ptr(), 3)
+            img_i, _, bbox, K = sc["dets"][j]
+            shim.camK = K
+            t1 = time.perf_counter()
+            r = shim.est_pose(sc["images"][img_i], bbox)
+            lat.append(time.perf_counter() - t1)
+            n_ret += not (isinstance(r[4], int) and r[4] == -1)
+        lat = np.array(lat[5:]) * 1e3
+        out["single_det_ms"] = float(np.median(lat))
+        out["single_det"] = {"median_ms": float(np.median(lat)), "p90_ms": float(np.percentile(lat, 90)), "calls": args.latency, "poses_returned": int(n_ret),
+                             "note": "recognition.pix2pose.est_pose(rgb, bbox) on one detection: host frame in, (img_pred, valid_mask, R, t, frac_inlier, box) out"}
+    if solo and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.backbone, wts, args.cpu_sample)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define P2P_ABI_VERSION 2
+#define P2P_ABI_VERSION 3
 
 typedef enum {
     P2P_OK = 0,
@@ -46,6 +46,13 @@ typedef struct {
 } p2p_tensor;
 
 int p2p_abi_version(void);
+/* Binding self-checks: sizeof() of the public structs as this build of the library sees them
+ * (which: 0 p2p_tensor, 1 p2p_image, 2 p2p_object, 3 p2p_detection, 4 p2p_pose, 5 p2p_est_pose_opts,
+ * 6 p2p_kernel_stats; -1 otherwise), and the hash of the sources the library was built from
+ * (pix2pose_amd/build.py) -- a foreign-language binding compares both with its own declarations / tree
+ * before the first call, so that a stale .so is an error and not a silent struct mismatch. */
+int p2p_abi_sizeof(int which);
+const char* p2p_build_id(void);
 const char* p2p_last_error(void);
 int p2p_device_count(int* count);
 
@@ -97,6 +104,9 @@ int p2p_forward_async(p2p_ctx* ctx, const p2p_model* model, const float* x_dev, 
  * crop geometry get_boxes :28-69, pnp_ransac :195-224) for a whole batch of detections.
  * ---------------------------------------------------------------------------------------- */
 #define P2P_MAX_OUTLIER_TH 8
+/* Largest RANSAC iteration count (the reference hard-codes iterationsCount=100, recognition.py:217): the
+ * hypothesis storage of the solver is sized for it; larger requests fail with P2P_ERR_INVALID_ARG. */
+#define P2P_MAX_RANSAC_ITERATIONS 128
 
 typedef enum { P2P_IMG_U8 = 0, P2P_IMG_F32 = 1 } p2p_img_dtype;
 
@@ -157,7 +167,7 @@ typedef struct {
 /* Optional knobs; zero-initialise for the reference behaviour. */
 typedef struct {
     /* PnP-RANSAC constants hard-coded at recognition.py:216-217 / OpenCV defaults. 0 => default */
-    int ransac_iterations;      /* 100  */
+    int ransac_iterations;      /* 100; at most P2P_MAX_RANSAC_ITERATIONS */
     double reprojection_error;  /* 5.0  */
     double confidence;          /* 0.99 */
     /* TEST / BENCH ONLY: replace the decoder outputs after each generator pass (device
@@ -199,7 +209,10 @@ int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, c
  * and returns a ticket; `collect` waits for that batch and fills poses[n_dets].  At most two
  * batches may be in flight, so the latency-bound PnP tail of batch i overlaps the generator
  * passes of batch i+1.  Device-resident frames and injected maps must stay alive until the
- * collect.  The optional mask / debug / det_mask outputs of p2p_est_pose_opts are blocking-only. */
+ * collect.  The optional outputs of the reference's return tuple (valid_mask, img_pred: recognition.py:189-193)
+ * and the score_type-2 sums (det_mask -> mask_stats) are available here too: name the host buffers in the
+ * options of `submit`, keep them alive, and `collect` fills them (rendered on the tail stream, landed in pinned
+ * memory, copied out at collect time).  det_mask is read during `submit`.  Only the debug taps are blocking-only. */
 int p2p_est_pose_submit(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images,
                         int n_images, const p2p_detection* dets, int n_dets, const p2p_est_pose_opts* opts,
                         int* ticket);

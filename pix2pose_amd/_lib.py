@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P2P_LIB", os.path.join(_HERE, "libp2p_mi355.so"))     # P2P_LIB: development override
 
 P2P_OK = 0
+ABI_VERSION = 3            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
+MAX_RANSAC_ITERATIONS = 128
 BACKBONE = {"paper": 0, "resnet50": 1}
 PRECISION = {"f32": 0, "f16x3": 1}
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -73,23 +75,59 @@ class KernelStats(C.Structure):
 _lib = None
 
 
+def _stale_reason(path):
+    """Why the library at `path` must not be used with this tree (None = fine).  Checked through a private handle so a
+    refused library is never left typed in `_lib`."""
+    try:
+        L = C.CDLL(path)
+    except OSError as e:
+        return "cannot load %s: %s" % (path, e)
+    L.p2p_abi_version.restype = C.c_int
+    if L.p2p_abi_version() != ABI_VERSION:
+        return "ABI version %d, binding expects %d" % (L.p2p_abi_version(), ABI_VERSION)
+    if not hasattr(L, "p2p_build_id"):
+        return "no build id"
+    L.p2p_build_id.restype = C.c_char_p
+    if "P2P_LIB" not in os.environ:          # an explicitly named A/B build is taken as is
+        from . import build as _build
+        want = _build.source_hash()
+        got = (L.p2p_build_id() or b"").decode()
+        if got != want:
+            return "built from other sources (build id %s, tree %s)" % (got, want)
+    L.p2p_abi_sizeof.restype = C.c_int
+    L.p2p_abi_sizeof.argtypes = [C.c_int]
+    for which, typ in enumerate((Tensor, Image, Object, Detection, Pose, EstPoseOpts, KernelStats)):
+        if L.p2p_abi_sizeof(which) != C.sizeof(typ):
+            return "sizeof(%s) = %d in the library, %d in the binding" % (typ.__name__, L.p2p_abi_sizeof(which), C.sizeof(typ))
+    return None
+
+
 def lib():
-    """Load (building first if the .so is absent and hipcc is present) and type the library."""
+    """Load and type the library.  A missing or stale .so (other ABI version, other sources, other struct sizes) is
+    rebuilt when hipcc is present and refused otherwise -- never loaded silently."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _build
+    from . import build as _build
+    reason = "not built" if not os.path.exists(LIB_PATH) else _stale_reason(LIB_PATH)
+    if reason is not None:
+        if "P2P_LIB" in os.environ or not _build.have_compiler():
+            raise P2PError("%s: %s (the HIP path is mandatory, there is no fallback)" % (LIB_PATH, reason))
         try:
             _build.build()
         except Exception as e:  # pragma: no cover
-            raise P2PError("libp2p_mi355.so is not built and could not be built: %s" % (e,))
+            raise P2PError("libp2p_mi355.so is %s and could not be rebuilt: %s" % (reason, e))
+        reason = _stale_reason(LIB_PATH)
+        if reason is not None:
+            raise P2PError("%s: %s after a rebuild" % (LIB_PATH, reason))
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:
         raise P2PError("cannot load %s: %s (the HIP path is mandatory, there is no fallback)" % (LIB_PATH, e))
     vp, fp, ci = C.c_void_p, C.POINTER(C.c_float), C.c_int
     L.p2p_abi_version.restype = ci
+    L.p2p_abi_sizeof.argtypes = [ci]
+    L.p2p_build_id.restype = C.c_char_p
     L.p2p_last_error.restype = C.c_char_p
     L.p2p_device_count.argtypes = [C.POINTER(ci)]
     L.p2p_ctx_create.argtypes = [ci, ci, C.POINTER(vp)]

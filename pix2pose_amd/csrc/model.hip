@@ -773,6 +773,10 @@ hipEvent_t Ctx::prof_get_event()
 
 int Ctx::prof_harvest()
 {
+    // events are recorded on whichever lane ran the pass: wait for all of them (an event still pending
+    // makes hipEventElapsedTime fail with hipErrorNotReady)
+    for (Lane& ln : lane)
+        if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
     HIP_TRY(hipStreamSynchronize(stream));
     for (const ProfEvent& ev : prof_pending) {
         float ms = 0.f;
@@ -854,6 +858,20 @@ using namespace p2p;
 extern "C" {
 
 int p2p_abi_version(void) { return P2P_ABI_VERSION; }
+
+int p2p_abi_sizeof(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(p2p_tensor);
+    case 1: return (int)sizeof(p2p_image);
+    case 2: return (int)sizeof(p2p_object);
+    case 3: return (int)sizeof(p2p_detection);
+    case 4: return (int)sizeof(p2p_pose);
+    case 5: return (int)sizeof(p2p_est_pose_opts);
+    case 6: return (int)sizeof(p2p_kernel_stats);
+    default: return -1;
+    }
+}
 const char* p2p_last_error(void) { return get_error(); }
 
 int p2p_device_count(int* count)

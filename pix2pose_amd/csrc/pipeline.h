@@ -82,15 +82,29 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// growable pinned host buffer (D2H landing zone: the copy is truly asynchronous and the caller's pageable
+// buffer is filled with one memcpy at collect time)
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // Per-batch buffers: double buffered.  Asynchronous batches alternate between two generator lanes (stream +
 // activation workspace, Ctx::lane[0/1]) so that the passes of batch i+1 fill the launch tails of batch i, and
 // their PnP-RANSAC tails run on a third stream.
 struct Slot {
     DevBuf det, s1, cand, probs, results, poses, corr, hyp;
     DevBuf x1, y1, x2, y2, images;      // network inputs / outputs of both stages, uploaded frames
+    DevBuf mask, pred, dmask, mstat;    // optional outputs of the batch (valid_mask_full, img_pred_f, detector masks, IoU sums)
     p2p_pose* host_poses = nullptr;     // pinned
     size_t host_cap = 0;
+    PinnedBuf h_mask, h_pred, h_stat;   // pinned landing buffers of the optional outputs (sorted order)
     std::vector<int> perm;
+    std::vector<int> img_hw;            // H*W of each detection's frame (sorted order)
+    p2p_est_pose_opts opt;              // the caller's output pointers (host), filled at collect time
     int n = 0;
     int ticket = -1;                    // in-flight async batch, -1 = free
     hipEvent_t done = nullptr;
@@ -99,7 +113,6 @@ struct Slot {
 struct Pipeline {
     static constexpr int N_SLOTS = 2;   // asynchronous batches in flight (each on its own generator lane)
     Slot slot[N_SLOTS];
-    DevBuf mask, pred, dmask, mstat;
     hipStream_t tail_stream = nullptr;  // PnP + selection + D2H of async batches
     hipEvent_t corr_ready = nullptr;
     int next_ticket = 0;

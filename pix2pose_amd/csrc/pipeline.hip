@@ -48,14 +48,35 @@ void DevBuf::release()
     p = nullptr;
     cap = 0;
 }
+int PinnedBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return P2P_OK;
+    release();
+    const size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return P2P_ERR_HIP;
+    }
+    cap = want;
+    return P2P_OK;
+}
+void PinnedBuf::release()
+{
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
 Pipeline::~Pipeline()
 {
     for (Slot& s : slot) {
-        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images}) b->release();
+        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images,
+                          &s.mask, &s.pred, &s.dmask, &s.mstat}) b->release();
+        for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    for (DevBuf* b : {&mask, &pred, &dmask, &mstat}) b->release();
     if (corr_ready) (void)hipEventDestroy(corr_ready);
     if (tail_stream) (void)hipStreamDestroy(tail_stream);
 }
@@ -571,6 +592,26 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict
 // async_ticket == nullptr: blocking call, results in `poses`.  Otherwise the batch is only enqueued:
 // generator passes and glue on the context stream, PnP-RANSAC + selection + D2H on the tail stream,
 // and p2p_est_pose_collect() picks the poses up.
+// Hand a finished batch over to the caller: sorted order -> caller order, pinned landing buffers -> the caller's
+// (pageable) output arrays named in the options of the submit / blocking call.
+static void finish_batch(const Slot& s, p2p_pose* poses)
+{
+    const p2p_est_pose_opts& opt = s.opt;
+    const unsigned long long* hstat = s.h_stat.as<unsigned long long>();
+    for (int i = 0; i < s.n; ++i) {
+        const int o = s.perm[i];
+        poses[o] = s.host_poses[i];
+        if (opt.valid_mask) {       // bytes past H*W of the detection's frame are zeroed like the rest of the mask
+            memcpy(opt.valid_mask + (size_t)o * opt.mask_stride, s.h_mask.as<unsigned char>() + (size_t)i * opt.mask_stride, (size_t)opt.mask_stride);
+        }
+        if (opt.img_pred) memcpy(opt.img_pred + (size_t)o * opt.pred_stride, s.h_pred.as<unsigned char>() + (size_t)i * opt.pred_stride, (size_t)opt.pred_stride);
+        if (opt.det_mask && opt.mask_stats) {
+            const long long inter = (long long)hstat[3 * i], dc = (long long)hstat[3 * i + 1], vc = (long long)hstat[3 * i + 2];
+            opt.mask_stats[3 * o] = inter; opt.mask_stats[3 * o + 1] = dc + vc - inter; opt.mask_stats[3 * o + 2] = vc;
+        }
+    }
+}
+
 static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
                         const p2p_detection* dets, int n, p2p_pose* poses, const p2p_est_pose_opts& opt, int* async_ticket)
 {
@@ -599,8 +640,16 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         set_error("an asynchronous batch (ticket %d) is in flight: collect it before a blocking call", SL.ticket);
         return P2P_ERR_CAPACITY;
     }
-    if (async && (opt.valid_mask || opt.img_pred || opt.dbg_x1 || opt.dbg_x2 || opt.dbg_boxes2 || opt.dbg_cand || opt.det_mask)) {
-        set_error("optional mask / debug outputs are only available from the blocking call");
+    if (async && (opt.dbg_x1 || opt.dbg_x2 || opt.dbg_boxes2 || opt.dbg_cand)) {
+        set_error("the debug taps are only available from the blocking call");
+        return P2P_ERR_INVALID_ARG;
+    }
+    if (opt.ransac_iterations > P2P_MAX_RANSAC_ITERATIONS) {
+        set_error("ransac_iterations %d exceeds P2P_MAX_RANSAC_ITERATIONS (%d)", opt.ransac_iterations, P2P_MAX_RANSAC_ITERATIONS);
+        return P2P_ERR_INVALID_ARG;
+    }
+    if ((opt.det_mask != nullptr) != (opt.mask_stats != nullptr)) {
+        set_error("det_mask and mask_stats go together");
         return P2P_ERR_INVALID_ARG;
     }
 
@@ -767,6 +816,25 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         if ((rc = inject(opt.inject2, y2, (size_t)K * 16384 * 4))) return rc;
     }
 
+    // -- optional outputs: argument checks and the detector-mask upload come first (context stream), so that the
+    //    tail below only has kernels and D2H copies
+    const bool want_mask = opt.valid_mask != nullptr, want_pred = opt.img_pred != nullptr, want_iou = opt.det_mask != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const long long hw = (long long)hd[i].H * hd[i].W;
+        if (want_mask && hw > opt.mask_stride) { set_error("mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
+        if (want_iou && hw > opt.det_mask_stride) { set_error("det_mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
+    }
+    if (want_mask && ((rc = SL.mask.reserve((size_t)opt.mask_stride * n)) || (rc = SL.h_mask.reserve((size_t)opt.mask_stride * n)))) return rc;
+    if (want_pred && ((rc = SL.pred.reserve((size_t)opt.pred_stride * n)) || (rc = SL.h_pred.reserve((size_t)opt.pred_stride * n)))) return rc;
+    if (want_iou) {
+        if ((rc = SL.dmask.reserve((size_t)opt.det_mask_stride * n)) || (rc = SL.mstat.reserve(sizeof(unsigned long long) * 3 * n)) ||
+            (rc = SL.h_stat.reserve(sizeof(unsigned long long) * 3 * n))) return rc;
+        for (int i = 0; i < n; ++i)      // caller order -> sorted order
+            HIP_TRY(hipMemcpyAsync(SL.dmask.as<unsigned char>() + (size_t)i * opt.det_mask_stride,
+                                   opt.det_mask + (size_t)perm[i] * opt.det_mask_stride, (size_t)hd[i].H * hd[i].W,
+                                   hipMemcpyHostToDevice, st));
+    }
+
     // -- correspondences, PnP-RANSAC, selection
     hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
                        SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>());
@@ -793,53 +861,40 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     }
     p2p_pose* hp = SL.host_poses;
     HIP_TRY(hipMemcpyAsync(hp, SL.poses.p, sizeof(p2p_pose) * n, hipMemcpyDeviceToHost, ts));
+
+    // -- optional outputs of the reference's return tuple (recognition.py:189-193: img_pred_f, valid_mask_full) and the
+    //    score_type-2 mask sums: rendered on the tail stream, landed in the slot's pinned buffers, handed over by finish_batch()
+    if (want_mask || want_pred) {
+        if (want_mask) HIP_TRY(hipMemsetAsync(SL.mask.p, 0, (size_t)opt.mask_stride * n, ts));
+        if (want_pred) HIP_TRY(hipMemsetAsync(SL.pred.p, 0, (size_t)opt.pred_stride * n, ts));
+        hipLaunchKernelGGL(render_best_kernel, dim3(64, n), dim3(256), 0, ts, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
+                           want_mask ? SL.mask.as<unsigned char>() : nullptr, (long long)opt.mask_stride,
+                           want_pred ? SL.pred.as<unsigned char>() : nullptr, (long long)opt.pred_stride);
+        HIP_TRY(hipGetLastError());
+        if (want_mask) HIP_TRY(hipMemcpyAsync(SL.h_mask.p, SL.mask.p, (size_t)opt.mask_stride * n, hipMemcpyDeviceToHost, ts));
+        if (want_pred) HIP_TRY(hipMemcpyAsync(SL.h_pred.p, SL.pred.p, (size_t)opt.pred_stride * n, hipMemcpyDeviceToHost, ts));
+    }
+    if (want_iou) {
+        HIP_TRY(hipMemsetAsync(SL.mstat.p, 0, sizeof(unsigned long long) * 3 * n, ts));
+        hipLaunchKernelGGL(mask_iou_kernel, dim3(32, n), dim3(256), 0, ts, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
+                           SL.dmask.as<unsigned char>(), (long long)opt.det_mask_stride, SL.mstat.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(SL.h_stat.p, SL.mstat.p, sizeof(unsigned long long) * 3 * n, hipMemcpyDeviceToHost, ts));
+    }
+    SL.perm = perm;
+    SL.n = n;
+    SL.opt = opt;
+    SL.img_hw.resize(n);
+    for (int i = 0; i < n; ++i) SL.img_hw[i] = hd[i].H * hd[i].W;
     if (async) {
         HIP_TRY(hipEventRecord(SL.done, ts));
         // the slot's buffers are rewritten by the batch after next on the context stream
-        SL.perm = perm;
-        SL.n = n;
         SL.ticket = P.next_ticket;
         *async_ticket = P.next_ticket++;
         return P2P_OK;
     }
 
-    // -- optional outputs
-    std::vector<unsigned char> hmask, hpred;
-    if (opt.valid_mask || opt.img_pred) {
-        if (opt.valid_mask) {
-            if ((rc = P.mask.reserve((size_t)opt.mask_stride * n))) return rc;
-            HIP_TRY(hipMemsetAsync(P.mask.p, 0, (size_t)opt.mask_stride * n, st));
-        }
-        if (opt.img_pred) {
-            if ((rc = P.pred.reserve((size_t)opt.pred_stride * n))) return rc;
-            HIP_TRY(hipMemsetAsync(P.pred.p, 0, (size_t)opt.pred_stride * n, st));
-        }
-        for (int i = 0; i < n; ++i)
-            if (opt.valid_mask && (long long)hd[i].H * hd[i].W > opt.mask_stride) { set_error("mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
-        hipLaunchKernelGGL(render_best_kernel, dim3(64, n), dim3(256), 0, st, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
-                           opt.valid_mask ? P.mask.as<unsigned char>() : nullptr, (long long)opt.mask_stride,
-                           opt.img_pred ? P.pred.as<unsigned char>() : nullptr, (long long)opt.pred_stride);
-        HIP_TRY(hipGetLastError());
-        if (opt.valid_mask) { hmask.resize((size_t)opt.mask_stride * n); HIP_TRY(hipMemcpyAsync(hmask.data(), P.mask.p, hmask.size(), hipMemcpyDeviceToHost, st)); }
-        if (opt.img_pred) { hpred.resize((size_t)opt.pred_stride * n); HIP_TRY(hipMemcpyAsync(hpred.data(), P.pred.p, hpred.size(), hipMemcpyDeviceToHost, st)); }
-    }
-    std::vector<unsigned long long> hstat;
-    if (opt.det_mask && opt.mask_stats) {
-        for (int i = 0; i < n; ++i)
-            if ((long long)hd[i].H * hd[i].W > opt.det_mask_stride) { set_error("det_mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
-        if ((rc = P.dmask.reserve((size_t)opt.det_mask_stride * n))) return rc;
-        if ((rc = P.mstat.reserve(sizeof(unsigned long long) * 3 * n))) return rc;
-        for (int i = 0; i < n; ++i)      // caller order -> sorted order
-            HIP_TRY(hipMemcpyAsync(P.dmask.as<unsigned char>() + (size_t)i * opt.det_mask_stride,
-                                   opt.det_mask + (size_t)perm[i] * opt.det_mask_stride, (size_t)hd[i].H * hd[i].W,
-                                   hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(P.mstat.p, 0, sizeof(unsigned long long) * 3 * n, st));
-        hipLaunchKernelGGL(mask_iou_kernel, dim3(32, n), dim3(256), 0, st, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
-                           P.dmask.as<unsigned char>(), (long long)opt.det_mask_stride, P.mstat.as<unsigned long long>());
-        HIP_TRY(hipGetLastError());
-        hstat.resize((size_t)3 * n);
-        HIP_TRY(hipMemcpyAsync(hstat.data(), P.mstat.p, sizeof(unsigned long long) * 3 * n, hipMemcpyDeviceToHost, st));
-    }
+    // -- debug taps (blocking call only)
     std::vector<float> hx1, hx2;
     std::vector<Stage1> hs1;
     std::vector<CandStat> hcs;
@@ -853,16 +908,9 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         HIP_TRY(hipMemcpyAsync(hres.data(), SL.results.p, sizeof(PnpResult) * n * K, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
-
+    finish_batch(SL, poses);
     for (int i = 0; i < n; ++i) {
         const int o = perm[i];
-        poses[o] = hp[i];
-        if (opt.valid_mask) memcpy(opt.valid_mask + (size_t)o * opt.mask_stride, hmask.data() + (size_t)i * opt.mask_stride, opt.mask_stride);
-        if (opt.img_pred) memcpy(opt.img_pred + (size_t)o * opt.pred_stride, hpred.data() + (size_t)i * opt.pred_stride, opt.pred_stride);
-        if (!hstat.empty()) {
-            const long long inter = (long long)hstat[3 * i], dc = (long long)hstat[3 * i + 1], vc = (long long)hstat[3 * i + 2];
-            opt.mask_stats[3 * o] = inter; opt.mask_stats[3 * o + 1] = dc + vc - inter; opt.mask_stats[3 * o + 2] = vc;
-        }
         if (opt.dbg_x1) memcpy(opt.dbg_x1 + (size_t)o * 16384 * 3, hx1.data() + (size_t)i * 16384 * 3, 16384 * 3 * 4);
         if (opt.dbg_x2) memcpy(opt.dbg_x2 + (size_t)o * K * 16384 * 3, hx2.data() + (size_t)i * K * 16384 * 3, (size_t)K * 16384 * 3 * 4);
         if (opt.dbg_boxes2) memcpy(opt.dbg_boxes2 + (size_t)o * 12, &hs1[i].b2, sizeof(Boxes));
@@ -883,7 +931,7 @@ static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses)
     for (Slot& s : X.pipe->slot)
         if (s.ticket == ticket) {
             HIP_TRY(hipEventSynchronize(s.done));
-            for (int i = 0; i < s.n; ++i) poses[s.perm[i]] = s.host_poses[i];
+            finish_batch(s, poses);
             s.ticket = -1;
             return P2P_OK;
         }
@@ -942,6 +990,10 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
 {
     if (!ctx || n_problems < 0 || (n_problems > 0 && (!camK || !obj_pts || !img_pts || !offsets || !R || !t || !info || !ok))) {
         set_error("p2p_pnp_ransac_batch: bad arguments");
+        return P2P_ERR_INVALID_ARG;
+    }
+    if (iterations > P2P_MAX_RANSAC_ITERATIONS) {
+        set_error("p2p_pnp_ransac_batch: iterations %d exceeds P2P_MAX_RANSAC_ITERATIONS (%d)", iterations, P2P_MAX_RANSAC_ITERATIONS);
         return P2P_ERR_INVALID_ARG;
     }
     if (n_problems == 0) return P2P_OK;

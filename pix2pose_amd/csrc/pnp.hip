@@ -746,7 +746,7 @@ __device__ __forceinline__ bool is_inlier(const double* R, const double* t, cons
     return err <= thr2;
 }
 
-constexpr int MAX_ITERS = 128;
+constexpr int MAX_ITERS = P2P_MAX_RANSAC_ITERATIONS;   // the entry points reject larger requests
 
 // State handed from the scoring kernel to the refit kernels (one record per problem).
 struct PnpFit {

@@ -168,10 +168,9 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
     by_image = {(im["scene_id"], im["im_id"]): im for im in dump["images"]}
     rows = []
     tlist = group_targets(dump["targets"])
-    for b0 in range(0, len(tlist), batch_images):
-        chunk = tlist[b0:b0 + batch_images]
+
+    def prepare(chunk):
         frames, dets, det_masks, owners = [], [], [], []
-        t1 = time.time()
         for ti, (scene_id, im_id, obj_id_targets, inst_counts) in enumerate(chunk):
             im = by_image.get((scene_id, im_id))
             if im is None:
@@ -187,10 +186,12 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
                     if masks is None:
                         raise ValueError("score_type 2 needs detector masks for scene %s image %s" % (scene_id, im_id))
                     det_masks.append(masks[:, :, r_id])
-        if not dets:
-            continue
-        poses, ex = runtime.est_pose_batch(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
-                                           **(est_pose_kwargs or {}))
+        return frames, dets, det_masks, owners
+
+    def finish(job):
+        chunk, owners, pending, t1 = job
+        poses = pending.collect()
+        ex = pending.extras
         dt = time.time() - t1
         per_image = {}
         for k, (ti, r_id) in enumerate(owners):
@@ -205,8 +206,25 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
                                                  "R": np.array(p.R).reshape(3, 3), "t": np.array(p.t)})
         for ti, (scene_id, im_id, obj_id_targets, inst_counts) in enumerate(chunk):
             n_here = sum(1 for o in owners if o[0] == ti)
-            rows += rank_image_results(per_image.get(ti, []), obj_id_targets, inst_counts, task_type, scene_id, im_id,
-                                       dt * n_here / max(len(owners), 1))    # batch time amortised over its detections
+            rows.extend(rank_image_results(per_image.get(ti, []), obj_id_targets, inst_counts, task_type, scene_id, im_id,
+                                           dt * n_here / max(len(owners), 1)))   # batch time amortised over its detections
+
+    # detection stream: chunk i+1 is read from disk and enqueued (p2p_est_pose_submit) while chunk i is on the GPU;
+    # the score_type-2 mask sums come back through the same asynchronous call
+    in_flight = []
+    for b0 in range(0, len(tlist), batch_images):
+        chunk = tlist[b0:b0 + batch_images]
+        t1 = time.time()
+        frames, dets, det_masks, owners = prepare(chunk)
+        if not dets:
+            continue
+        pending = runtime.est_pose_submit(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
+                                          **(est_pose_kwargs or {}))
+        in_flight.append((chunk, owners, pending, t1))
+        if len(in_flight) == 2:
+            finish(in_flight.pop(0))
+    while in_flight:
+        finish(in_flight.pop(0))
     out_dir = cfg.get("path_to_output")
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)

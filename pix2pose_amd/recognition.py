@@ -65,6 +65,7 @@ class pix2pose():
         weights = weight_fn if isinstance(weight_fn, dict) else W.load_weights(weight_fn, backbone)
         self.ctx = ctx
         self.generator_train = runtime.Generator(weights, backbone, ctx)
+        self._inject = None                    # TEST / BENCH ONLY: (inject1_ptr, inject2_ptr, slots) device maps that replace the decoder outputs
 
     def _spec(self):
         return runtime.ObjectSpec(self.generator_train, np.concatenate([np.asarray(self.obj_scale, float),
@@ -79,8 +80,9 @@ class pix2pose():
         or (placeholder, -1, -1, -1, -1, box) on failure (reference recognition.py:79,127,191,193)."""
         rgb = np.asarray(rgb)
         H, Wd = rgb.shape[0], rgb.shape[1]
+        inj = {} if self._inject is None else dict(inject1=self._inject[0], inject2=self._inject[1], inject_slots=self._inject[2])
         poses, ex = runtime.est_pose_batch(self.ctx, [self._spec()], [rgb], [(0, 0, [int(b) for b in bbox], self.camK)],
-                                           want_masks=True)
+                                           want_masks=True, **inj)
         p = poses[0]
         box = np.array(list(p.bbox_t), int)
         if p.status != 0:

@@ -172,14 +172,14 @@ def _image_struct(img):
     return s, a
 
 
-def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
-                   want_masks=False, debug=False, ransac_iterations=0, reprojection_error=0.0, confidence=0.0,
-                   det_masks=None):
-    """detections: list of (image_idx, object_idx, bbox[v1,u1,v2,u2], camK 3x3).
-    Returns (poses: list[_lib.Pose], extras: dict)."""
+def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks, det_masks, ransac_iterations,
+             reprojection_error, confidence):
+    """Build the C arrays of one batch call.  -> (objs, imgs, dets, opts, extras, keep-alive list)"""
     n = len(detections)
+    if ransac_iterations > _lib.MAX_RANSAC_ITERATIONS:
+        raise ValueError("ransac_iterations %d exceeds the library's limit of %d" % (ransac_iterations, _lib.MAX_RANSAC_ITERATIONS))
     objs = (_lib.Object * max(len(objects), 1))(*[o.as_struct() for o in objects])
-    keep = []
+    keep = [objects, images]
     imgs = (_lib.Image * max(len(images), 1))()
     for i, im in enumerate(images):
         imgs[i], a = _image_struct(im)
@@ -192,12 +192,10 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
         Kf = np.asarray(K, np.float64).reshape(9)
         for k in range(9):
             dets[i].camK[k] = Kf[k]
-    poses = (_lib.Pose * max(n, 1))()
     opts = _lib.EstPoseOpts()
     opts.ransac_iterations, opts.reprojection_error, opts.confidence = ransac_iterations, reprojection_error, confidence
     opts.inject1, opts.inject2, opts.inject_slots = inject1, inject2, inject_slots
     extras = {}
-    K = max([len(o.th_outlier) for o in objects], default=0)
     if want_masks and n:
         def hw(i):
             im = images[detections[i][0]]
@@ -218,6 +216,19 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
         extras["_dm"] = dm
         opts.det_mask, opts.det_mask_stride = dm.ctypes.data, dms
         opts.mask_stats = extras["mask_stats"].ctypes.data
+    return objs, imgs, dets, opts, extras, keep
+
+
+def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
+                   want_masks=False, debug=False, ransac_iterations=0, reprojection_error=0.0, confidence=0.0,
+                   det_masks=None):
+    """detections: list of (image_idx, object_idx, bbox[v1,u1,v2,u2], camK 3x3).
+    Returns (poses: list[_lib.Pose], extras: dict)."""
+    n = len(detections)
+    objs, imgs, dets, opts, extras, keep = _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks,
+                                                    det_masks, ransac_iterations, reprojection_error, confidence)
+    poses = (_lib.Pose * max(n, 1))()
+    K = max([len(o.th_outlier) for o in objects], default=0)
     if debug and n:
         extras["x1"] = np.zeros((n, 128, 128, 3), np.float32)
         extras["x2"] = np.zeros((n, K, 128, 128, 3), np.float32)
@@ -231,13 +242,14 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
 
 
 class PendingBatch:
-    """Handle of a batch enqueued with est_pose_submit (keeps the argument buffers alive)."""
+    """Handle of a batch enqueued with est_pose_submit (keeps the argument and output buffers alive)."""
 
-    def __init__(self, ctx, ticket, n, keep):
-        self.ctx, self.ticket, self.n, self._keep = ctx, ticket, n, keep
+    def __init__(self, ctx, ticket, n, keep, extras):
+        self.ctx, self.ticket, self.n, self._keep, self.extras = ctx, ticket, n, keep, extras
 
     def collect(self):
-        """Wait for the batch; -> list of p2p_pose records in the caller's detection order."""
+        """Wait for the batch; -> list of p2p_pose records in the caller's detection order.  The optional outputs
+        requested at submit time (valid_mask / img_pred / mask_stats) are in ``self.extras`` afterwards."""
         poses = (_lib.Pose * max(self.n, 1))()
         _lib.check(_lib.lib().p2p_est_pose_collect(self.ctx.handle, self.ticket, poses), "p2p_est_pose_collect")
         self._keep = None
@@ -245,32 +257,18 @@ class PendingBatch:
 
 
 def est_pose_submit(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
-                    ransac_iterations=0, reprojection_error=0.0, confidence=0.0) -> PendingBatch:
+                    ransac_iterations=0, reprojection_error=0.0, confidence=0.0, want_masks=False, det_masks=None) -> PendingBatch:
     """Asynchronous est_pose_batch for detection streams: enqueue and return; at most two batches in
-    flight per context.  The PnP-RANSAC tail of this batch overlaps the generator passes of the next."""
+    flight per context.  The PnP-RANSAC tail of this batch overlaps the generator passes of the next.
+    ``want_masks`` / ``det_masks`` as in est_pose_batch: the arrays in ``PendingBatch.extras`` are filled by collect()."""
     n = len(detections)
-    objs = (_lib.Object * max(len(objects), 1))(*[o.as_struct() for o in objects])
-    keep = [objs, objects]
-    imgs = (_lib.Image * max(len(images), 1))()
-    for i, im in enumerate(images):
-        imgs[i], a = _image_struct(im)
-        keep.append(a)
-    dets = (_lib.Detection * max(n, 1))()
-    for i, (ii, oi, bbox, K) in enumerate(detections):
-        dets[i].image, dets[i].object = int(ii), int(oi)
-        for k in range(4):
-            dets[i].bbox[k] = int(bbox[k])
-        Kf = np.asarray(K, np.float64).reshape(9)
-        for k in range(9):
-            dets[i].camK[k] = Kf[k]
-    opts = _lib.EstPoseOpts()
-    opts.ransac_iterations, opts.reprojection_error, opts.confidence = ransac_iterations, reprojection_error, confidence
-    opts.inject1, opts.inject2, opts.inject_slots = inject1, inject2, inject_slots
+    objs, imgs, dets, opts, extras, keep = _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks,
+                                                    det_masks, ransac_iterations, reprojection_error, confidence)
     ticket = C.c_int(-1)
     _lib.check(_lib.lib().p2p_est_pose_submit(ctx.handle, objs, len(objects), imgs, len(images), dets, n, C.byref(opts),
                                               C.byref(ticket)), "p2p_est_pose_submit")
-    keep += [imgs, dets, images]
-    return PendingBatch(ctx, ticket.value, n, keep)
+    keep += [objs, imgs, dets, opts]
+    return PendingBatch(ctx, ticket.value, n, keep, extras)
 
 
 def pnp_ransac_batch(ctx: Context, Ks, objs, imgs, iterations=100, reproj_err=5.0, confidence=0.99, want_mask=False):

@@ -23,7 +23,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libp2p_mi355.so does not export %s" % n
-    assert _lib.lib().p2p_abi_version() == 2
+    assert _lib.lib().p2p_abi_version() == _lib.ABI_VERSION
 
 
 def test_no_gpu_fails_loudly_not_silently():
