@@ -165,7 +165,10 @@ def main():
     ap.add_argument("--f32-steps", type=int, default=3, help="steps of the strict-fp32 leg (N=1, single object; 0 = skip)")
     ap.add_argument("--host-frames", type=int, default=3, help="steps of the host-frame leg (N=1; 0 = skip)")
     ap.add_argument("--latency", type=int, default=100, help="calls of the single-detection latency leg (N=1; 0 = skip)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the f32 / host-frame / latency / CPU legs (profiling runs)")
     args = ap.parse_args()
+    if args.no_legs:
+        args.f32_steps = args.host_frames = args.latency = args.cpu_sample = 0
     args.overlap = not args.blocking
     args.inflight = max(1, min(args.inflight, 2))
 

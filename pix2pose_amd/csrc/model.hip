@@ -127,12 +127,15 @@ static float f16_to_f32(uint16_t h)
 static bool specialised_kernels() { static const bool on = getenv("P2P_NO_HALO") == nullptr; return on; }
 
 static thread_local int g_pack_prec = PREC_F32;   // precision of the model being packed (build_model)
-// Power-of-two pre-scale of a layer's weights for the split: the largest |w| lands in [2^13, 2^14)
-// (f16 max is 65504), so the lo parts of all but vanishing weights stay in the f16 normal range.
-static float f16x3_weight_scale(const std::vector<float>& w)
+// Power-of-two pre-scale of ONE OUTPUT CHANNEL's weights for the split: the largest |w| of the row lands in
+// [2^13, 2^14) (f16 max is 65504), so the lo parts of all but vanishing weights stay in the f16 normal range.
+// Per row, not per layer: in a trained network the rows of one layer differ by orders of magnitude (BatchNorm
+// variances spread over decades, and the folded BN scale then multiplies a small row's rounding error back up);
+// the epilogue scale is per output channel anyway and carries the inverse.
+static float f16x3_row_scale(const float* w, size_t n, size_t stride = 1)
 {
     float m = 0.f;
-    for (float v : w) m = std::max(m, std::fabs(v));
+    for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(w[i * stride]));
     if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
     int e = 0;
     std::frexp(m, &e);                 // m = f * 2^e, f in [0.5, 1)
@@ -140,23 +143,26 @@ static float f16x3_weight_scale(const std::vector<float>& w)
 }
 
 // fp32 panel [rows][K] -> split-f16 panel of the same byte size: per row and 32-wide K-step the image
-// [hi x32 | lo x32], hi = f16(w * s), lo = f16(w * s - hi), s = F16X3_WEIGHT_SCALE (a power of two).
-// The epilogue scale carries 1/s.
-static std::vector<float> split_panel(const std::vector<float>& w, int K, float F16X3_WEIGHT_SCALE)
+// [hi x32 | lo x32], hi = f16(w * s_row), lo = f16(w * s_row - hi), s_row a power of two (row_scale[r]).
+// The epilogue scale carries 1/s_row.
+static std::vector<float> split_panel(const std::vector<float>& w, int K, std::vector<float>& row_scale)
 {
     std::vector<float> out(w.size());
     uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
     const size_t rows = w.size() / K;
-    for (size_t r = 0; r < rows; ++r)
+    row_scale.assign(rows, 1.f);
+    for (size_t r = 0; r < rows; ++r) {
+        const float sc = row_scale[r] = f16x3_row_scale(w.data() + r * K, (size_t)K);
         for (int k0 = 0; k0 < K; k0 += 32) {
             uint16_t* blk = o + (r * K + k0) * 2;
             for (int k = 0; k < 32; ++k) {
-                const float v = w[r * K + k0 + k] * F16X3_WEIGHT_SCALE;
+                const float v = w[r * K + k0 + k] * sc;
                 const uint16_t hi = f32_to_f16(v);
                 blk[k] = hi;
                 blk[32 + k] = f32_to_f16(v - f16_to_f32(hi));
             }
         }
+    }
     return out;
 }
 
@@ -165,10 +171,11 @@ static int finish_layer(ConvLayer& L, const std::vector<float>& w, const std::ve
 {
     int rc;
     if (L.prec == PREC_F16X3) {
-        const float ws = f16x3_weight_scale(w);
+        std::vector<float> rs;
+        std::vector<float> panel = split_panel(w, L.K, rs);
         std::vector<float> sc(scale);
-        for (float& v : sc) v *= 1.f / ws;          // exact: ws is a power of two
-        if ((rc = upload(split_panel(w, L.K, ws), &L.w))) return rc;
+        for (size_t c = 0; c < sc.size(); ++c) sc[c] *= 1.f / rs[c];          // exact: a power of two
+        if ((rc = upload(panel, &L.w))) return rc;
         if ((rc = upload(sc, &L.scale))) return rc;
     } else {
         if ((rc = upload(w, &L.w))) return rc;
@@ -230,19 +237,19 @@ static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& n
     }
     if (g_pack_prec == PREC_F16X3 && KH == 7 && L.Cout == 64 && specialised_kernels()) {
         // matrix-core variant (conv1.hip): split-f16 panel in that kernel's own layout; L.prec marks it
-        const float ws = f16x3_weight_scale(w);
-        std::vector<float> panel(conv1_f16x3_panel_floats(), 0.f), sc(scale);
+        std::vector<float> panel(conv1_f16x3_panel_floats(), 0.f), sc(scale), ws(64);
+        for (int co = 0; co < 64; ++co) ws[co] = f16x3_row_scale(w.data() + co, (size_t)L.K, (size_t)L.Cout);   // per output channel
         uint16_t* o = reinterpret_cast<uint16_t*>(panel.data());
         for (int kh = 0; kh < 7; ++kh)
             for (int kw = 0; kw < 7; ++kw)
                 for (int c = 0; c < 3; ++c)
                     for (int co = 0; co < 64; ++co) {
-                        const float v = w[(size_t)((kh * 7 + kw) * 3 + c) * L.Cout + co] * ws;
+                        const float v = w[(size_t)((kh * 7 + kw) * 3 + c) * L.Cout + co] * ws[co];
                         const uint16_t hi = f32_to_f16(v);
                         o[conv1_f16x3_panel_index(kh, 0, kw, c, co)] = hi;
                         o[conv1_f16x3_panel_index(kh, 1, kw, c, co)] = f32_to_f16(v - f16_to_f32(hi));
                     }
-        for (float& v : sc) v *= 1.f / ws;
+        for (int co = 0; co < 64; ++co) sc[co] *= 1.f / ws[co];
         L.prec = PREC_F16X3;
         int rc;
         if ((rc = upload(panel, &L.w))) return rc;

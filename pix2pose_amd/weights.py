@@ -185,6 +185,36 @@ def synthetic_weights(backbone: str, seed: int = 1) -> dict:
     return out
 
 
+def trained_like_weights(backbone: str, seed: int = 1) -> dict:
+    """Synthetic weights with the statistics of a TRAINED network instead of a freshly initialised one: BatchNorm moving
+    variances spread over four decades (log-uniform 1e-3 .. 1e1), gammas log-uniform 0.05 .. 2, and every layer's kernel /
+    bias / moving mean rescaled per output channel so that its pre-BN activations really have that variance (which is what
+    training produces: BN statistics follow the layer, not the other way round).  The network function stays O(1) -- the
+    per-channel factors cancel inside BN up to the eps term -- but the operands the kernels see do not: weight rows differ by
+    two decades within a layer and the folded BN scales by three.  Used by the precision tests of the split-f16 arithmetic."""
+    w = synthetic_weights(backbone, seed)
+    for stream, (name, shape) in enumerate(tensor_specs(backbone)):
+        if not name.endswith(".var"):
+            continue
+        base = name[:-4]
+        c = shape[0]
+        u1 = hash_uniform(seed + 7919, stream, c)
+        u2 = hash_uniform(seed + 104729, stream, c)
+        var = np.exp(np.log(1e-3) + u1 * (np.log(1e1) - np.log(1e-3)))
+        gamma_hi = 0.8 if base.endswith("_2c") else 2.0          # residual-branch outputs stay damped (seven stacked blocks)
+        gamma = np.exp(np.log(0.05) + u2 * (np.log(gamma_hi) - np.log(0.05)))
+        f = np.sqrt(var / w[name].astype(np.float64))             # per-channel factor on the pre-BN activation
+        k = w[base + ".kernel"].astype(np.float64)
+        is_t = k.ndim == 4 and (base.startswith("up") or base.startswith("head_"))
+        k = k * (f[None, None, :, None] if is_t else f)           # Conv2DTranspose kernels are (kh,kw,Cout,Cin)
+        w[base + ".kernel"] = k.astype(np.float32)
+        w[base + ".bias"] = (w[base + ".bias"].astype(np.float64) * f).astype(np.float32)
+        w[base + ".mean"] = (w[base + ".mean"].astype(np.float64) * f).astype(np.float32)
+        w[name] = var.astype(np.float32)
+        w[base + ".gamma"] = gamma.astype(np.float32)
+    return w
+
+
 def check_weights(backbone: str, w: dict) -> None:
     """Raise ValueError on a missing / mis-shaped tensor."""
     for name, shape in tensor_specs(backbone):
@@ -201,6 +231,11 @@ def save_weights(path: str, backbone: str, w: dict) -> None:
 
 def load_weights(weight_fn: str, backbone: str) -> dict:
     """``weight_fn`` is a ``.npz`` artefact or ``synthetic:<backbone>:<seed>``."""
+    if weight_fn.startswith("trained-like:"):
+        _, bb, seed = weight_fn.split(":")
+        if bb != backbone:
+            raise ValueError("weights are for backbone %r, not %r" % (bb, backbone))
+        return trained_like_weights(backbone, int(seed))
     if weight_fn.startswith("synthetic:"):
         parts = weight_fn.split(":")
         bb = parts[1] if len(parts) > 1 and parts[1] else backbone

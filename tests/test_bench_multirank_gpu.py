@@ -1,0 +1,44 @@
+"""bench.py's multi-rank path on ONE GPU: `python bench.py --gpus 2` from a plain shell (no launcher) starts its own
+ranks, every rank runs the whole pipeline on its shard, the (R, t, score) records are all-gathered inside the timed step
+and rank 0 prints the one JSON line.  With a single device the ranks share cuda:0 and talk over gloo
+(--backend gloo --same-device); on an 8-GPU node the same code path runs one rank per GPU over RCCL.
+Detections are independent in the reference (tools/5_evaluation_bop_basic.py:289-304), so there is no data-path
+collective to test -- only the launch, the sharded seeds, the gather and the max-over-ranks timing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*extra, timeout=1500):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+                        "--steps", "2", "--warmup", "1", "--cpu-sample", "0"] + list(extra),
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_self_launched():
+    out = _bench()
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["gathered_records"] == 512                 # 256 detections per rank, all-gathered
+    assert out["config"]["detections_per_gpu"] == 256 and out["config"]["parallelism"] == "dp2"
+    assert out["poses_ok"] >= 250 and out["value"] > 0
+    assert out["cpu_baseline"] is None and "roofline" in out
+
+
+def test_bench_two_ranks_configs3_shape():
+    """BASELINE.json configs[3]'s shape: the detections of every rank spread over 30 object models."""
+    out = _bench("--objects", "30", "--chunk", "512")
+    assert out["n_gpus"] == 2 and out["gathered_records"] == 512
+    assert out["config"]["objects"] == 30 and "configs[3]" in out["config"]["workload"]
+    assert out["poses_ok"] >= 245

@@ -1,7 +1,8 @@
-"""BASELINE.json full-size properties (configs[1]: batch 64 generator; configs[2]: 256 detections
-+ 768 PnP solves) through size-independent invariants -- the oracle is too slow at these sizes:
-determinism, chunking invariance, batch-order (permutation) invariance, batch-composition
-independence, and agreement with ground truth of the synthetic scene."""
+"""BASELINE.json full sizes.  configs[1] (batch-64 generator): chunking invariance, device-pointer path.  configs[2]
+(256 detections + 768 PnP solves): EVERY detection against the oracle (the injected pipeline and PnP are fast on the
+CPU), plus determinism, batch-order and batch-composition invariance and agreement with the scene's ground truth.
+configs[3] single-GPU share (30 resnet50 objects x 256 detections): the grouped generator pass == per-object passes bit
+for bit, oracle on a 16-detection subset.  The asynchronous API returns the full reference tuple."""
 import numpy as np
 import pytest
 
@@ -70,6 +71,69 @@ def test_est_pose_256_detections_invariants():
         R = np.array(p.R).reshape(3, 3)
         assert abs(np.linalg.det(R) - 1) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
         assert 0 < p.frac_inlier <= 4.0 and p.n_inliers >= 5
+    # every one of the 256 detections against the oracle: status, counts, selected candidate, box exactly; pose to rounding
+    _check_against_oracle(sc, p1, range(256))
+
+
+def _check_against_oracle(sc, poses, idx, th_o=TH_O, th_i=TH_I, obj_param=None):
+    from oracle import est_pose_oracle as E
+    n_ok = 0
+    for i in idx:
+        def predict(x, stage, slots=None, i=i):
+            m = sc["inject1"][i][None] if stage == 1 else sc["inject2"][i][slots]
+            return [m[..., :3].copy(), m[..., 3:].copy()]
+        img_i, _, bbox, K = sc["dets"][i]
+        dbg = {}
+        ref = E.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"] if obj_param is None else obj_param, th_o, th_i, debug=dbg)
+        p = poses[i]
+        ok_ref = not (isinstance(ref[4], int) and ref[4] == -1)
+        assert (p.status == 0) == ok_ref, (i, p.status)
+        np.testing.assert_array_equal(np.array(list(p.bbox_t)), ref[5])
+        assert p.n_init_mask == dbg.get("n_init_mask", p.n_init_mask), i
+        if ok_ref:
+            n_ok += 1
+            assert abs(p.frac_inlier - ref[4]) < 1e-12, (i, p.frac_inlier, ref[4])
+            assert p.best_slot == dbg["slots"][dbg["best"]], i
+            assert p.n_inliers == dbg["cands"][dbg["best"]]["n_inliers"], i
+            dt, dr = S.pose_error(ref[2], ref[3], np.array(p.R).reshape(3, 3), np.array(p.t))
+            assert dt < 1e-6 and dr < 1e-4, (i, dt, dr)
+    return n_ok
+
+
+def test_configs3_share_30_objects_256_detections():
+    """BASELINE.json configs[3] on one GPU: 256 detections spread over 30 resnet50 object models (per-object weights,
+    per-object obj_param), one grouped generator pass per stage.  (a) equals the 30 per-object passes bit for bit;
+    (b) equals the oracle on a 16-detection subset; (c) the real (non-injected) generator output of the grouped pass
+    equals the per-object generator output bit for bit (stage-2 inputs and candidate counts through the debug taps)."""
+    import torch
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
+    n_obj, n_det = 30, 256
+    ctx = Context(0, max_batch=1024)
+    params = [S.OBJ_PARAM * (1.0 + 0.02 * k) for k in range(n_obj)]
+    specs = [ObjectSpec(Generator(W.synthetic_weights("resnet50", 100 + k), "resnet50", ctx), params[k], TH_O, TH_I) for k in range(n_obj)]
+    sc = S.make_scene(n_det, seed=31)
+    obj_of = [(7 * i + 3) % n_obj for i in range(n_det)]                  # interleaved: the library sorts by object
+    dets = [(d[0], obj_of[i], d[2], d[3]) for i, d in enumerate(sc["dets"])]
+    j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
+    torch.cuda.synchronize()
+    both = est_pose_batch(ctx, specs, list(sc["images"]), dets, inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3)[0]
+    raw_both = est_pose_batch(ctx, specs, list(sc["images"]), dets, debug=True)[1]       # generator output drives everything
+    for o in range(n_obj):
+        idx = [i for i in range(n_det) if obj_of[i] == o]
+        sub = [(dets[i][0], 0, dets[i][2], dets[i][3]) for i in idx]
+        ii = torch.tensor(idx, device="cuda")
+        a, b = j1[ii].contiguous(), j2[ii].contiguous()
+        torch.cuda.synchronize()
+        alone = est_pose_batch(ctx, [specs[o]], list(sc["images"]), sub, inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3)[0]
+        assert [_key(both[i]) for i in idx] == [_key(x) for x in alone], o
+        raw_alone = est_pose_batch(ctx, [specs[o]], list(sc["images"]), sub, debug=True)[1]
+        for k, i in enumerate(idx):
+            np.testing.assert_array_equal(raw_both["x2"][i], raw_alone["x2"][k])       # depends on the stage-1 network output
+            np.testing.assert_array_equal(raw_both["cand"][i], raw_alone["cand"][k])   # depends on the stage-2 network output
+    # oracle on a subset (per-object obj_param)
+    for i in range(0, n_det, 16):
+        _check_against_oracle(sc, both, [i], obj_param=params[obj_of[i]])
+    assert sum(1 for p in both if p.status == 0) >= 245
 
 
 def test_async_submit_collect_equals_blocking():
@@ -84,17 +148,38 @@ def test_async_submit_collect_equals_blocking():
     scenes = [S.make_scene(24, seed=40 + k) for k in range(4)]
     inj = [(torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()) for sc in scenes]
     torch.cuda.synchronize()
-    ref = [est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3)[0]
-           for sc, (a, b) in zip(scenes, inj)]
+    # detector masks for the score_type-2 sums: a rectangle inside every box
+    dmasks = []
+    for sc in scenes:
+        H, Wd = sc["images"].shape[1:3]
+        ms = []
+        for d in sc["dets"]:
+            m = np.zeros((H, Wd), bool)
+            m[d[2][0] + 10:d[2][2] - 5, d[2][1] + 8:d[2][3] - 12] = True
+            ms.append(m)
+        dmasks.append(ms)
+    ref = [est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3,
+                          want_masks=True, det_masks=dm)
+           for sc, (a, b), dm in zip(scenes, inj, dmasks)]
     pend, got = [], []
-    for sc, (a, b) in zip(scenes, inj):
-        pend.append(est_pose_submit(ctx, [spec], list(sc["images"]), sc["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3))
+    for sc, (a, b), dm in zip(scenes, inj, dmasks):
+        pend.append(est_pose_submit(ctx, [spec], list(sc["images"]), sc["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3,
+                                    want_masks=True, det_masks=dm))
         if len(pend) == 2:
-            got.append(pend.pop(0).collect())
+            pb = pend.pop(0)
+            got.append((pb.collect(), pb.extras))
     while pend:
-        got.append(pend.pop(0).collect())
-    for r, g in zip(ref, got):
-        assert [_key(x) for x in r] == [_key(x) for x in g]
+        pb = pend.pop(0)
+        got.append((pb.collect(), pb.extras))
+    for (rp, rex), (gp, gex) in zip(ref, got):
+        assert [_key(x) for x in rp] == [_key(x) for x in gp]
+        # the full reference tuple comes back from the asynchronous call too (recognition.py:189-193) ...
+        np.testing.assert_array_equal(rex["valid_mask"], gex["valid_mask"])
+        np.testing.assert_array_equal(rex["img_pred"], gex["img_pred"])
+        assert rex["valid_mask"].any() and rex["img_pred"].any()
+        # ... and so do the score_type-2 mask sums (tools/5_evaluation_bop_basic.py:307-316)
+        np.testing.assert_array_equal(rex["mask_stats"], gex["mask_stats"])
+    ref = [r[0] for r in ref]
     # three in flight -> capacity error; blocking call while one is in flight -> error; then recover
     a, b = inj[0]
     p1 = est_pose_submit(ctx, [spec], list(scenes[0]["images"]), scenes[0]["dets"], inject1=a.data_ptr(), inject2=b.data_ptr(), inject_slots=3)

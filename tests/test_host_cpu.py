@@ -155,3 +155,34 @@ def test_pose_gather_world_size_2_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_binding_refuses_a_stale_library(monkeypatch):
+    """A .so built from other sources, or with other struct layouts, must not be loaded silently (it is git-ignored and
+    travels out of band): the binding compares p2p_build_id() with the tree's source hash and p2p_abi_sizeof() with
+    its own ctypes declarations."""
+    from pix2pose_amd import _lib, build
+    build.build()
+    assert _lib._stale_reason(_lib.LIB_PATH) is None
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 32)
+    assert "other sources" in _lib._stale_reason(_lib.LIB_PATH)
+    monkeypatch.undo()
+
+    class Fat(_lib.C.Structure):
+        _fields_ = _lib.Pose._fields_ + [("extra", _lib.C.c_int * 4)]
+    monkeypatch.setattr(_lib, "Pose", Fat)
+    assert "sizeof(Fat)" in _lib._stale_reason(_lib.LIB_PATH)
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher re-executes itself under torch.distributed.run on 127.0.0.1."""
+    import importlib
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(os, "execve", lambda exe, cmd, env: seen.update(exe=exe, cmd=cmd, env=env))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+    bench._self_launch(8)
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -1,9 +1,28 @@
 """GPU parity of the batched HIP EPnP+RANSAC kernel (through p2p_pnp_ransac_batch) against the
-oracle restatement of cv2.solvePnPRansac.  Integer results (inlier counts, winning iteration) are
-expected to match exactly on these well-posed scenes; poses within 1e-6 mm / 1e-6 deg of the
-oracle (north_star bar: 1 mm / 1 deg)."""
+oracle restatement of cv2.solvePnPRansac.  Integer results (inlier sets, iteration counts, winning
+iteration) must match EXACTLY on every problem -- the GPU solver replays OpenCV's sampling order and
+best-so-far rule -- and poses within 1e-6 mm / 1e-4 deg of the oracle (north_star bar: 1 mm / 1 deg).
+The exact-match rate of each test is appended to gpurun_out/pnp_exact_match.json."""
+import json
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _log_rate(test, n_exact, n_total, mismatches):
+    """Record the measured exact-match rate (DESIGN.md quotes it); best effort, never fails the test."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        fn = os.path.join(d, "pnp_exact_match.json")
+        log = json.load(open(fn)) if os.path.exists(fn) else {}
+        log[test] = {"exact": int(n_exact), "problems": int(n_total), "mismatches": mismatches}
+        json.dump(log, open(fn, "w"), indent=1)
+    except OSError:
+        pass
 
 from tests import synth
 
@@ -30,26 +49,26 @@ def test_pnp_batch_matches_oracle():
     from pix2pose_amd.runtime import default_context, pnp_ransac_batch
     Ks, objs, imgs, gts = _scenes(48)
     ok, R, t, info, masks = pnp_ransac_batch(default_context(), Ks, objs, imgs, want_mask=True)
-    n_exact = 0
+    n_exact, n_ok, bad = 0, 0, []
     for p in range(len(objs)):
         ok0, R0, t0, inl0, meta = O.solve_pnp_ransac(objs[p], imgs[p], Ks[p])
         assert bool(ok[p]) == ok0, p
         if not ok0:
             continue
+        n_ok += 1
         dt, dr = synth.pose_error(R0, t0, R[p], t[p])
-        # same hypothesis, same inlier set => agreement to rounding; allow a different (equally
-        # good) winner on rare ties, where the north_star bar still has to hold
-        if info[p, 2] == meta["best_iter"] and info[p, 0] == meta["n_inliers"]:
+        if info[p, 2] == meta["best_iter"] and info[p, 0] == meta["n_inliers"] and info[p, 1] == meta["iterations"] \
+                and np.array_equal(np.nonzero(masks[p])[0], inl0):
             n_exact += 1
             assert dt < 1e-6 and dr < 1e-4, (p, dt, dr)   # arccos resolves ~1e-6 deg near identity
-            np.testing.assert_array_equal(np.nonzero(masks[p])[0], inl0)
-            assert info[p, 1] == meta["iterations"]
         else:
-            assert dt < 1.0 and dr < 1.0, (p, dt, dr)
+            bad.append({"problem": p, "n": len(objs[p]), "gpu": [int(v) for v in info[p]],
+                        "oracle": [meta["n_inliers"], meta["iterations"], meta["best_iter"]], "dt_mm": dt, "dr_deg": dr})
         gdt, gdr = synth.pose_error(gts[p][0], gts[p][1], R[p], t[p])
         if len(objs[p]) > 100:
             assert gdt < 5.0 and gdr < 1.0, (p, gdt, gdr)
-    assert n_exact >= 0.9 * len(objs)
+    _log_rate("test_pnp_batch_matches_oracle", n_exact, n_ok, bad)
+    assert not bad, bad               # every problem: same winning hypothesis, same inlier set, same iteration count
 
 
 def test_pnp_lazy_second_hypothesis_batch_matches_oracle():
@@ -60,21 +79,26 @@ def test_pnp_lazy_second_hypothesis_batch_matches_oracle():
     from pix2pose_amd.runtime import default_context, pnp_ransac_batch
     Ks, objs, imgs, gts = _scenes(24, seed0=321, n_pts=(200, 1500), outliers=(0.45, 0.7))
     ok, R, t, info, masks = pnp_ransac_batch(default_context(), Ks, objs, imgs, want_mask=True)
-    n_tail = n_exact = 0
+    n_tail = n_exact = n_ok = 0
+    bad = []
     for p in range(len(objs)):
         ok0, R0, t0, inl0, meta = O.solve_pnp_ransac(objs[p], imgs[p], Ks[p])
         assert bool(ok[p]) == ok0, p
         if not ok0:
             continue
+        n_ok += 1
         n_tail += meta["iterations"] > 64
-        if info[p, 2] == meta["best_iter"] and info[p, 0] == meta["n_inliers"]:
+        dt, dr = synth.pose_error(R0, t0, R[p], t[p])
+        if info[p, 2] == meta["best_iter"] and info[p, 0] == meta["n_inliers"] and info[p, 1] == meta["iterations"] \
+                and np.array_equal(np.nonzero(masks[p])[0], inl0):
             n_exact += 1
-            assert info[p, 1] == meta["iterations"], p
-            np.testing.assert_array_equal(np.nonzero(masks[p])[0], inl0)
-            dt, dr = synth.pose_error(R0, t0, R[p], t[p])
             assert dt < 1e-6 and dr < 1e-4, (p, dt, dr)
+        else:
+            bad.append({"problem": p, "n": len(objs[p]), "gpu": [int(v) for v in info[p]],
+                        "oracle": [meta["n_inliers"], meta["iterations"], meta["best_iter"]], "dt_mm": dt, "dr_deg": dr})
+    _log_rate("test_pnp_lazy_second_hypothesis_batch_matches_oracle", n_exact, n_ok, bad)
     assert n_tail >= 5, n_tail            # the scenes really reach the second batch
-    assert n_exact >= 0.9 * len(objs)
+    assert not bad, bad
 
 
 def test_pnp_edge_cases():
@@ -100,18 +124,31 @@ def test_pnp_edge_cases():
     for Rx, tx in ((R5, t5), (R[4], t[4])):          # float32 point storage bounds the accuracy
         dt, dr = synth.pose_error(R5g, t5g, Rx, tx)
         assert dt < 0.05 and dr < 0.01, (dt, dr)
+    with pytest.raises(Exception):       # more iterations than the solver's hypothesis storage: an error, not a silent clamp
+        pnp_ransac_batch(default_context(), Ks[:1], objs[:1], imgs[:1], iterations=129)
+    ok128, _, _, info128, _ = pnp_ransac_batch(default_context(), Ks[:1], objs[:1], imgs[:1], iterations=128)
+    assert ok128[0] and info128[0, 1] <= 128
     for p in (3, 5, 6):      # failure convention of recognition.py:215,219: identity, zero, -1
         np.testing.assert_array_equal(R[p], np.eye(3))
         np.testing.assert_array_equal(t[p], np.zeros(3))
         assert info[p, 0] == -1
 
 
-def test_pnp_large_problem_property():
-    """Full-size candidate (n = 128*128 correspondences, 20 % outliers): pose within the
-    north_star bar of ground truth and the result is invariant to batch position."""
+def test_pnp_full_size_problems_match_oracle():
+    """Full-size candidates (n = 128*128 correspondences, the BASELINE.json configs[2-3] size; 20 % outliers): the C oracle
+    handles them in milliseconds, so they are compared like the small ones -- same inlier set, winner and iteration count,
+    pose to rounding -- plus ground truth and invariance to the batch position."""
+    from oracle import pnp_oracle as O
     from pix2pose_amd.runtime import default_context, pnp_ransac_batch
     Ks, objs, imgs, gts = _scenes(6, seed0=11, n_pts=(16384, 16385), outliers=(0.2, 0.2))
-    ok, R, t, info, _ = pnp_ransac_batch(default_context(), Ks, objs, imgs)
+    ok, R, t, info, masks = pnp_ransac_batch(default_context(), Ks, objs, imgs, want_mask=True)
+    for p in range(6):
+        ok0, R0, t0, inl0, meta = O.solve_pnp_ransac(objs[p], imgs[p], Ks[p])
+        assert ok0 and ok[p]
+        assert [int(v) for v in info[p]] == [meta["n_inliers"], meta["iterations"], meta["best_iter"]], p
+        np.testing.assert_array_equal(np.nonzero(masks[p])[0], inl0)
+        dt, dr = synth.pose_error(R0, t0, R[p], t[p])
+        assert dt < 1e-6 and dr < 1e-4, (p, dt, dr)
     ok2, R2, t2, info2, _ = pnp_ransac_batch(default_context(), Ks[::-1], objs[::-1], imgs[::-1])
     np.testing.assert_array_equal(R, R2[::-1])
     np.testing.assert_array_equal(info, info2[::-1])
