@@ -53,6 +53,10 @@ int p2p_abi_version(void);
  * before the first call, so that a stale .so is an error and not a silent struct mismatch. */
 int p2p_abi_sizeof(int which);
 const char* p2p_build_id(void);
+/* Test hook, no GPU needed: the one-sided Gaussian weights (centre first) the anti-aliased resize uses for crop side
+ * `side` against the 128-px network resolution; w must hold 256 doubles.  Returns the radius (0: no filtering), -1 on a bad
+ * side.  tests/ hold it against scipy.ndimage's own kernel bit for bit. */
+int p2p_aa_weights(int side, double* w);
 const char* p2p_last_error(void);
 int p2p_device_count(int* count);
 
@@ -197,6 +201,15 @@ typedef struct {
     const unsigned char* det_mask;
     int64_t det_mask_stride;
     int64_t* mask_stats;
+    /* skimage.transform.resize version switch.  The reference calls resize(order=1) six times per detection
+     * (recognition.py:82,103,121,134,144,146) and does not pin scikit-image (requirements.txt does not list it):
+     *   0 (default): scikit-image <= 0.14 -- plain bilinear warp;
+     *   1: scikit-image 0.15 - 0.18, where anti_aliasing=True became the default -- every DOWN-scaling resize is preceded
+     *      by scipy.ndimage.gaussian_filter(sigma = (in/out - 1)/2, truncate 4, border 'mirror' / 'constant'+cval, result
+     *      kept in the array's dtype), restated in csrc/resize_aa.hip.
+     * (scikit-image >= 0.19 rejects the bool array of recognition.py:103, so the reference does not run there.)
+     * clip=True of resize (output clamped to the input's range, cval preserved) is common to all versions and always on. */
+    int resize_anti_aliasing;
 } p2p_est_pose_opts;
 
 /* Blocking.  poses[i] corresponds to dets[i]. */

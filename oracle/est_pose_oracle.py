@@ -5,8 +5,12 @@ CPU (numpy) restatement of ``pix2pose.est_pose`` / ``get_boxes`` / ``pnp_ransac`
 quirks listed in SURVEY.md section 8a-Q.  Third-party pieces are replaced by restatements:
 
   * ``skimage.transform.resize(order=1)``  -> :func:`resize_bilinear` (half-pixel
-    centres, per-tap border handling 'reflect' / 'constant'+cval, no anti-aliasing -- the
-    scikit-image version is unpinned in the reference; anti_aliasing was off by default until 0.15)
+    centres, per-tap border handling 'reflect' / 'constant'+cval, ``clip=True`` output clipping to the input's
+    range with cval preservation).  The scikit-image version is unpinned in the reference (requirements.txt does
+    not list it): ``anti_aliasing=False`` (default here) is scikit-image <= 0.14, ``anti_aliasing=True`` is the
+    0.15 - 0.18 default: ``scipy.ndimage.gaussian_filter`` with sigma = (in/out - 1)/2 per down-scaled axis --
+    the REAL scipy routine skimage calls, not a restatement -- before the warp.  (>= 0.19 refuses the bool
+    array recognition.py:103 passes, so the reference cannot run there at all.)
   * ``cv2.solvePnPRansac`` / ``cv2.Rodrigues`` -> oracle/pnp_oracle.c
   * ``generator_train.predict``            -> any callable (oracle/ae_oracle.forward, or injected
     decoder outputs for the synthetic PnP scenes)
@@ -37,14 +41,27 @@ def _map_reflect(i, n):
     return np.where(i >= n, p - i, i)
 
 
-def resize_bilinear(img, out_shape, mode, cval=0.0):
+def resize_bilinear(img, out_shape, mode, cval=0.0, anti_aliasing=False, clip=True):
     """img [H,W] or [H,W,C] (bool/float) -> float64 [oh,ow(,C)].
     src = dst*scale + (0.5*scale - 0.5), scale = in/out; taps floor/ceil; out-of-range taps are
-    reflected ('reflect') or replaced by cval ('constant')."""
-    a = np.asarray(img)
-    a = a.astype(np.float64)
-    h, w = a.shape[:2]
+    reflected ('reflect') or replaced by cval ('constant').
+    anti_aliasing (skimage 0.15-0.18 default): Gaussian pre-filter, sigma = max(0, (in/out - 1)/2) per axis, truncated at
+    4 sigma, border mode 'mirror' (for 'reflect') or 'constant' with cval; the filter keeps the input's dtype (a float32
+    map is rounded to float32 after each axis pass, exactly what scipy does for skimage).
+    clip (skimage default): the output is clipped to [min, max] of the (filtered) input; in 'constant' mode with cval
+    outside that range, pixels exactly equal to cval are kept (skimage._shared / transform._warps._clip_warp_output)."""
+    a0 = np.asarray(img)
+    if a0.dtype == bool or a0.dtype.kind not in "f":
+        a0 = a0.astype(np.float64)                  # img_as_float(bool / ints used here) -> float64
+    h, w = a0.shape[:2]
     oh, ow = out_shape
+    if anti_aliasing:
+        from scipy import ndimage as ndi
+        sig = [max(0.0, (h / oh - 1) / 2), max(0.0, (w / ow - 1) / 2)] + [0.0] * (a0.ndim - 2)
+        if max(sig) > 0:
+            a0 = ndi.gaussian_filter(a0, sig, cval=cval, mode="mirror" if mode == "reflect" else "constant")
+    lo_v, hi_v = (float(a0.min()), float(a0.max())) if a0.size else (0.0, 0.0)
+    a = a0.astype(np.float64)
 
     def axis(n_in, n_out):
         s = n_in / n_out
@@ -75,7 +92,14 @@ def resize_bilinear(img, out_shape, mode, cval=0.0):
         drb = dr[:, None]
     top = (1 - dcb) * tap(r0, c0) + dcb * tap(r0, c1)
     bot = (1 - dcb) * tap(r1, c0) + dcb * tap(r1, c1)
-    return (1 - drb) * top + drb * bot
+    out = (1 - drb) * top + drb * bot
+    if clip:
+        preserve = mode == "constant" and not (lo_v <= cval <= hi_v)
+        keep = (out == cval) if preserve else None
+        out = np.clip(out, lo_v, hi_v)
+        if preserve:
+            out[keep] = cval
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -160,7 +184,7 @@ def pnp_ransac(rgb_aug, img_prob_ori, non_zero, v1, v2, u1, u2, camK, obj_scale,
 # est_pose  (recognition.py:70-193)
 # --------------------------------------------------------------------------------------
 def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th_inlier=0.1, box_size=1.5,
-             debug=None):
+             debug=None, anti_aliasing=False):
     """Returns the reference's 6-tuple.  ``predict(x[N,128,128,3]) -> [decode, prob]``.
     ``debug`` (dict) receives intermediates for stage-wise parity tests."""
     camK = np.asarray(camK, np.float64).reshape(3, 3)
@@ -179,7 +203,8 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
     if base.shape[0] < 5 or base.shape[1] < 5 or crop.shape[0] < 5 or crop.shape[1] < 5:   # :78-79
         return np.zeros((1)), -1, -1, -1, -1, fail_box
     base[b1.vv1:b1.vv2, b1.uu1:b1.uu2] = crop                                        # :81
-    x1 = resize_bilinear(base, (128, 128), "reflect")                                # :82
+    aa = bool(anti_aliasing)
+    x1 = resize_bilinear(base, (128, 128), "reflect", anti_aliasing=aa)              # :82
     dbg["x1"] = x1.astype(np.float32)
     decode, prob = predict(np.expand_dims(x1, 0), stage=1)                           # :84
     decode = np.array(decode, np.float32)
@@ -199,7 +224,7 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
             continue
         bb = np.array([vs.min(), us.min(), vs.max(), us.max()])                      # :101 (of non_gray, not keep)
         bb = bb * np.array([side / 128, (b1.u2_ori - b1.u1_ori) / 128] * 2)          # :102
-        keep_ori = resize_bilinear(keep, (side, b1.u2_ori - b1.u1_ori), "constant", 0) > 0.9       # :103
+        keep_ori = resize_bilinear(keep, (side, b1.u2_ori - b1.u1_ori), "constant", 0, anti_aliasing=aa) > 0.9     # :103
         keep_ori = keep_ori[b1.vv1:b1.vv2, b1.uu1:b1.uu2]                            # :104
         bg_full = np.ones((H, W), bool)                                              # :105-106
         bg_full[b1.v1:b1.v2, b1.u1:b1.u2] = np.invert(keep_ori)
@@ -218,7 +243,7 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
         # mis-align boxes and inputs afterwards; we keep them aligned (the misaligned case needs
         # a <5 px re-crop and does not occur for boxes that passed the stage-1 check).
         base2[b2.vv1:b2.vv2, b2.uu1:b2.uu2] = crop2                                  # :120
-        inputs.append(resize_bilinear(base2, (128, 128), "reflect"))                 # :121-122
+        inputs.append(resize_bilinear(base2, (128, 128), "reflect", anti_aliasing=aa))   # :121-122
         boxes.append(b2)
         slots.append(slot)
     dbg["slots"] = slots
@@ -238,14 +263,14 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
         b = boxes[c]
         last = b
         side2, wid2 = b.v2_ori - b.v1_ori, b.u2_ori - b.u1_ori
-        prob_ori = resize_bilinear(prob[c, :, :, 0], (side2, wid2), "constant", 1)   # :134
+        prob_ori = resize_bilinear(prob[c, :, :, 0], (side2, wid2), "constant", 1, anti_aliasing=aa)   # :134 (float32 map)
         prob_ori = prob_ori[b.vv1:b.vv2, b.uu1:b.uu2]                                # :135
         gray = np.linalg.norm(decode[c], axis=2) < 0.3                               # :137
         ng = np.invert(gray)                                                         # :138
         decode[c, gray, :] = 0                                                       # :139
         pred = np.clip((decode[c] + 1) / 2, 0, 1)                                    # :141-143
-        pred_ori = resize_bilinear(pred, (side2, wid2), "constant", 0.5) * 255       # :144
-        ng = resize_bilinear(ng.astype(float), (side2, wid2), "constant", 0) > 0.9   # :146
+        pred_ori = resize_bilinear(pred, (side2, wid2), "constant", 0.5, anti_aliasing=aa) * 255       # :144 (float32 map)
+        ng = resize_bilinear(ng.astype(float), (side2, wid2), "constant", 0, anti_aliasing=aa) > 0.9   # :146
         ng = ng[b.vv1:b.vv2, b.uu1:b.uu2]                                            # :147
         n_non_gray = int(np.sum(ng))                                                 # :148
         cd = {"slot": slots[c], "n_non_gray": n_non_gray}

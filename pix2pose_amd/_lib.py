@@ -55,7 +55,8 @@ class EstPoseOpts(C.Structure):
                 ("valid_mask", C.c_void_p), ("mask_stride", C.c_int64), ("img_pred", C.c_void_p),
                 ("pred_stride", C.c_int64), ("dbg_x1", C.c_void_p), ("dbg_x2", C.c_void_p),
                 ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p),
-                ("det_mask", C.c_void_p), ("det_mask_stride", C.c_int64), ("mask_stats", C.c_void_p)]
+                ("det_mask", C.c_void_p), ("det_mask_stride", C.c_int64), ("mask_stats", C.c_void_p),
+                ("resize_anti_aliasing", C.c_int)]
 
 
 PROFILE_SLOTS = 6      # P2P_PROFILE_SLOTS
@@ -128,6 +129,7 @@ def lib():
     L.p2p_abi_version.restype = ci
     L.p2p_abi_sizeof.argtypes = [ci]
     L.p2p_build_id.restype = C.c_char_p
+    L.p2p_aa_weights.argtypes = [ci, C.POINTER(C.c_double)]
     L.p2p_last_error.restype = C.c_char_p
     L.p2p_device_count.argtypes = [C.POINTER(ci)]
     L.p2p_ctx_create.argtypes = [ci, ci, C.POINTER(vp)]

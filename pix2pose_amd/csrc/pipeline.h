@@ -31,7 +31,41 @@ struct DetInfo {
     int ok1;                // 0 => recognition.py:78-79 early return
     long long corr_off;     // float offset of this detection's correspondence storage
     int corr_cap;           // points per candidate (stage-1 side squared)
+    int aa;                 // anti-aliased resizes (scikit-image 0.15 - 0.18 default), p2p_est_pose_opts.resize_anti_aliasing
+    long long cv_off;       // double offset of this detection's (1 + K) canvases of corr_cap * 3 doubles each (aa, side > 128)
 };
+
+// One image of an anti-aliased resize (skimage: ndi.gaussian_filter before the warp): filtered in place.
+struct AaItem {
+    double* a;              // [H][W][C] interleaved
+    double* tmp;            // scratch of the same size (result of the first axis pass)
+    int H, W, C;
+    int radius;             // 0 = nothing to do (item inactive, or sigma == 0)
+    const double* w;        // one-sided weights w[0 .. radius], centre first
+    int mode;               // 0 = 'mirror' (skimage mode 'reflect'), 1 = 'constant'
+    int round32;            // the image is a float32 array in the reference: round to float32 after each axis pass
+    double cval;
+    double vmin, vmax;      // range of the filtered image (skimage clips the warp output to it)
+};
+
+// Ranges skimage's clip=True needs for the 'constant'-mode back-resizes of one candidate (recognition.py:134,144,146):
+// [min, max] of the warp INPUT (the raw 128x128 map, or its anti-aliased version).
+struct CandRange {
+    double pmin, pmax;      // prob                       (cval 1)
+    double qmin, qmax;      // img_pred, all 3 channels   (cval 0.5)
+    double gmin, gmax;      // non_gray as float          (cval 0)
+};
+
+// Gaussian weights per crop side (resize_aa.hip), device pointers
+struct AaTable {
+    const double* w = nullptr;
+    const int* off = nullptr;
+    const int* rad = nullptr;
+    int max_side = 0;
+};
+int aa_table_get(int device, AaTable* out);          // builds + uploads once per device
+hipError_t launch_aa_filter(AaItem* items, int n_items, int max_elems, hipStream_t s);   // both axis passes + range
+
 
 // Stage-1 reductions + stage-2 geometry, written by the device.
 struct Stage1 {
@@ -40,6 +74,7 @@ struct Stage1 {
     long long sum_v, sum_u;
     int keep_cnt[MAX_TH];
     int valid2[MAX_TH];     // candidate built for threshold slot k
+    double kmin[MAX_TH], kmax[MAX_TH];   // range of the keep mask image fed to the warp (clip=True), per slot
     int n_cand;
     Boxes b2;               // all candidates of a detection share it (quirk)
 };
@@ -98,6 +133,8 @@ struct PinnedBuf {
 struct Slot {
     DevBuf det, s1, cand, probs, results, poses, corr, hyp;
     DevBuf x1, y1, x2, y2, images;      // network inputs / outputs of both stages, uploaded frames
+    DevBuf crange;                      // CandRange per candidate
+    DevBuf aa_items, aa_cv, aa_cv_tmp, aa_kp, aa_kp_tmp, aa_bk, aa_bk_tmp;   // anti-aliased resizes: descriptors, canvases, 128x128 planes
     DevBuf mask, pred, dmask, mstat;    // optional outputs of the batch (valid_mask_full, img_pred_f, detector masks, IoU sums)
     p2p_pose* host_poses = nullptr;     // pinned
     size_t host_cap = 0;

@@ -72,7 +72,7 @@ Pipeline::~Pipeline()
 {
     for (Slot& s : slot) {
         for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images,
-                          &s.mask, &s.pred, &s.dmask, &s.mstat}) b->release();
+                          &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_kp, &s.aa_kp_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
         for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
         if (s.done) (void)hipEventDestroy(s.done);
@@ -163,6 +163,24 @@ __device__ inline double lerp2(double tl, double tr, double bl, double br, doubl
     return (1 - dr) * top + dr * bot;
 }
 
+// skimage's clip=True (every version the reference can run on): the warp output is clamped to [min, max] of the warp
+// INPUT; in 'constant' mode with cval outside that range, outputs exactly equal to cval are left alone
+// (skimage.transform._warps._clip_warp_output).  A no-op unless taps fall outside the image (up-scaling borders) or
+// the anti-aliasing filter mixed cval in.
+__device__ inline double clip_warp(double v, double lo, double hi, double cval)
+{
+    if (!(lo <= cval && cval <= hi) && v == cval) return v;
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// anti-aliased resizes (resize_aa.hip): descriptor arrays per image kind, all null when the option is off
+struct AaPtrs {
+    AaItem* k0;   // [n]        stage-1 canvases           (side > 128)
+    AaItem* k1;   // [n*K]      stage-2 canvases           (side > 128)
+    AaItem* k2;   // [n*K]      keep masks, 128x128        (stage-1 side < 128)
+    AaItem* k3;   // [n*K*5]    prob, pred r/g/b, non_gray (stage-2 side < 128)
+};
+
 // (pixel - 128) / 128 of frame pixel (y, x), channel ch
 __device__ inline double frame_px(const DetInfo& D, int y, int x, int ch)
 {
@@ -181,7 +199,7 @@ __device__ inline bool non_gray_at(const float* y4)   // np.linalg.norm(decode, 
 // ------------------------------------------------------------------------------------------
 // K1: stage-1 network inputs  (recognition.py:75-82)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stage1_input_kernel(const DetInfo* __restrict__ dets, float* __restrict__ x1)
+__global__ __launch_bounds__(256) void stage1_input_kernel(const DetInfo* __restrict__ dets, float* __restrict__ x1, AaPtrs aa)
 {
     const int d = blockIdx.x >> 6;
     const int pix = ((blockIdx.x & 63) << 8) | threadIdx.x;
@@ -194,10 +212,12 @@ __global__ __launch_bounds__(256) void stage1_input_kernel(const DetInfo* __rest
     const Tap tr = axis_tap(oy, S, 128), tc = axis_tap(ox, Sw, 128);
     const int r[2] = {reflect_idx(tr.i0, S), reflect_idx(tr.i1, S)};
     const int c[2] = {reflect_idx(tc.i0, Sw), reflect_idx(tc.i1, Sw)};
+    const double* cv = (aa.k0 && aa.k0[d].radius > 0) ? aa.k0[d].a : nullptr;      // anti-aliased canvas instead of the frame
     for (int ch = 0; ch < 3; ++ch) {
         double v[2][2];
         for (int a = 0; a < 2; ++a)
             for (int e = 0; e < 2; ++e) {
+                if (cv) { v[a][e] = cv[((size_t)r[a] * Sw + c[e]) * 3 + ch]; continue; }
                 const bool in = r[a] >= b.vv1 && r[a] < b.vv2 && c[e] >= b.uu1 && c[e] < b.uu2;
                 v[a][e] = in ? frame_px(D, b.v1 + r[a] - b.vv1, b.u1 + c[e] - b.uu1, ch) : 0.0;
             }
@@ -259,6 +279,8 @@ __global__ __launch_bounds__(256) void stage1_stats_kernel(const DetInfo* __rest
         const bool geo_ok = boxes_ok(b2, D.H, D.W);
         for (int k = 0; k < D.n_th; ++k) {
             o.keep_cnt[k] = s_keep[k];
+            o.kmin[k] = s_keep[k] == 16384 ? 1.0 : 0.0;      // range of the bool mask as float (clip=True of the :103 resize)
+            o.kmax[k] = s_keep[k] > 0 ? 1.0 : 0.0;
             o.valid2[k] = (s_keep[k] >= 10 && geo_ok) ? 1 : 0;                             // :96-97, :117-119
             if (o.valid2[k]) { any = true; ++o.n_cand; }
         }
@@ -267,8 +289,9 @@ __global__ __launch_bounds__(256) void stage1_stats_kernel(const DetInfo* __rest
     s1[d] = o;
 }
 
-// resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square
-__device__ inline bool keep_ori_at(const float* y1d, float th, int r, int c, int S, int Sw)
+// resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square.  kp: the anti-aliased keep
+// image (null: the raw mask from the network output); [kmin, kmax]: range of the warp input (clip=True).
+__device__ inline bool keep_ori_at(const float* y1d, const double* kp, float th, double kmin, double kmax, int r, int c, int S, int Sw)
 {
     const Tap tr = axis_tap(r, 128, S), tc = axis_tap(c, 128, Sw);
     double v[2][2];
@@ -277,19 +300,38 @@ __device__ inline bool keep_ori_at(const float* y1d, float th, int r, int c, int
         for (int e = 0; e < 2; ++e) {
             double k = 0.0;
             if (ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
-                const float* q = y1d + ((size_t)ri[a] * 128 + cj[e]) * 4;
-                k = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
+                if (kp) k = kp[ri[a] * 128 + cj[e]];
+                else {
+                    const float* q = y1d + ((size_t)ri[a] * 128 + cj[e]) * 4;
+                    k = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
+                }
             }
             v[a][e] = k;
         }
-    return lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d) > 0.9;
+    return clip_warp(lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d), kmin, kmax, 0.0) > 0.9;
+}
+
+// value of the stage-2 canvas (recognition.py:113-120) at canvas position (r, c), channel ch: the frame pixel where the
+// kept mask says foreground, zero elsewhere
+__device__ inline bool stage2_fg(const DetInfo& D, const Stage1& S, const float* y1d, const double* kp, int slot, int r, int c, int* fy, int* fx)
+{
+    const Boxes& b1 = D.b1;
+    const Boxes& b = S.b2;
+    const bool in = r >= b.vv1 && r < b.vv2 && c >= b.uu1 && c < b.uu2;
+    if (!in) return false;
+    const int y = b.v1 + r - b.vv1, x = b.u1 + c - b.uu1;
+    *fy = y; *fx = x;
+    // bg_full: True outside the stage-1 clipped crop, ~keep_ori inside   (:105-106)
+    if (y >= b1.v1 && y < b1.v2 && x >= b1.u1 && x < b1.u2)
+        return keep_ori_at(y1d, kp, D.th_o[slot], S.kmin[slot], S.kmax[slot], y - b1.v1_ori, x - b1.u1_ori, b1.v2_ori - b1.v1_ori, b1.u2_ori - b1.u1_ori);
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------
 // K4: stage-2 network inputs  (recognition.py:103-121)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
-                                                           const float* __restrict__ y1, int K, float* __restrict__ x2)
+                                                           const float* __restrict__ y1, int K, float* __restrict__ x2, AaPtrs aa)
 {
     const int cand = blockIdx.x >> 6;
     const int d = cand / K, slot = cand - d * K;
@@ -299,36 +341,31 @@ __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __rest
     const Stage1& S = s1[d];
     float* out = x2 + ((size_t)cand * 16384 + pix) * 3;
     if (slot >= D.n_th || !S.valid2[slot]) { out[0] = out[1] = out[2] = 0.f; return; }
-    const Boxes& b1 = D.b1;
     const Boxes& b = S.b2;
-    const int S1 = b1.v2_ori - b1.v1_ori, S1w = b1.u2_ori - b1.u1_ori;
     const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
     const Tap tr = axis_tap(oy, S2, 128), tc = axis_tap(ox, S2w, 128);
     const int r[2] = {reflect_idx(tr.i0, S2), reflect_idx(tr.i1, S2)};
     const int c[2] = {reflect_idx(tc.i0, S2w), reflect_idx(tc.i1, S2w)};
-    const float* y1d = y1 + (size_t)d * 16384 * 4;
-    const float th = D.th_o[slot];
-    bool fg[2][2];
-    int fy[2], fx[2];
-    for (int a = 0; a < 2; ++a) {
-        fy[a] = b.v1 + r[a] - b.vv1;
-        fx[a] = b.u1 + c[a] - b.uu1;
-    }
-    for (int a = 0; a < 2; ++a)
-        for (int e = 0; e < 2; ++e) {
-            const bool in = r[a] >= b.vv1 && r[a] < b.vv2 && c[e] >= b.uu1 && c[e] < b.uu2;
-            bool f = false;
-            if (in) {
-                const int y = fy[a], x = fx[e];
-                // bg_full: True outside the stage-1 clipped crop, ~keep_ori inside   (:105-106)
-                if (y >= b1.v1 && y < b1.v2 && x >= b1.u1 && x < b1.u2) f = keep_ori_at(y1d, th, y - b1.v1_ori, x - b1.u1_ori, S1, S1w);
-            }
-            fg[a][e] = f;
+    const double* cv = (aa.k1 && aa.k1[cand].radius > 0) ? aa.k1[cand].a : nullptr;   // anti-aliased canvas
+    if (cv) {
+        for (int ch = 0; ch < 3; ++ch) {
+            double v[2][2];
+            for (int a = 0; a < 2; ++a)
+                for (int e = 0; e < 2; ++e) v[a][e] = cv[((size_t)r[a] * S2w + c[e]) * 3 + ch];
+            out[ch] = (float)lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d);
         }
+        return;
+    }
+    const float* y1d = y1 + (size_t)d * 16384 * 4;
+    const double* kp = (aa.k2 && aa.k2[cand].radius > 0) ? aa.k2[cand].a : nullptr;
+    bool fg[2][2];
+    int fy[2][2], fx[2][2];
+    for (int a = 0; a < 2; ++a)
+        for (int e = 0; e < 2; ++e) fg[a][e] = stage2_fg(D, S, y1d, kp, slot, r[a], c[e], &fy[a][e], &fx[a][e]);
     for (int ch = 0; ch < 3; ++ch) {
         double v[2][2];
         for (int a = 0; a < 2; ++a)
-            for (int e = 0; e < 2; ++e) v[a][e] = fg[a][e] ? frame_px(D, fy[a], fx[e], ch) : 0.0;
+            for (int e = 0; e < 2; ++e) v[a][e] = fg[a][e] ? frame_px(D, fy[a][e], fx[a][e], ch) : 0.0;
         out[ch] = (float)lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d);
     }
 }
@@ -342,7 +379,23 @@ struct CandPixel {
     unsigned char q[3];
 };
 
-__device__ inline CandPixel cand_pixel(const float* y2c, int r, int c, int S2, int S2w, double th_i)
+// raw 128x128 maps of one network output pixel (recognition.py:137-143): prob, non_gray as float, img_pred
+__device__ inline void cand_raw(const float* q, double* prob, double* ng, double pred[3])
+{
+    const float s = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    const bool gray = sqrtf(s) < 0.3f;                                  // :137
+    *prob = (double)q[3];
+    *ng = gray ? 0.0 : 1.0;
+    for (int ch = 0; ch < 3; ++ch) {
+        const float dq = gray ? 0.f : q[ch];                            // :139
+        float ip = (dq + 1.0f) / 2.0f;                                  // :141 (float32)
+        ip = ip > 1.f ? 1.f : (ip < 0.f ? 0.f : ip);                    // :142-143
+        pred[ch] = (double)ip;
+    }
+}
+
+// bk: the candidate's five anti-aliased planes [prob | pred r | g | b | non_gray][128*128] (null: raw maps from y2c)
+__device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const CandRange& R, int r, int c, int S2, int S2w, double th_i)
 {
     const Tap tr = axis_tap(r, 128, S2), tc = axis_tap(c, 128, S2w);
     const int ri[2] = {tr.i0, tr.i1}, cj[2] = {tc.i0, tc.i1};
@@ -350,16 +403,15 @@ __device__ inline CandPixel cand_pixel(const float* y2c, int r, int c, int S2, i
     for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 2; ++e) {
             if (ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
-                const float* q = y2c + ((size_t)ri[a] * 128 + cj[e]) * 4;
-                const float s = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-                const bool gray = sqrtf(s) < 0.3f;                                  // :137
-                prob[a][e] = (double)q[3];
-                ng[a][e] = gray ? 0.0 : 1.0;
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float dq = gray ? 0.f : q[ch];                            // :139
-                    float ip = (dq + 1.0f) / 2.0f;                                  // :141 (float32)
-                    ip = ip > 1.f ? 1.f : (ip < 0.f ? 0.f : ip);                    // :142-143
-                    pred[ch][a][e] = (double)ip;
+                const int idx = ri[a] * 128 + cj[e];
+                if (bk) {
+                    prob[a][e] = bk[idx];
+                    for (int ch = 0; ch < 3; ++ch) pred[ch][a][e] = bk[(1 + ch) * 16384 + idx];
+                    ng[a][e] = bk[4 * 16384 + idx];
+                } else {
+                    double pr3[3];
+                    cand_raw(y2c + (size_t)idx * 4, &prob[a][e], &ng[a][e], pr3);
+                    for (int ch = 0; ch < 3; ++ch) pred[ch][a][e] = pr3[ch];
                 }
             } else {          // resize(..., mode='constant', cval=1 / 0.5 / 0)       :134,144,146
                 prob[a][e] = 1.0; ng[a][e] = 0.0;
@@ -367,14 +419,44 @@ __device__ inline CandPixel cand_pixel(const float* y2c, int r, int c, int S2, i
             }
         }
     CandPixel o;
-    o.non_gray = lerp2(ng[0][0], ng[0][1], ng[1][0], ng[1][1], tr.d, tc.d) > 0.9;
-    const double pr = lerp2(prob[0][0], prob[0][1], prob[1][0], prob[1][1], tr.d, tc.d);
+    o.non_gray = clip_warp(lerp2(ng[0][0], ng[0][1], ng[1][0], ng[1][1], tr.d, tc.d), R.gmin, R.gmax, 0.0) > 0.9;
+    const double pr = clip_warp(lerp2(prob[0][0], prob[0][1], prob[1][0], prob[1][1], tr.d, tc.d), R.pmin, R.pmax, 1.0);
     o.valid = o.non_gray && pr < th_i;                                              // :203-204
     for (int ch = 0; ch < 3; ++ch) {
-        const double v = lerp2(pred[ch][0][0], pred[ch][0][1], pred[ch][1][0], pred[ch][1][1], tr.d, tc.d) * 255;
+        const double v = clip_warp(lerp2(pred[ch][0][0], pred[ch][0][1], pred[ch][1][0], pred[ch][1][1], tr.d, tc.d), R.qmin, R.qmax, 0.5) * 255;
         o.q[ch] = (unsigned char)(int)v;                                            // uint8 canvas: truncation (:152-154)
     }
     return o;
+}
+
+// [min, max] of the raw 128x128 maps of every candidate (the warp inputs when no anti-aliasing filter ran)
+__global__ __launch_bounds__(256) void cand_range_kernel(const float* __restrict__ y2, CandRange* __restrict__ out)
+{
+    __shared__ double s_v[4][6];
+    const float* y2c = y2 + (size_t)blockIdx.x * 16384 * 4;
+    double v[6] = {1e300, -1e300, 1e300, -1e300, 1e300, -1e300};
+    for (int p = threadIdx.x; p < 16384; p += 256) {
+        double prob, ng, pred[3];
+        cand_raw(y2c + (size_t)p * 4, &prob, &ng, pred);
+        v[0] = fmin(v[0], prob); v[1] = fmax(v[1], prob);
+        for (int ch = 0; ch < 3; ++ch) { v[2] = fmin(v[2], pred[ch]); v[3] = fmax(v[3], pred[ch]); }
+        v[4] = fmin(v[4], ng); v[5] = fmax(v[5], ng);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        for (int k = 0; k < 6; ++k) {
+            const double w = __shfl_down(v[k], o, 64);
+            v[k] = (k & 1) ? fmax(v[k], w) : fmin(v[k], w);
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 6; ++k) s_v[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            for (int k = 0; k < 6; ++k) v[k] = (k & 1) ? fmax(v[k], s_v[w][k]) : fmin(v[k], s_v[w][k]);
+        CandRange R;
+        R.pmin = v[0]; R.pmax = v[1]; R.qmin = v[2]; R.qmax = v[3]; R.gmin = v[4]; R.gmax = v[5];
+        out[blockIdx.x] = R;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -382,7 +464,8 @@ __device__ inline CandPixel cand_pixel(const float* y2c, int r, int c, int S2, i
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cand_corr_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
                                                         const float* __restrict__ y2, int K, float* __restrict__ corr,
-                                                        CandStat* __restrict__ cstat, PnpProblem* __restrict__ probs)
+                                                        CandStat* __restrict__ cstat, PnpProblem* __restrict__ probs,
+                                                        const CandRange* __restrict__ crange, AaPtrs aa)
 {
     __shared__ int s_wave[4];
     __shared__ int s_ng;
@@ -402,6 +485,8 @@ __global__ __launch_bounds__(256) void cand_corr_kernel(const DetInfo* __restric
         const int h = b.v2 - b.v1, w = b.u2 - b.u1;
         const int npx = h * w;
         const float* y2c = y2 + (size_t)cand * 16384 * 4;
+        const double* bk = (aa.k3 && aa.k3[cand * 5].radius > 0) ? aa.k3[cand * 5].a : nullptr;
+        const CandRange R = crange[cand];
         int ng_cnt = 0;
         unsigned long long sv = 0, su = 0;
         float* PX = pts; float* PY = pts + D.corr_cap; float* PZ = pts + 2 * (size_t)D.corr_cap;
@@ -413,7 +498,7 @@ __global__ __launch_bounds__(256) void cand_corr_kernel(const DetInfo* __restric
             int rr = 0, cc = 0;
             if (p < npx) {
                 rr = p / w; cc = p - rr * w;
-                cp = cand_pixel(y2c, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+                cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
                 valid = cp.valid;
                 if (cp.non_gray) { ++ng_cnt; sv += (unsigned)(b.v1 + rr); su += (unsigned)(b.u1 + cc); }
             }
@@ -523,7 +608,8 @@ __global__ void select_kernel(const DetInfo* __restrict__ dets, const Stage1* __
 __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
                                                           const p2p_pose* __restrict__ poses, const float* __restrict__ y2,
                                                           int K, unsigned char* __restrict__ mask, long long mask_stride,
-                                                          unsigned char* __restrict__ pred, long long pred_stride)
+                                                          unsigned char* __restrict__ pred, long long pred_stride,
+                                                          const CandRange* __restrict__ crange, AaPtrs aa)
 {
     const int d = blockIdx.y;
     const p2p_pose& P = poses[d];
@@ -532,10 +618,13 @@ __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restr
     const Boxes& b = s1[d].b2;
     const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
     const int h = b.v2 - b.v1, w = b.u2 - b.u1;
-    const float* y2c = y2 + (size_t)(d * K + P.best_slot) * 16384 * 4;
+    const int cand = d * K + P.best_slot;
+    const float* y2c = y2 + (size_t)cand * 16384 * 4;
+    const double* bk = (aa.k3 && aa.k3[cand * 5].radius > 0) ? aa.k3[cand * 5].a : nullptr;
+    const CandRange R = crange[cand];
     for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
         const int rr = p / w, cc = p - rr * w;
-        const CandPixel cp = cand_pixel(y2c, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+        const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
         if (mask) mask[(size_t)d * mask_stride + (size_t)(b.v1 + rr) * D.W + (b.u1 + cc)] = cp.valid ? 1 : 0;
         if (pred && (long long)(p + 1) * 3 <= pred_stride) {
             unsigned char* q = pred + (size_t)d * pred_stride + (size_t)p * 3;
@@ -553,7 +642,8 @@ __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restr
 __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
                                                        const p2p_pose* __restrict__ poses, const float* __restrict__ y2, int K,
                                                        const unsigned char* __restrict__ det_mask, long long stride,
-                                                       unsigned long long* __restrict__ stats)
+                                                       unsigned long long* __restrict__ stats,
+                                                       const CandRange* __restrict__ crange, AaPtrs aa)
 {
     const int d = blockIdx.y;
     const DetInfo& D = dets[d];
@@ -566,10 +656,13 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict
         const Boxes& b = s1[d].b2;
         const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
         const int h = b.v2 - b.v1, w = b.u2 - b.u1;
-        const float* y2c = y2 + (size_t)(d * K + P.best_slot) * 16384 * 4;
+        const int cand = d * K + P.best_slot;
+        const float* y2c = y2 + (size_t)cand * 16384 * 4;
+        const double* bk = (aa.k3 && aa.k3[cand * 5].radius > 0) ? aa.k3[cand * 5].a : nullptr;
+        const CandRange R = crange[cand];
         for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
             const int rr = p / w, cc = p - rr * w;
-            const CandPixel cp = cand_pixel(y2c, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
             if (cp.valid) {
                 ++vcount;
                 inter += dm[(size_t)(b.v1 + rr) * D.W + (b.u1 + cc)] != 0;
@@ -584,6 +677,167 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict
         if (dcount) atomicAdd(&stats[3 * d + 1], dcount);
         if (vcount) atomicAdd(&stats[3 * d + 2], vcount);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// anti-aliased resizes (p2p_est_pose_opts.resize_anti_aliasing; filter itself: resize_aa.hip)
+// ------------------------------------------------------------------------------------------
+struct AaBufs {
+    double *cv, *cv_tmp;      // canvases: per detection (1 + K) x corr_cap x 3 doubles at DetInfo::cv_off
+    double *kp, *kp_tmp;      // keep masks: [n*K][128*128]
+    double *bk, *bk_tmp;      // back-resize planes: [n*K][5][128*128]
+};
+
+__device__ inline void aa_item_off(AaItem& I)
+{
+    I.a = I.tmp = nullptr; I.w = nullptr;
+    I.H = I.W = I.C = 0; I.radius = 0; I.mode = 0; I.round32 = 0; I.cval = 0; I.vmin = I.vmax = 0;
+}
+
+// phase 0 (before stage 1): every descriptor off, stage-1 canvases planned.  phase 1 (after the stage-1 reductions, which
+// fix the stage-2 geometry on the device): stage-2 canvases, keep masks, back-resize planes.  One thread per (detection, slot).
+__global__ void aa_plan_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1, int n, int K, int phase, AaTable tab,
+                               AaBufs B, AaPtrs aa)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * K) return;
+    const int d = t / K, slot = t - d * K;
+    const DetInfo& D = dets[d];
+    const int S1 = D.b1.v2_ori - D.b1.v1_ori;
+    const size_t cap3 = (size_t)D.corr_cap * 3;
+    if (phase == 0) {
+        aa_item_off(aa.k1[t]); aa_item_off(aa.k2[t]);
+        for (int j = 0; j < 5; ++j) aa_item_off(aa.k3[t * 5 + j]);
+        if (slot == 0) {
+            AaItem I;
+            aa_item_off(I);
+            if (D.aa && D.ok1 && S1 > 128 && S1 <= tab.max_side && tab.rad[S1] > 0) {
+                I.a = B.cv + D.cv_off; I.tmp = B.cv_tmp + D.cv_off;
+                I.H = S1; I.W = D.b1.u2_ori - D.b1.u1_ori; I.C = 3;
+                I.radius = tab.rad[S1]; I.w = tab.w + tab.off[S1];
+            }
+            aa.k0[d] = I;
+        }
+        return;
+    }
+    const Stage1& S = s1[d];
+    if (!D.aa || !D.ok1 || slot >= D.n_th) return;
+    if (S1 < 128 && S.keep_cnt[slot] >= 10 && tab.rad[S1] > 0) {        // :103 shrinks the 128x128 keep mask to the stage-1 square
+        AaItem& I = aa.k2[t];
+        I.a = B.kp + (size_t)t * 16384; I.tmp = B.kp_tmp + (size_t)t * 16384;
+        I.H = I.W = 128; I.C = 1; I.radius = tab.rad[S1]; I.w = tab.w + tab.off[S1];
+        I.mode = 1; I.cval = 0.0; I.round32 = 0;                          // bool -> float64
+    }
+    if (!S.valid2[slot]) return;
+    const int S2 = S.b2.v2_ori - S.b2.v1_ori;
+    if (S2 > 128 && S2 <= tab.max_side && tab.rad[S2] > 0) {              // :121 shrinks the stage-2 canvas to 128
+        AaItem& I = aa.k1[t];
+        I.a = B.cv + D.cv_off + (size_t)(1 + slot) * cap3; I.tmp = B.cv_tmp + D.cv_off + (size_t)(1 + slot) * cap3;
+        I.H = S2; I.W = S.b2.u2_ori - S.b2.u1_ori; I.C = 3; I.radius = tab.rad[S2]; I.w = tab.w + tab.off[S2];
+    }
+    if (S2 < 128 && S2 > 0 && tab.rad[S2] > 0)                           // :134,144,146 shrink the network output maps
+        for (int j = 0; j < 5; ++j) {
+            AaItem& I = aa.k3[t * 5 + j];
+            I.a = B.bk + ((size_t)t * 5 + j) * 16384; I.tmp = B.bk_tmp + ((size_t)t * 5 + j) * 16384;
+            I.H = I.W = 128; I.C = 1; I.radius = tab.rad[S2]; I.w = tab.w + tab.off[S2];
+            I.mode = 1; I.cval = j == 0 ? 1.0 : (j == 4 ? 0.0 : 0.5);
+            I.round32 = j < 4;                                            // prob and img_pred are float32 arrays, non_gray.astype(float) is float64
+        }
+}
+
+// stage-1 canvas (recognition.py:75-81): zeros, the normalised clipped crop pasted in.  grid (64, n)
+__global__ __launch_bounds__(256) void aa_canvas1_kernel(const DetInfo* __restrict__ dets, AaPtrs aa)
+{
+    const int d = blockIdx.y;
+    const AaItem& I = aa.k0[d];
+    if (I.radius <= 0) return;
+    const DetInfo& D = dets[d];
+    const Boxes& b = D.b1;
+    const int npx = I.H * I.W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
+        const int r = p / I.W, c = p - r * I.W;
+        const bool in = r >= b.vv1 && r < b.vv2 && c >= b.uu1 && c < b.uu2;
+        for (int ch = 0; ch < 3; ++ch) I.a[(size_t)p * 3 + ch] = in ? frame_px(D, b.v1 + r - b.vv1, b.u1 + c - b.uu1, ch) : 0.0;
+    }
+}
+
+// keep masks as float (recognition.py:94-95,103).  grid (64, n*K)
+__global__ __launch_bounds__(256) void aa_keep_fill_kernel(const DetInfo* __restrict__ dets, const float* __restrict__ y1, int K, AaPtrs aa)
+{
+    const int t = blockIdx.y;
+    const AaItem& I = aa.k2[t];
+    if (I.radius <= 0) return;
+    const int d = t / K, slot = t - d * K;
+    const float th = dets[d].th_o[slot];
+    const float* y1d = y1 + (size_t)d * 16384 * 4;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < 16384; p += gridDim.x * 256) {
+        const float* q = y1d + (size_t)p * 4;
+        I.a[p] = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
+    }
+}
+
+// filtered keep-mask range -> Stage1 (clip=True of the :103 resize).  one thread per (detection, slot)
+__global__ void aa_keep_range_kernel(Stage1* __restrict__ s1, int n, int K, AaPtrs aa)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * K) return;
+    const AaItem& I = aa.k2[t];
+    if (I.radius <= 0) return;
+    const int d = t / K, slot = t - d * K;
+    s1[d].kmin[slot] = I.vmin;
+    s1[d].kmax[slot] = I.vmax;
+}
+
+// stage-2 canvases (recognition.py:113-120).  grid (64, n*K)
+__global__ __launch_bounds__(256) void aa_canvas2_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
+                                                         const float* __restrict__ y1, int K, AaPtrs aa)
+{
+    const int t = blockIdx.y;
+    const AaItem& I = aa.k1[t];
+    if (I.radius <= 0) return;
+    const int d = t / K, slot = t - d * K;
+    const DetInfo& D = dets[d];
+    const Stage1& S = s1[d];
+    const float* y1d = y1 + (size_t)d * 16384 * 4;
+    const double* kp = aa.k2[t].radius > 0 ? aa.k2[t].a : nullptr;     // (never both: stage-2 side > 128 implies stage-1 side > 128)
+    const int npx = I.H * I.W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
+        const int r = p / I.W, c = p - r * I.W;
+        int fy = 0, fx = 0;
+        const bool fg = stage2_fg(D, S, y1d, kp, slot, r, c, &fy, &fx);
+        for (int ch = 0; ch < 3; ++ch) I.a[(size_t)p * 3 + ch] = fg ? frame_px(D, fy, fx, ch) : 0.0;
+    }
+}
+
+// the five maps of a candidate the back-resizes read (recognition.py:134-146).  grid (64, n*K)
+__global__ __launch_bounds__(256) void aa_back_fill_kernel(const float* __restrict__ y2, AaPtrs aa)
+{
+    const int t = blockIdx.y;
+    const AaItem& I = aa.k3[t * 5];
+    if (I.radius <= 0) return;
+    const float* y2c = y2 + (size_t)t * 16384 * 4;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < 16384; p += gridDim.x * 256) {
+        double prob, ng, pred[3];
+        cand_raw(y2c + (size_t)p * 4, &prob, &ng, pred);
+        I.a[p] = prob;
+        for (int ch = 0; ch < 3; ++ch) I.a[(size_t)(1 + ch) * 16384 + p] = pred[ch];
+        I.a[(size_t)4 * 16384 + p] = ng;
+    }
+}
+
+// filtered ranges -> CandRange.  one thread per candidate
+__global__ void aa_back_range_kernel(CandRange* __restrict__ crange, int n_cand, AaPtrs aa)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_cand) return;
+    const AaItem* I = aa.k3 + (size_t)t * 5;
+    if (I[0].radius <= 0) return;
+    CandRange R;
+    R.pmin = I[0].vmin; R.pmax = I[0].vmax;
+    R.qmin = fmin(I[1].vmin, fmin(I[2].vmin, I[3].vmin));
+    R.qmax = fmax(I[1].vmax, fmax(I[2].vmax, I[3].vmax));
+    R.gmin = I[4].vmin; R.gmax = I[4].vmax;
+    crange[t] = R;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -697,7 +951,9 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
 
     // -- per-detection constants + stage-1 geometry (recognition.py:71-79)
     std::vector<DetInfo> hd(n);
-    long long corr_total = 0;
+    long long corr_total = 0, cv_total = 0;
+    int max_side = 0;
+    const bool use_aa = opt.resize_anti_aliasing != 0;
     for (int i = 0; i < n; ++i) {
         const p2p_detection& dt = dets[perm[i]];
         const p2p_object& ob = objects[dt.object];
@@ -722,6 +978,13 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         D.corr_cap = D.ok1 ? (int)(side * side) : 0;
         D.corr_off = corr_total;
         corr_total += (long long)D.corr_cap * 5 * K;
+        D.aa = use_aa ? 1 : 0;
+        D.cv_off = cv_total;
+        if (use_aa && D.ok1 && side > 128) {
+            if (side > 4096) { set_error("detection %d: crop side %lld exceeds the anti-aliasing table (4096)", perm[i], side); return P2P_ERR_CAPACITY; }
+            cv_total += (long long)(1 + K) * D.corr_cap * 3;
+        }
+        if (D.ok1) max_side = std::max(max_side, (int)side);
     }
     if ((rc = SL.det.reserve(sizeof(DetInfo) * n))) return rc;
     if ((rc = SL.s1.reserve(sizeof(Stage1) * n))) return rc;
@@ -735,6 +998,21 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     if ((rc = SL.x2.reserve(sizeof(float) * 16384 * 3 * (size_t)n * K))) return rc;
     if ((rc = SL.y2.reserve(sizeof(float) * 16384 * 4 * (size_t)n * K))) return rc;
     if ((rc = SL.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
+    if ((rc = SL.crange.reserve(sizeof(CandRange) * (size_t)n * K))) return rc;
+    AaPtrs aa = {nullptr, nullptr, nullptr, nullptr};
+    AaBufs aab = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    AaTable aat;
+    const int aa_n_items = n + 7 * n * K;
+    if (use_aa) {
+        if ((rc = aa_table_get(X.device, &aat))) return rc;
+        const size_t cvb = sizeof(double) * (size_t)std::max<long long>(cv_total, 1), plane = sizeof(double) * 16384 * (size_t)n * K;
+        if ((rc = SL.aa_items.reserve(sizeof(AaItem) * (size_t)aa_n_items)) || (rc = SL.aa_cv.reserve(cvb)) || (rc = SL.aa_cv_tmp.reserve(cvb)) ||
+            (rc = SL.aa_kp.reserve(plane)) || (rc = SL.aa_kp_tmp.reserve(plane)) || (rc = SL.aa_bk.reserve(plane * 5)) || (rc = SL.aa_bk_tmp.reserve(plane * 5))) return rc;
+        AaItem* it = SL.aa_items.as<AaItem>();
+        aa = {it, it + n, it + n + n * K, it + n + 2 * n * K};
+        aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_kp.as<double>(), SL.aa_kp_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
+    }
+    const int canvas_elems = max_side * max_side * 3;
     HIP_TRY(hipMemcpyAsync(SL.det.p, hd.data(), sizeof(DetInfo) * n, hipMemcpyHostToDevice, st));
 
     const DetInfo* d_det = SL.det.as<DetInfo>();
@@ -800,7 +1078,13 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     };
 
     // -- stage 1
-    hipLaunchKernelGGL(stage1_input_kernel, dim3(n * 64), dim3(256), 0, st, d_det, x1);
+    if (use_aa) {      // anti-aliased stage-1 canvases (sides > 128): build, filter in place
+        hipLaunchKernelGGL(aa_plan_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_det, d_s1, n, K, 0, aat, aab, aa);
+        hipLaunchKernelGGL(aa_canvas1_kernel, dim3(64, n), dim3(256), 0, st, d_det, aa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_aa_filter(aa.k0, n, canvas_elems, st));
+    }
+    hipLaunchKernelGGL(stage1_input_kernel, dim3(n * 64), dim3(256), 0, st, d_det, x1, aa);
     HIP_TRY(hipGetLastError());
     if ((rc = forward_groups(1, x1, y1))) return rc;
     if (opt.inject1 && (rc = inject(opt.inject1, y1, 16384 * 4))) return rc;
@@ -808,7 +1092,17 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     HIP_TRY(hipGetLastError());
 
     // -- stage 2
-    hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, x2);
+    if (use_aa) {      // anti-aliased keep masks (stage-1 sides < 128) and stage-2 canvases (sides > 128)
+        hipLaunchKernelGGL(aa_plan_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_det, d_s1, n, K, 1, aat, aab, aa);
+        hipLaunchKernelGGL(aa_keep_fill_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, y1, K, aa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_aa_filter(aa.k2, n * K, 16384, st));
+        hipLaunchKernelGGL(aa_keep_range_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_s1, n, K, aa);
+        hipLaunchKernelGGL(aa_canvas2_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, d_s1, y1, K, aa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_aa_filter(aa.k1, n * K, canvas_elems, st));
+    }
+    hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, x2, aa);
     HIP_TRY(hipGetLastError());
     if ((rc = forward_groups(K, x2, y2))) return rc;
     if (opt.inject2) {
@@ -835,9 +1129,21 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
                                    hipMemcpyHostToDevice, st));
     }
 
+    // -- ranges of the back-resize inputs (clip=True), anti-aliased maps where the stage-2 side is < 128
+    CandRange* d_cr = SL.crange.as<CandRange>();
+    hipLaunchKernelGGL(cand_range_kernel, dim3(n * K), dim3(256), 0, st, y2, d_cr);
+    HIP_TRY(hipGetLastError());
+    if (use_aa) {
+        hipLaunchKernelGGL(aa_back_fill_kernel, dim3(64, n * K), dim3(256), 0, st, y2, aa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_aa_filter(aa.k3, 5 * n * K, 16384, st));
+        hipLaunchKernelGGL(aa_back_range_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_cr, n * K, aa);
+        HIP_TRY(hipGetLastError());
+    }
+
     // -- correspondences, PnP-RANSAC, selection
     hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
-                       SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>());
+                       SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>(), d_cr, aa);
     HIP_TRY(hipGetLastError());
     const int iters = opt.ransac_iterations > 0 ? opt.ransac_iterations : 100;
     const double rerr = opt.reprojection_error > 0 ? opt.reprojection_error : 5.0;
@@ -869,7 +1175,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         if (want_pred) HIP_TRY(hipMemsetAsync(SL.pred.p, 0, (size_t)opt.pred_stride * n, ts));
         hipLaunchKernelGGL(render_best_kernel, dim3(64, n), dim3(256), 0, ts, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
                            want_mask ? SL.mask.as<unsigned char>() : nullptr, (long long)opt.mask_stride,
-                           want_pred ? SL.pred.as<unsigned char>() : nullptr, (long long)opt.pred_stride);
+                           want_pred ? SL.pred.as<unsigned char>() : nullptr, (long long)opt.pred_stride, d_cr, aa);
         HIP_TRY(hipGetLastError());
         if (want_mask) HIP_TRY(hipMemcpyAsync(SL.h_mask.p, SL.mask.p, (size_t)opt.mask_stride * n, hipMemcpyDeviceToHost, ts));
         if (want_pred) HIP_TRY(hipMemcpyAsync(SL.h_pred.p, SL.pred.p, (size_t)opt.pred_stride * n, hipMemcpyDeviceToHost, ts));
@@ -877,7 +1183,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     if (want_iou) {
         HIP_TRY(hipMemsetAsync(SL.mstat.p, 0, sizeof(unsigned long long) * 3 * n, ts));
         hipLaunchKernelGGL(mask_iou_kernel, dim3(32, n), dim3(256), 0, ts, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
-                           SL.dmask.as<unsigned char>(), (long long)opt.det_mask_stride, SL.mstat.as<unsigned long long>());
+                           SL.dmask.as<unsigned char>(), (long long)opt.det_mask_stride, SL.mstat.as<unsigned long long>(), d_cr, aa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(SL.h_stat.p, SL.mstat.p, sizeof(unsigned long long) * 3 * n, hipMemcpyDeviceToHost, ts));
     }

@@ -1,0 +1,214 @@
+// Anti-aliased resizes: the Gaussian pre-filter scikit-image 0.15 - 0.18 applies by default before down-scaling
+// (skimage.transform.resize(anti_aliasing=True) -> scipy.ndimage.gaussian_filter(image, sigma, mode, cval) -> warp), for all
+// six resize call sites of est_pose (reference recognition.py:82,103,121,134,144,146).  The reference does not pin its
+// scikit-image version (requirements.txt does not list it): p2p_est_pose_opts.resize_anti_aliasing selects this behaviour,
+// default off = scikit-image <= 0.14.
+//
+// What is restated here is scipy's separable filter exactly as it runs for skimage:
+//   sigma  = max(0, (n_in / n_out - 1) / 2)                                (skimage _warps.resize)
+//   radius = int(4 * sigma + 0.5)                                          (gaussian_filter1d, truncate = 4)
+//   w[x]   = exp((-0.5 / sigma^2) * x^2), x = -radius .. radius, divided by numpy's pairwise sum of the vector
+//   per axis (axis 0 first, then axis 1; the channel axis has sigma 0 and is skipped), per output element
+//       t = in[0] * w[0];  for d = radius .. 1:  t += (in[-d] + in[+d]) * w[d]        (NI_Correlate1D, symmetric branch)
+//   in double, no FMA; the result of each axis pass is stored in the ARRAY's dtype -- float32 for the prob / img_pred maps
+//   (round32), float64 for everything else; borders 'mirror' (d c b | a b c d | c b a) or 'constant' (cval).
+// The images are tiny next to the generator passes (a 300-px crop is 2 MB), so the kernels are plain: one thread per
+// output element, taps from L2.
+#include "pipeline.h"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+
+#pragma clang fp contract(off)
+
+namespace p2p {
+
+namespace {
+
+constexpr int AA_MAX_SIDE = 4096;
+
+// numpy's pairwise summation of a float64 vector (np.add.reduce, pairwise_sum in loops_utils.h): up to 128 elements in 8
+// partial sums, longer vectors split in halves (first half rounded down to a multiple of 8)
+double np_sum(const double* a, int n)
+{
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_sum(a, n2) + np_sum(a + n2, n - n2);
+}
+
+}  // namespace
+
+// sigma / radius / one-sided weights for crop side `side` against the 128-px network resolution:
+// side > 128 -> the side x side canvas is filtered before shrinking to 128; side < 128 -> the 128x128 map is filtered
+// before shrinking to side.  Returns the radius (0 = no filtering); w receives radius + 1 values, centre first.
+int aa_weights_for_side(int side, std::vector<double>& w)
+{
+    w.clear();
+    if (side <= 0 || side == 128) return 0;
+    const double n_in = side > 128 ? (double)side : 128.0, n_out = side > 128 ? 128.0 : (double)side;
+    const double factor = n_in / n_out;
+    double sigma = (factor - 1) / 2;
+    if (!(sigma > 0)) return 0;
+    const int radius = (int)(4.0 * sigma + 0.5);
+    if (radius <= 0) return 0;                     // scipy still correlates with the 1-tap kernel [1.0]: the identity
+    const double sigma2 = sigma * sigma;
+    const double c = -0.5 / sigma2;
+    std::vector<double> phi(2 * radius + 1);
+    for (int x = -radius; x <= radius; ++x) phi[x + radius] = std::exp(c * (double)((long long)x * x));
+    const double s = np_sum(phi.data(), (int)phi.size());
+    w.resize(radius + 1);
+    for (int d = 0; d <= radius; ++d) w[d] = phi[radius + d] / s;
+    return radius;
+}
+
+int aa_table_get(int device, AaTable* out)
+{
+    static std::mutex mu;
+    static std::map<int, AaTable> tables;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tables.find(device);
+    if (it != tables.end()) { *out = it->second; return P2P_OK; }
+    std::vector<double> pool, w;
+    std::vector<int> off(AA_MAX_SIDE + 1, 0), rad(AA_MAX_SIDE + 1, 0);
+    for (int s = 1; s <= AA_MAX_SIDE; ++s) {
+        rad[s] = aa_weights_for_side(s, w);
+        off[s] = (int)pool.size();
+        pool.insert(pool.end(), w.begin(), w.end());
+    }
+    if (pool.empty()) pool.push_back(1.0);
+    double* dw = nullptr;
+    int *doff = nullptr, *drad = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&dw, pool.size() * sizeof(double))) != hipSuccess ||
+        (e = hipMalloc((void**)&doff, off.size() * sizeof(int))) != hipSuccess ||
+        (e = hipMalloc((void**)&drad, rad.size() * sizeof(int))) != hipSuccess ||
+        (e = hipMemcpy(dw, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(doff, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(drad, rad.data(), rad.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) {
+        set_error("anti-aliasing weight table: %s", hipGetErrorString(e));
+        return P2P_ERR_HIP;
+    }
+    AaTable t;
+    t.w = dw; t.off = doff; t.rad = drad; t.max_side = AA_MAX_SIDE;
+    tables[device] = t;            // lives as long as the process (a few MB per device)
+    *out = t;
+    return P2P_OK;
+}
+
+namespace {
+
+__device__ inline int mirror_idx(int i, int n)   // scipy 'mirror' == numpy-pad 'reflect'
+{
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - i : i;
+}
+
+// one axis pass of every item: thread per output element
+template <int AXIS>
+__global__ __launch_bounds__(256) void aa_filter_kernel(const AaItem* __restrict__ items)
+{
+    const AaItem& I = items[blockIdx.y];
+    const int r = I.radius;
+    if (r <= 0) return;
+    const double* src = AXIS == 0 ? I.a : I.tmp;
+    double* dst = AXIS == 0 ? I.tmp : I.a;
+    const int H = I.H, W = I.W, C = I.C;
+    const long long total = (long long)H * W * C;
+    const double* w = I.w;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long long px = e / C;
+        const int x = (int)(px % W), y = (int)(px / W);
+        const int pos = AXIS == 0 ? y : x, len = AXIS == 0 ? H : W;
+        const long long stride = AXIS == 0 ? (long long)W * C : (long long)C;
+        const double* line = src + (AXIS == 0 ? (long long)x * C + c : (long long)y * W * C + c);
+        double t = line[(long long)pos * stride] * w[0];
+        for (int d = r; d >= 1; --d) {
+            const int lo = pos - d, hi = pos + d;
+            double a, b;
+            if (I.mode == 0) {
+                a = line[(long long)mirror_idx(lo, len) * stride];
+                b = line[(long long)mirror_idx(hi, len) * stride];
+            } else {
+                a = lo >= 0 ? line[(long long)lo * stride] : I.cval;
+                b = hi < len ? line[(long long)hi * stride] : I.cval;
+            }
+            t += (a + b) * w[d];
+        }
+        dst[e] = I.round32 ? (double)(float)t : t;
+    }
+}
+
+// [min, max] of every (filtered) image: what skimage's clip=True clips the warp output to.  One block per item.
+__global__ __launch_bounds__(256) void aa_range_kernel(AaItem* __restrict__ items)
+{
+    __shared__ double s_lo[4], s_hi[4];
+    AaItem& I = items[blockIdx.x];
+    if (I.radius <= 0) return;
+    const long long total = (long long)I.H * I.W * I.C;
+    double lo = 1e300, hi = -1e300;
+    for (long long e = threadIdx.x; e < total; e += 256) {
+        const double v = I.a[e];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; }
+        I.vmin = lo; I.vmax = hi;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_aa_filter(AaItem* items, int n_items, int max_elems, hipStream_t s)
+{
+    if (n_items <= 0) return hipSuccess;
+    const int bx = std::max(1, std::min(256, (max_elems + 255) / 256));
+    for (int i0 = 0; i0 < n_items; i0 += 65535) {        // gridDim.y limit
+        const int ni = std::min(65535, n_items - i0);
+        hipLaunchKernelGGL((aa_filter_kernel<0>), dim3(bx, ni), dim3(256), 0, s, items + i0);
+        hipLaunchKernelGGL((aa_filter_kernel<1>), dim3(bx, ni), dim3(256), 0, s, items + i0);
+    }
+    hipLaunchKernelGGL(aa_range_kernel, dim3(n_items), dim3(256), 0, s, items);
+    return hipGetLastError();
+}
+
+}  // namespace p2p
+
+// Test hook (no GPU needed): the host-side weights of one crop side, so that the CPU suite can hold them against
+// scipy.ndimage's own kernel bit for bit.  w must hold 256 doubles; returns the radius, -1 on a bad side.
+extern "C" int p2p_aa_weights(int side, double* w)
+{
+    if (!w || side <= 0 || side > p2p::AA_MAX_SIDE) return -1;
+    std::vector<double> v;
+    const int r = p2p::aa_weights_for_side(side, v);
+    if (r + 1 > 256) return -1;
+    for (int d = 0; d <= r && d < (int)v.size(); ++d) w[d] = v[d];
+    return r;
+}

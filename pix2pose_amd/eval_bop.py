@@ -219,6 +219,7 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
         if not dets:
             continue
         pending = runtime.est_pose_submit(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
+                                          anti_aliasing=bool(cfg.get("resize_anti_aliasing", False)),     # scikit-image >= 0.15 semantics
                                           **(est_pose_kwargs or {}))
         in_flight.append((chunk, owners, pending, t1))
         if len(in_flight) == 2:

@@ -64,6 +64,9 @@ class pix2pose():
         ctx = kwargs.get("ctx") or runtime.default_context(kwargs.get("device", 0))
         weights = weight_fn if isinstance(weight_fn, dict) else W.load_weights(weight_fn, backbone)
         self.ctx = ctx
+        # skimage.transform.resize semantics: False = scikit-image <= 0.14 (no anti-aliasing), True = 0.15 - 0.18 (Gaussian
+        # pre-filter when down-scaling); the reference does not pin the version
+        self.anti_aliasing = bool(kwargs.get("anti_aliasing", False))
         self.generator_train = runtime.Generator(weights, backbone, ctx)
         self._inject = None                    # TEST / BENCH ONLY: (inject1_ptr, inject2_ptr, slots) device maps that replace the decoder outputs
 
@@ -82,7 +85,7 @@ class pix2pose():
         H, Wd = rgb.shape[0], rgb.shape[1]
         inj = {} if self._inject is None else dict(inject1=self._inject[0], inject2=self._inject[1], inject_slots=self._inject[2])
         poses, ex = runtime.est_pose_batch(self.ctx, [self._spec()], [rgb], [(0, 0, [int(b) for b in bbox], self.camK)],
-                                           want_masks=True, **inj)
+                                           want_masks=True, anti_aliasing=self.anti_aliasing, **inj)
         p = poses[0]
         box = np.array(list(p.bbox_t), int)
         if p.status != 0:
@@ -96,7 +99,7 @@ class pix2pose():
         """Many detections of this object at once (the reason this library exists).
         -> list of p2p_pose records (pix2pose_amd._lib.Pose)."""
         dets = [(i, 0, [int(b) for b in bboxes[i]], self.camK if camKs is None else camKs[i]) for i in range(len(bboxes))]
-        return runtime.est_pose_batch(self.ctx, [self._spec()], list(rgbs), dets)[0]
+        return runtime.est_pose_batch(self.ctx, [self._spec()], list(rgbs), dets, anti_aliasing=self.anti_aliasing)[0]
 
     def pnp_ransac(self, rgb_aug_test, img_prob_ori, non_zero, v1, v2, u1, u2):
         """Reference recognition.py:195-224 with the solve on the GPU."""

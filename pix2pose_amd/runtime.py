@@ -173,7 +173,7 @@ def _image_struct(img):
 
 
 def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks, det_masks, ransac_iterations,
-             reprojection_error, confidence):
+             reprojection_error, confidence, anti_aliasing=False):
     """Build the C arrays of one batch call.  -> (objs, imgs, dets, opts, extras, keep-alive list)"""
     n = len(detections)
     if ransac_iterations > _lib.MAX_RANSAC_ITERATIONS:
@@ -195,6 +195,7 @@ def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_m
     opts = _lib.EstPoseOpts()
     opts.ransac_iterations, opts.reprojection_error, opts.confidence = ransac_iterations, reprojection_error, confidence
     opts.inject1, opts.inject2, opts.inject_slots = inject1, inject2, inject_slots
+    opts.resize_anti_aliasing = 1 if anti_aliasing else 0
     extras = {}
     if want_masks and n:
         def hw(i):
@@ -221,12 +222,13 @@ def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_m
 
 def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
                    want_masks=False, debug=False, ransac_iterations=0, reprojection_error=0.0, confidence=0.0,
-                   det_masks=None):
+                   det_masks=None, anti_aliasing=False):
     """detections: list of (image_idx, object_idx, bbox[v1,u1,v2,u2], camK 3x3).
+    anti_aliasing: scikit-image 0.15-0.18 resize semantics (Gaussian pre-filter when down-scaling); default = <= 0.14.
     Returns (poses: list[_lib.Pose], extras: dict)."""
     n = len(detections)
     objs, imgs, dets, opts, extras, keep = _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks,
-                                                    det_masks, ransac_iterations, reprojection_error, confidence)
+                                                    det_masks, ransac_iterations, reprojection_error, confidence, anti_aliasing)
     poses = (_lib.Pose * max(n, 1))()
     K = max([len(o.th_outlier) for o in objects], default=0)
     if debug and n:
@@ -257,13 +259,14 @@ class PendingBatch:
 
 
 def est_pose_submit(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
-                    ransac_iterations=0, reprojection_error=0.0, confidence=0.0, want_masks=False, det_masks=None) -> PendingBatch:
+                    ransac_iterations=0, reprojection_error=0.0, confidence=0.0, want_masks=False, det_masks=None,
+                    anti_aliasing=False) -> PendingBatch:
     """Asynchronous est_pose_batch for detection streams: enqueue and return; at most two batches in
     flight per context.  The PnP-RANSAC tail of this batch overlaps the generator passes of the next.
     ``want_masks`` / ``det_masks`` as in est_pose_batch: the arrays in ``PendingBatch.extras`` are filled by collect()."""
     n = len(detections)
     objs, imgs, dets, opts, extras, keep = _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks,
-                                                    det_masks, ransac_iterations, reprojection_error, confidence)
+                                                    det_masks, ransac_iterations, reprojection_error, confidence, anti_aliasing)
     ticket = C.c_int(-1)
     _lib.check(_lib.lib().p2p_est_pose_submit(ctx.handle, objs, len(objects), imgs, len(images), dets, n, C.byref(opts),
                                               C.byref(ticket)), "p2p_est_pose_submit")

@@ -27,10 +27,10 @@ def rig():
     return ctx, gen, spec
 
 
-def _oracle(sc, i, predict, dbg):
+def _oracle(sc, i, predict, dbg, anti_aliasing=False):
     from oracle import est_pose_oracle as E
     img_i, _, bbox, K = sc["dets"][i]
-    return E.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], TH_O, TH_I, debug=dbg)
+    return E.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], TH_O, TH_I, debug=dbg, anti_aliasing=anti_aliasing)
 
 
 def _compare(p, ex, i, ref, dbg, injected):
@@ -64,7 +64,7 @@ def _compare(p, ex, i, ref, dbg, injected):
         np.testing.assert_array_equal(ex["img_pred"][i][:(v2 - v1) * (u2 - u1) * 3].reshape(v2 - v1, u2 - u1, 3), ref[0])
 
 
-def _run_injected(rig, sc):
+def _run_injected(rig, sc, anti_aliasing=False):
     import torch
     from pix2pose_amd.runtime import est_pose_batch
     ctx, gen, spec = rig
@@ -72,7 +72,7 @@ def _run_injected(rig, sc):
     j2 = torch.from_numpy(sc["inject2"]).cuda()
     torch.cuda.synchronize()
     poses, ex = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=j1.data_ptr(), inject2=j2.data_ptr(),
-                               inject_slots=3, want_masks=True, debug=True)
+                               inject_slots=3, want_masks=True, debug=True, anti_aliasing=anti_aliasing)
     n_ok = 0
     for i in range(len(sc["dets"])):
         def predict(x, stage, slots=None, i=i):
@@ -82,7 +82,7 @@ def _run_injected(rig, sc):
                 m = sc["inject2"][i][slots]
             return [m[..., :3].copy(), m[..., 3:].copy()]
         dbg = {}
-        ref = _oracle(sc, i, predict, dbg)
+        ref = _oracle(sc, i, predict, dbg, anti_aliasing)
         _compare(poses[i], ex, i, ref, dbg, True)
         if poses[i].status == 0:
             n_ok += 1
@@ -104,6 +104,44 @@ def test_injected_scenes_general_crop_sizes(rig):
     """Non-identity resizes (crop sides 74..300 px, up- and down-sampling), 'next' row f-3."""
     sc = synth.make_scene(10, seed=4, bbox_side=(50, 200))
     assert _run_injected(rig, sc) >= 8
+
+
+def test_anti_aliased_resizes_small_crops(rig):
+    """p2p_est_pose_opts.resize_anti_aliasing (scikit-image 0.15 - 0.18): crop sides 60..126 px -- the keep mask and the
+    prob / img_pred / non_gray maps are Gaussian-filtered (scipy.ndimage.gaussian_filter in the oracle, csrc/resize_aa.hip on
+    the device; float32 maps rounded per axis pass) before they shrink to the crop; network inputs are up-scaled (no filter).
+    Same exactness as without the filter: masks, u8 images, counts, boxes bit for bit."""
+    sc = synth.make_scene(8, seed=41, bbox_side=(40, 84))
+    assert _run_injected(rig, sc, anti_aliasing=True) >= 6
+
+
+def test_anti_aliased_resizes_large_crops(rig):
+    """Crop sides 136..450 px: the stage-1 / stage-2 canvases cut from the frame are filtered ('mirror' border) before they
+    shrink to 128x128; stage-2 re-crops below 128 px take the other branch in the same detection."""
+    sc = synth.make_scene(8, seed=42, bbox_side=(91, 300))
+    assert _run_injected(rig, sc, anti_aliasing=True) >= 6
+
+
+def test_anti_aliasing_off_and_on_differ_and_identity_at_128(rig):
+    import torch
+    from pix2pose_amd.runtime import est_pose_batch
+    ctx, gen, spec = rig
+    sc = synth.make_scene(3, seed=43, bbox_side=(150, 200))
+    j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
+    torch.cuda.synchronize()
+    kw = dict(inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3, debug=True)
+    off = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], **kw)[1]
+    on = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], anti_aliasing=True, **kw)[1]
+    assert np.abs(off["x1"] - on["x1"]).max() > 0.05          # random frames: the filter changes the network input a lot
+    sc = synth.make_scene(3, seed=44)                          # 128-px crops: sigma = 0, the option changes nothing
+    j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
+    torch.cuda.synchronize()
+    kw = dict(inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3, debug=True, want_masks=True)
+    p0, e0 = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], **kw)
+    p1, e1 = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], anti_aliasing=True, **kw)
+    for k in ("x1", "x2", "cand", "valid_mask", "img_pred"):
+        np.testing.assert_array_equal(e0[k], e1[k])
+    assert [tuple(a.R) for a in p0] == [tuple(b.R) for b in p1]
 
 
 def test_real_generator_and_frame_border_crops(rig):

@@ -98,8 +98,11 @@ def test_resize_restatement_matches_scipy_zoom(n_in, n_out, mode, cval):
     z = ndi.zoom(a, n_out / n_in, order=1, mode="mirror" if mode == "reflect" else "grid-constant", cval=cval, grid_mode=True)
     if z.shape != (n_out, n_out):
         return      # zoom rounds the output size itself for some ratios
-    r = resize_bilinear(a, (n_out, n_out), mode, cval)
+    r = resize_bilinear(a, (n_out, n_out), mode, cval, clip=False)     # the warp itself; skimage then clips (own test below)
     assert np.abs(z - r).max() < 1e-12
+    rc = resize_bilinear(a, (n_out, n_out), mode, cval)
+    keep = (r == cval) if (mode == "constant" and not (a.min() <= cval <= a.max())) else np.zeros_like(r, bool)
+    assert np.array_equal(rc, np.where(keep, cval, np.clip(r, a.min(), a.max())))
 
 
 def test_shard_detections_balanced_and_grouped():
@@ -186,3 +189,73 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_anti_aliasing_weights_equal_scipy_gaussian_kernel():
+    """The library's host-side Gaussian weights (p2p_aa_weights: sigma = (in/out - 1)/2, radius int(4 sigma + .5),
+    numpy's pairwise normalisation) against scipy.ndimage's own kernel builder: identical up to the last bit of exp().
+    numpy >= 1.19 evaluates float64 exp with its own SIMD routine, which differs from libm's by 1 ulp on ~30 % of the
+    vectors; the reference's era (numpy <= 1.18) called libm like the library does.  So: bit-exact against the scipy
+    formula evaluated with libm's exp, and within a few ulp of today's scipy."""
+    import ctypes as C
+    import math
+    from scipy.ndimage import _filters
+    from pix2pose_amd import _lib
+    L = _lib.lib()
+    n = 0
+    for side in list(range(5, 128)) + list(range(129, 700, 3)):
+        w = (C.c_double * 256)()
+        r = L.p2p_aa_weights(side, w)
+        n_in, n_out = (side, 128) if side > 128 else (128, side)
+        sigma = max(0.0, (n_in / n_out - 1) / 2)
+        lw = int(4.0 * float(sigma) + 0.5)
+        assert r == lw, side
+        if lw == 0:
+            continue
+        n += 1
+        x = np.arange(-lw, lw + 1)
+        phi = np.array([math.exp(-0.5 / (sigma * sigma) * float(v * v)) for v in x])
+        phi = phi / phi.sum()
+        assert np.array_equal(np.array(w[:lw + 1]), phi[lw:]), side
+        k = _filters._gaussian_kernel1d(sigma, 0, lw)[::-1]
+        assert np.abs(np.array(w[:lw + 1]) - k[lw:]).max() <= 1e-15 * k.max(), side     # a few ulp: exp() and the normalising sum
+    assert n > 250
+    assert L.p2p_aa_weights(128, (C.c_double * 256)()) == 0 and L.p2p_aa_weights(0, (C.c_double * 256)()) == -1
+
+
+@settings(max_examples=30, deadline=None)
+@given(st.integers(130, 400), st.sampled_from(["reflect", "constant"]), st.sampled_from([0.0, 0.5, 1.0]), st.booleans())
+def test_resize_restatement_anti_aliasing_and_clip(n_in, mode, cval, f32):
+    """Down-scaling with anti_aliasing: Gaussian filter (scipy itself) then the bilinear warp == gaussian_filter + zoom of
+    current scipy (what scikit-image >= 0.19 literally does for float images); clip keeps the result inside the filtered
+    image's range, and a float32 map is filtered in float32 like scipy does for skimage."""
+    from scipy import ndimage as ndi
+    from oracle.est_pose_oracle import resize_bilinear
+    a = np.random.RandomState(n_in).rand(n_in, n_in)
+    if f32:
+        a = a.astype(np.float32)
+    ndi_mode = "mirror" if mode == "reflect" else "constant"
+    sig = (n_in / 128 - 1) / 2
+    filt = ndi.gaussian_filter(a, (sig, sig), cval=cval, mode=ndi_mode)
+    assert filt.dtype == a.dtype
+    z = ndi.zoom(filt.astype(np.float64), 128 / n_in, order=1, mode="mirror" if mode == "reflect" else "grid-constant", cval=cval, grid_mode=True)
+    r = resize_bilinear(a, (128, 128), mode, cval, anti_aliasing=True)
+    if z.shape == (128, 128):
+        zc = np.clip(z, filt.min(), filt.max())
+        assert np.abs(zc - r).max() < 1e-12
+    assert r.min() >= float(filt.min()) and r.max() <= float(filt.max())
+
+
+def test_resize_clip_preserves_cval_like_skimage():
+    """clip=True: up-scaling a map whose values all sit below cval -- border pixels mix cval in, are clipped back to the
+    map's maximum, and pixels exactly equal to cval are left alone (skimage _clip_warp_output)."""
+    from oracle.est_pose_oracle import resize_bilinear
+    a = np.full((8, 8), 0.25)
+    a[3, 3] = 0.3
+    r = resize_bilinear(a, (20, 20), "constant", 1.0)
+    assert r.max() == 0.3 and r[0, 0] == 0.3                 # the corner mixed cval = 1 in; clipped back to [0.25, 0.3]
+    r2 = resize_bilinear(a, (20, 20), "constant", 1.0, clip=False)
+    assert r2[0, 0] > 0.5
+    b = np.ones((8, 8))
+    r3 = resize_bilinear(b, (20, 20), "constant", 0.0)       # all-ones mask, cval 0 outside its range: everything clips up to 1
+    assert r3.min() == 1.0

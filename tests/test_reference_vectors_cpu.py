@@ -36,9 +36,13 @@ def test_shim_get_boxes_matches_reference():
         assert [int(v) for v in out] == c["out"], c
 
 
-def test_est_pose_matches_reference():
+@pytest.mark.parametrize("key", ["scenes", "scenes_aa"])
+def test_est_pose_matches_reference(key):
+    """"scenes": resize stand-in without anti-aliasing (scikit-image <= 0.14); "scenes_aa": with the Gaussian pre-filter of
+    scikit-image 0.15 - 0.18 (scipy.ndimage.gaussian_filter itself)."""
     n = 0
-    for s in G["scenes"]:
+    aa = key == "scenes_aa"
+    for s in G[key]:
         spec = s["spec"]
         sc = synthetic.make_scene(spec["n_det"], seed=spec["seed"], bbox_side=tuple(spec["bbox_side"]), outlier_frac=spec.get("outlier_frac", 0.2))
         for i, gd in enumerate(s["dets"]):
@@ -51,7 +55,7 @@ def test_est_pose_matches_reference():
                 sums.append(float(np.asarray(x, np.float64).sum()))
                 m = sc["inject1"][i][None] if stage == 1 else sc["inject2"][i][slots]
                 return [m[..., :3].copy(), m[..., 3:].copy()]
-            r = O.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], G["th_outlier"], G["th_inlier"])
+            r = O.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], G["th_outlier"], G["th_inlier"], anti_aliasing=aa)
             assert [int(v) for v in r[5]] == gd["bbox_t"]
             assert np.allclose(sums, gd["x_sums"], rtol=0, atol=1e-6)          # the network inputs of both stages
             ok = not (isinstance(r[1], (int, np.integer)) and r[1] == -1)
@@ -64,6 +68,24 @@ def test_est_pose_matches_reference():
             assert int(np.sum(r[1])) == gd["mask_sum"] and _crc(np.packbits(r[1])) == gd["mask_crc"]
             assert list(r[0].shape) == gd["img_pred_shape"] and _crc(r[0]) == gd["img_pred_crc"]
     assert n >= 10
+
+
+def test_anti_aliasing_changes_the_result():
+    """The two scikit-image generations are really different inputs to the network and different masks (otherwise the
+    switch would be untested): same scene, both settings."""
+    sc = synthetic.make_scene(2, seed=513, bbox_side=(150, 210))
+    outs = []
+    for aa in (False, True):
+        dbg = {}
+        i = 0
+        img_i, _, bbox, K = sc["dets"][i]
+
+        def predict(x, stage, slots=None):
+            m = sc["inject1"][i][None] if stage == 1 else sc["inject2"][i][slots]
+            return [m[..., :3].copy(), m[..., 3:].copy()]
+        O.est_pose(sc["images"][img_i], bbox, predict, K, sc["obj_param"], G["th_outlier"], G["th_inlier"], debug=dbg, anti_aliasing=aa)
+        outs.append(dbg["x1"])
+    assert np.abs(outs[0] - outs[1]).max() > 0.05
 
 
 def test_degenerate_boxes_match_reference():

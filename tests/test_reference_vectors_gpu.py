@@ -20,20 +20,23 @@ def _crc(a):
     return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
 
 
-def test_est_pose_pipeline_matches_reference_vectors():
+@pytest.mark.parametrize("key", ["scenes", "scenes_aa"])
+def test_est_pose_pipeline_matches_reference_vectors(key):
+    """"scenes_aa": p2p_est_pose_opts.resize_anti_aliasing = 1 against the reference run with an anti-aliasing resize
+    (scikit-image 0.15 - 0.18 semantics; the Gaussian filter there was scipy.ndimage's own)."""
     import torch
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
     ctx = Context(0, max_batch=16)
     gen = Generator(W.synthetic_weights("paper", 1), "paper", ctx)
     spec = ObjectSpec(gen, synthetic.OBJ_PARAM, G["th_outlier"], G["th_inlier"])
     n = 0
-    for s in G["scenes"]:
+    for s in G[key]:
         sp = s["spec"]
         sc = synthetic.make_scene(sp["n_det"], seed=sp["seed"], bbox_side=tuple(sp["bbox_side"]), outlier_frac=sp.get("outlier_frac", 0.2))
         j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
         torch.cuda.synchronize()
         poses, ex = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=j1.data_ptr(), inject2=j2.data_ptr(),
-                                   inject_slots=3, want_masks=True, debug=True)
+                                   inject_slots=3, want_masks=True, debug=True, anti_aliasing=key == "scenes_aa")
         H, Wd = sc["images"].shape[1:3]
         for i, gd in enumerate(s["dets"]):
             p = poses[i]
