@@ -4,10 +4,10 @@
 // The heads are a 3x3-tap convolution over the 64x64 grid with 16 outputs (4 sub-pixel phases x
 // (x, y, z, prob)), K = 9 x 128.  As an implicit GEMM with only 16 output columns the layer is pure
 // operand traffic: every input pixel is gathered nine times (once per tap) and the generic kernel
-// (igemm.hip) moved 3.6 GB per launch for a 0.54 GB tensor.  Here a workgroup walks full-width row tiles
-// (TH rows each) of one sample, brings the (TH+2) x 66 halo of a 32-channel slice into LDS ONCE (split into f16
-// hi / lo halves on the way, like the igemm loader), and all nine taps read their operands from that
-// image.  HBM traffic = the tensor once (+ halo rows out of L2) + the output.
+// (igemm.hip) moved 3.6 GB per launch for a 0.54 GB tensor.  Here a workgroup owns 16 full-width grid rows of one
+// sample and, per 32-channel slice, sweeps them with a rolling window of 6 rows x 66 columns in LDS (split into f16
+// hi / lo halves on the way, like the igemm loader); all nine taps read their operands from that image.
+// HBM traffic = the tensor 1.125 times (18 rows fetched per 16 rows of output) + the output.
 //
 // Arithmetic: PREC_F16X3 only (v_mfma_f32_16x16x32_f16, three products per block, fp32 accumulate);
 // the GEMM is taken transposed (rows = the 16 outputs, columns = 16 consecutive pixels) so that a lane
@@ -23,27 +23,45 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int HEADS_TH = 4;                 // grid rows per tile (one per wave)
-constexpr int HEADS_TILES = 4;              // row tiles a workgroup walks
+constexpr int HEADS_TH = 4;                 // grid rows per step (one per wave)
+constexpr int HEADS_TILES = 4;              // steps a workgroup walks: 16 consecutive grid rows of one sample
 constexpr int HEADS_W = 64;                 // grid width (full rows: the x halo is the zero padding)
 constexpr int HEADS_WP = HEADS_W + 2;
-constexpr int HEADS_HP = HEADS_TH + 2;
-constexpr int HEADS_REC = 144;              // bytes per halo pixel: [hi f16 x32 | lo f16 x32 | pad]; 36 dwords => conflict-free b128
+constexpr int HEADS_RING = HEADS_TH + 2;    // LDS row ring: the 6 input rows a step reads; 4 of them are replaced per step
 constexpr int HEADS_CIN = 128;
 constexpr int HEADS_CHUNKS = HEADS_CIN / 32;
-constexpr int HEADS_LOADS = HEADS_HP * HEADS_W * 8 / 256;   // float4 loads per thread per chunk (12)
+constexpr int HEADS_LOADS = HEADS_TH * HEADS_W * 8 / 256;   // float4 loads per thread per step (8)
+
+// LDS image of a 32-channel slice: EIGHT PLANES -- the four 16-byte k-chunks of the hi halves, then of the lo halves --
+// each holding one 16-byte slot per pixel of the 6 x 66 ring.  The B operand of v_mfma_f32_16x16x32_f16 is read by lane
+// (pixel li, k-chunk lg); ds_read_b128 serves lanes in 16-lane groups that mix k-chunks 0 and 1 (or 2 and 3) of DIFFERENT
+// pixels ({0-3,12-15 | 20-27}: MI355X_MICROARCH.md, LDS), so a per-pixel record [hi x32 | lo x32] puts chunk 1 of pixel
+// li + 4.. on the slots chunk 0 of pixel li uses (2-way on 7 of 8 slots: SQ_LDS_BANK_CONFLICT was half of the LDS cycles
+// and the kernel was bound by its LDS reads).  With one plane per chunk a group reads 8 + 8 consecutive slots of two planes
+// whose bases differ by a multiple of 256 B: conflict-free.  Planes 2,3 start 32 B later than a multiple of 256 B so that
+// the ds_write_b64 stores of a pixel's quads (two per plane) spread over the 32 store banks (2-way instead of 4-way).
+constexpr int HEADS_PLANE = HEADS_RING * HEADS_WP * 16;     // 6336 B
+constexpr int HEADS_P1 = 6400, HEADS_P2 = 12832, HEADS_P3 = HEADS_P2 + 6400, HEADS_LO = HEADS_P3 + 6400;   // 25632
+constexpr int HEADS_XBYTES = 2 * HEADS_LO;
+// the weight fragments of a slice (9 taps x 16 outputs x [hi x32 | lo x32]) live in LDS too, in the same plane form (one
+// 16-byte slot per (tap, output row) in each of 8 planes of 9 * 256 B): 72 registers per lane otherwise, which with the
+// four steps' accumulators no longer fit two waves per SIMD
+constexpr int HEADS_WPLANE = 9 * 16 * 16;    // 2304 B = 9 * 256
+constexpr int HEADS_SMEM = HEADS_XBYTES + 8 * HEADS_WPLANE;
+static_assert(HEADS_P1 >= HEADS_PLANE && HEADS_P1 % 256 == 0 && (HEADS_P3 - HEADS_P2) % 256 == 0 && HEADS_LO % 16 == 0, "plane layout");
+
+__device__ inline int heads_plane(int c) { return c == 0 ? 0 : c == 1 ? HEADS_P1 : c == 2 ? HEADS_P2 : HEADS_P3; }
 
 __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[HEADS_HP * HEADS_WP * HEADS_REC];
+    __shared__ __attribute__((aligned(16))) char smem[HEADS_SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // a workgroup walks HEADS_TILES consecutive row tiles of one sample (the load pipeline keeps running
-    // across tiles).  XCD-aware order: block b runs on XCD b % 8; every XCD gets a contiguous run of
-    // workgroups so the halo rows two neighbours share come out of the same L2
+    // a workgroup owns 16 consecutive grid rows of one sample.  XCD-aware order: block b runs on XCD b % 8; every XCD
+    // gets a contiguous run of workgroups so the halo rows two neighbours share come out of the same L2
     const int wgs_per_sample = p.Hg / (HEADS_TH * HEADS_TILES);
     const int n_wgs = p.N * wgs_per_sample;
     const int per_xcd = (n_wgs + 7) / 8;
@@ -63,107 +81,131 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
         w = p.grp[g].w; scale = p.grp[g].scale; shift = p.grp[g].shift;
     }
 
-    // zero the two padding columns once (no chunk ever writes them)
-    for (int i = tid; i < HEADS_HP * 2 * (HEADS_REC / 16); i += 256) {
-        const int r = i / (2 * (HEADS_REC / 16)), rem = i - r * (2 * (HEADS_REC / 16));
-        const int side = rem / (HEADS_REC / 16), q = rem - side * (HEADS_REC / 16);
-        *reinterpret_cast<uint4*>(smem + (r * HEADS_WP + (side ? HEADS_WP - 1 : 0)) * HEADS_REC + q * 16) = make_uint4(0, 0, 0, 0);
+    // zero the two padding columns of every plane once (no slice ever writes them)
+    for (int i = tid; i < 8 * HEADS_RING * 2; i += 256) {
+        const int pl = i / (HEADS_RING * 2), rem = i - pl * (HEADS_RING * 2);
+        const int r = rem >> 1, side = rem & 1;
+        *reinterpret_cast<uint4*>(smem + (pl >= 4 ? HEADS_LO : 0) + heads_plane(pl & 3) + (r * HEADS_WP + (side ? HEADS_WP - 1 : 0)) * 16) = make_uint4(0, 0, 0, 0);
     }
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0].ptr), 0, (int)p.seg_bytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)p.w_bytes, 0x00020000);
 
-    // halo gather: float4 idx = tid + 256 j -> pixel idx/8 (row-major over HP x 64), quad idx%8
-    unsigned x_off[HEADS_LOADS];      // byte offset of the element in row gy_first - 1 + r (may be "negative": only used when valid)
-    int s_off[HEADS_LOADS];
-#pragma unroll
-    for (int j = 0; j < HEADS_LOADS; ++j) {
-        const int idx = tid + 256 * j;
-        const int pix = idx >> 3, q = idx & 7;
-        const int r = pix / HEADS_W, x = pix - r * HEADS_W;
-        x_off[j] = (unsigned)(((((long long)n * p.Hg + gy_first - 1 + r) * HEADS_W + x) * HEADS_CIN + q * 4) * 4);
-        s_off[j] = (r * HEADS_WP + x + 1) * HEADS_REC + q * 8;
-    }
+    // loader: float4 idx = tid + 256 j -> pixel idx/8 (row-major over 4 rows x 64), quad idx%8 (4 channels of the 32-wide slice)
+    // A step brings in 4 new rows; the first step of a slice 6 (two extra passes over rows -1, 0 handled as a half step).
+    const int lq = tid & 7;                                  // quad: k-chunk lq >> 1, 8-byte half lq & 1
+    const int l_dst = heads_plane(lq >> 1) + (lq & 1) * 8;   // + (ring_row * 66 + x + 1) * 16
     f32x4 rx[HEADS_LOADS];
-    auto gload = [&](int it) {                    // it = tile * HEADS_CHUNKS + chunk
-        const int tile = it / HEADS_CHUNKS, chunk = it - tile * HEADS_CHUNKS;
-        const int gy_top = gy_first + tile * HEADS_TH - 1;
-        const unsigned tile_off = (unsigned)(tile * HEADS_TH * HEADS_W * HEADS_CIN * 4);
+    // rows row0 .. row0 + nrows - 1 of the sample (nrows <= 4) into registers
+    auto gload = [&](int chunk, int row0, int nrows) {
 #pragma unroll
         for (int j = 0; j < HEADS_LOADS; ++j) {
-            const int r = (tid + 256 * j) / (8 * HEADS_W);
-            const int gy = gy_top + r;
-            const unsigned off = (gy >= 0 && gy < p.Hg) ? x_off[j] + tile_off : 0xFFFFFFF0u;
+            const int pix = (tid + 256 * j) >> 3;
+            const int r = pix >> 6, x = pix & 63;
+            const int gy = row0 + r;
+            const unsigned off = (r < nrows && gy >= 0 && gy < p.Hg)
+                ? (unsigned)(((((long long)n * p.Hg + gy) * HEADS_W + x) * HEADS_CIN + lq * 4) * 4) : 0xFFFFFFF0u;
             rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, chunk * 128, 0));
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int row0, int nrows) {
 #pragma unroll
         for (int j = 0; j < HEADS_LOADS; ++j) {
+            const int pix = (tid + 256 * j) >> 3;
+            const int r = pix >> 6, x = pix & 63;
+            if (r >= nrows) continue;
+            const int ring = (row0 + r + HEADS_RING) % HEADS_RING;          // row -1 -> slot 5
+            char* dst = smem + l_dst + (ring * HEADS_WP + x + 1) * 16;
             const f32x4 v = rx[j];
             const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
             fp16x2 l01, l23;
             l01[0] = (__fp16)(v[0] - (float)h01[0]); l01[1] = (__fp16)(v[1] - (float)h01[1]);
             l23[0] = (__fp16)(v[2] - (float)h23[0]); l23[1] = (__fp16)(v[3] - (float)h23[1]);
-            *reinterpret_cast<uint2*>(smem + s_off[j]) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-            *reinterpret_cast<uint2*>(smem + s_off[j] + 64) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+            *reinterpret_cast<uint2*>(dst + HEADS_LO) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
         }
     };
 
     // MFMA operands: A = weights (row = output l%16), B = pixels (column = pixel l%16); k = 8 (l/16) + i
     const int li = lane & 15, lg = lane >> 4;
-    const unsigned w_lane = (unsigned)(li * p.K * 4 + lg * 16);           // bytes into the split panel
-    const char* xs = smem + ((wave + 1) * HEADS_WP + li + 1) * HEADS_REC + lg * 16;
+    const char* wsm = smem + HEADS_XBYTES + lg * HEADS_WPLANE + li * 16;   // + tap * 256 (+ 4 planes for lo)
+    const char* xs = smem + heads_plane(lg) + (li + 1) * 16;             // + (ring_row * 66 + 16 m + dx) * 16
 
-    f32x4 acc[4];
+    f32x4 acc[HEADS_TILES][4];
+#pragma unroll
+    for (int t = 0; t < HEADS_TILES; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Slice-major walk: for each 32-channel slice the workgroup sweeps its 16 rows in 4 steps with a rolling 6-row window
+    // (18 rows fetched per 16 rows of output instead of 24); the four steps' accumulators stay in registers across the
+    // slices.  Per slice: a 2-row preamble (rows gy_first - 1, gy_first), then four 4-row fetches (rows gy_first + 1 + 4 s ..);
+    // the next fetch is in flight while a step computes.
+    gload(0, gy_first - 1, 2);
+#pragma unroll 1
+    for (int chunk = 0; chunk < HEADS_CHUNKS; ++chunk) {
+        // weight fragments of this slice: 9 taps x 16 rows x 128 B ([hi x32 | lo x32]; the panel's K order is (tap, cin))
+        f32x4 wq[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = tid + 256 * j;                      // 16-byte piece: tap i / 128, row (i % 128) / 8, piece i % 8
+            const int t = i >> 7, row = (i >> 3) & 15, c8 = i & 7;
+            const unsigned off = i < 9 * 128 ? (unsigned)(row * p.K * 4 + (t * HEADS_CHUNKS + chunk) * 128 + c8 * 16) : 0xFFFFFFF0u;
+            wq[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+        }
+        __syncthreads();                          // every wave is done with the previous slice's last step
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = tid + 256 * j;
+            const int t = i >> 7, row = (i >> 3) & 15, c8 = i & 7;
+            if (i < 9 * 128) *reinterpret_cast<f32x4*>(smem + HEADS_XBYTES + c8 * HEADS_WPLANE + (t * 16 + row) * 16) = wq[j];
+        }
+        lstore(gy_first - 1, 2);
+        gload(chunk, gy_first + 1, 4);
+#pragma unroll
+        for (int step = 0; step < HEADS_TILES; ++step) {
+            if (step) __syncthreads();            // every wave is done reading the rows this store replaces
+            lstore(gy_first + 1 + 4 * step, 4);
+            if (step + 1 < HEADS_TILES) gload(chunk, gy_first + 1 + 4 * (step + 1), 4);      // flies under this step's MFMAs
+            else if (chunk + 1 < HEADS_CHUNKS) gload(chunk + 1, gy_first - 1, 2);
+            __syncthreads();
+            const int gy = gy_first + 4 * step + wave;                        // this wave's grid row
+            // ring slots of rows gy - 1, gy, gy + 1
+            const int rs0 = (gy - 1 + HEADS_RING) % HEADS_RING, rs1 = gy % HEADS_RING, rs2 = (gy + 1) % HEADS_RING;
+            const char* xr[3] = {xs + rs0 * (HEADS_WP * 16), xs + rs1 * (HEADS_WP * 16), xs + rs2 * (HEADS_WP * 16)};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dx = t % 3 - 1;
+                const char* xt = xr[t / 3] + dx * 16;
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(wsm + t * 256);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(wsm + t * 256 + 4 * HEADS_WPLANE);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(xt + m * 256);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(xt + m * 256 + HEADS_LO);
+                    acc[step][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[step][m], 0, 0, 0);
+                    acc[step][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[step][m], 0, 0, 0);
+                    acc[step][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[step][m], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue.  lane: outputs 4 lg .. 4 lg + 3 = (x, y, z, prob) of phase lg for grid pixel (gy, 16 m + li)
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + lg * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + lg * 4);
-
-    gload(0);
-    for (int it = 0; it < HEADS_TILES * HEADS_CHUNKS; ++it) {
-        const int tile = it / HEADS_CHUNKS, chunk = it - tile * HEADS_CHUNKS;
-        if (chunk == 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // weight fragments of this chunk: 9 taps x (hi, lo); K order is (tap, cin), 128 B per 32-deep block
-        f16x8 wh[9], wl[9];
+    for (int step = 0; step < HEADS_TILES; ++step) {
+        const int oy = 2 * (gy_first + step * HEADS_TH + wave) + (lg >> 1);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int kb = t * HEADS_CHUNKS + chunk;
-            wh[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, kb * 128, 0));
-            wl[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, kb * 128 + 64, 0));
-        }
-        if (it) __syncthreads();             // every wave is done reading the previous slice
-        lstore();
-        __syncthreads();
-        if (it + 1 < HEADS_TILES * HEADS_CHUNKS) gload(it + 1);     // flies under this slice's MFMAs (and the epilogue)
+        for (int m = 0; m < 4; ++m) {
+            const int ox = 2 * (16 * m + li) + (lg & 1);
+            f32x4 v = acc[step][m], o;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const char* xt = xs + (dy * HEADS_WP + dx) * HEADS_REC;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(xt + m * 16 * HEADS_REC);
-                const f16x8 xl = *reinterpret_cast<const f16x8*>(xt + m * 16 * HEADS_REC + 64);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], xh, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xh, acc[m], 0, 0, 0);
-            }
-        }
-        if (chunk == HEADS_CHUNKS - 1) {
-            // lane: outputs 4 lg .. 4 lg + 3 = (x, y, z, prob) of phase lg for grid pixel (gy0 + wave, 16 m + li)
-            const int oy = 2 * (gy_first + tile * HEADS_TH + wave) + (lg >> 1);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int ox = 2 * (16 * m + li) + (lg & 1);
-                f32x4 v = acc[m], o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-                o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
-                o[3] = 1.f / (1.f + __expf(-v[3]));
-                *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Hout + oy) * p.Wout + ox) * 4) = o;
-            }
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+            o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
+            o[3] = 1.f / (1.f + __expf(-v[3]));
+            *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Hout + oy) * p.Wout + ox) * 4) = o;
         }
     }
 }
