@@ -59,3 +59,84 @@ def test_mapping_rejects_incomplete_files():
         CK.convert_named(bad, "paper")
     assert CK._resnet_name("res3d_branch2c") == "res3d_2c" and CK._resnet_name("bn2a_branch1") == "res2a_1"
     assert CK._resnet_name("bn_conv1") == "conv1" and CK._resnet_name("conv4_1") is None
+
+
+def test_read_hdf5_on_keras_file_layouts(monkeypatch, tmp_path):
+    """The HDF5 reader (row f-2) on the two file layouts the reference produces (tools/3_train_pix2pose.py:273-276): a
+    weights-only file (layer groups at the root) and a full model.save file (everything under 'model_weights', plus an
+    'optimizer_weights' group that must be ignored), with Keras' doubled group names ('dense_3/dense_3/kernel:0') and the
+    nested 'model_1' ResNet front.  h5py itself is not in this image, so a dict-backed stand-in with the h5py API
+    (File / Group / Dataset, `in`, [], visititems) carries the tree; with real files the traversal is the same
+    (tools/make_external_vectors.py exercises that where h5py and Keras exist)."""
+    import sys
+    import types
+
+    class Dataset:
+        def __init__(self, a):
+            self.a = np.asarray(a)
+
+        def __array__(self, dtype=None, copy=None):
+            return self.a if dtype is None else self.a.astype(dtype)
+
+    class Group:
+        def __init__(self, tree):
+            self.tree = tree
+
+        def __contains__(self, k):
+            return k in self.tree
+
+        def __getitem__(self, k):
+            v = self.tree[k]
+            return Group(v) if isinstance(v, dict) else v
+
+        def visititems(self, fn, prefix=""):
+            for k, v in self.tree.items():
+                name = prefix + k
+                if isinstance(v, dict):
+                    fn(name, Group(v))
+                    Group(v).visititems(fn, name + "/")
+                else:
+                    fn(name, v)
+
+    class File(Group):
+        trees = {}
+
+        def __init__(self, path, mode="r"):
+            super().__init__(File.trees[path])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    h5 = types.ModuleType("h5py")
+    h5.File, h5.Group, h5.Dataset = File, Group, Dataset
+    monkeypatch.setitem(sys.modules, "h5py", h5)
+
+    def tree_of(keras):
+        root = {}
+        for key, arr in keras.items():
+            node = root
+            parts = key.split("/")
+            for p in parts[:-1]:
+                node = node.setdefault(p, {})
+            node[parts[-1]] = Dataset(arr)
+        return root
+
+    for backbone, offset in (("paper", 1), ("resnet50", 22)):
+        w = W.synthetic_weights(backbone, 6)
+        keras = _fake_keras(backbone, w, offset)
+        File.trees["weights.hdf5"] = tree_of(keras)
+        File.trees["model.hdf5"] = {"model_weights": tree_of(keras), "optimizer_weights": {"Adam": {"iterations:0": Dataset(np.zeros(1))}}}
+        for fn in ("weights.hdf5", "model.hdf5"):
+            flat = CK.read_hdf5(fn)
+            assert not any("optimizer" in k or "Adam" in k for k in flat)
+            out = CK.convert_named(flat, backbone)
+            assert set(out) == set(w) and all(np.array_equal(out[k], w[k]) for k in w), (backbone, fn)
+    # the command-line entry point writes the artefact the runtime loads
+    File.trees["weights.hdf5"] = tree_of(_fake_keras("paper", W.synthetic_weights("paper", 6), 1))
+    out_fn = str(tmp_path / "obj.npz")
+    assert CK.main(["convert_keras", "weights.hdf5", "paper", out_fn]) == 0
+    w2 = W.load_weights(out_fn, "paper")
+    assert np.array_equal(w2["deconv2.kernel"], W.synthetic_weights("paper", 6)["deconv2.kernel"])
