@@ -64,8 +64,8 @@ PROFILE_SLOTS = 6      # P2P_PROFILE_SLOTS
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
                    ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
                    ("igemm_kernel 128x32 tiles", "igemm_kernel<4, 1, 1, 1, %d>"),
-                   ("igemm_halo_kernel 128x128 tiles (halo-tiled stride-1 multi-tap layers)", "igemm_halo_kernel<2>"),
-                   ("igemm_halo_kernel 128x64 tiles", "igemm_halo_kernel<1>"),
+                   ("igemm_halo_kernel 128x128 tiles (halo-tiled stride-1 multi-tap layers)", "igemm_halo_kernel<2, 2>"),
+                   ("igemm_halo_kernel 256x64 tiles (Cout = 64 layers)", "igemm_halo_kernel<4, 2>"),
                    ("heads_halo_kernel (merged output heads)", "heads_halo_kernel")]
 
 

@@ -140,7 +140,8 @@ struct Slot {
     size_t host_cap = 0;
     PinnedBuf h_mask, h_pred, h_stat;   // pinned landing buffers of the optional outputs (sorted order)
     std::vector<int> perm;
-    std::vector<int> img_hw;            // H*W of each detection's frame (sorted order)
+    std::vector<int> img_hw, img_w;     // H*W and W of each detection's frame (sorted order)
+    long long cmask_stride = 0, cpred_stride = 0;   // bytes per detection of the compact mask / image landing buffers
     p2p_est_pose_opts opt;              // the caller's output pointers (host), filled at collect time
     int n = 0;
     int ticket = -1;                    // in-flight async batch, -1 = free

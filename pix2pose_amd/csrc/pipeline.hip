@@ -603,7 +603,9 @@ __global__ void select_kernel(const DetInfo* __restrict__ dets, const Stage1* __
 }
 
 // ------------------------------------------------------------------------------------------
-// K9 (optional outputs): valid_mask_full and img_pred_f of the selected candidate (:175-177)
+// K9 (optional outputs): valid_mask_full and img_pred_f of the selected candidate (:175-177).  Both leave the device
+// COMPACT (row-major over the candidate's clipped box, which is all that is non-zero of the full-frame mask): 16 KB per
+// 128-px detection over PCIe instead of a 300 KB frame; finish_batch() pastes the mask into the caller's full frames.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
                                                           const p2p_pose* __restrict__ poses, const float* __restrict__ y2,
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restr
     for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
         const int rr = p / w, cc = p - rr * w;
         const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
-        if (mask) mask[(size_t)d * mask_stride + (size_t)(b.v1 + rr) * D.W + (b.u1 + cc)] = cp.valid ? 1 : 0;
+        if (mask && p < mask_stride) mask[(size_t)d * mask_stride + p] = cp.valid ? 1 : 0;      // compact: row-major over the clipped box
         if (pred && (long long)(p + 1) * 3 <= pred_stride) {
             unsigned char* q = pred + (size_t)d * pred_stride + (size_t)p * 3;
             q[0] = cp.q[0]; q[1] = cp.q[1]; q[2] = cp.q[2];
@@ -855,10 +857,21 @@ static void finish_batch(const Slot& s, p2p_pose* poses)
     for (int i = 0; i < s.n; ++i) {
         const int o = s.perm[i];
         poses[o] = s.host_poses[i];
-        if (opt.valid_mask) {       // bytes past H*W of the detection's frame are zeroed like the rest of the mask
-            memcpy(opt.valid_mask + (size_t)o * opt.mask_stride, s.h_mask.as<unsigned char>() + (size_t)i * opt.mask_stride, (size_t)opt.mask_stride);
+        if (opt.valid_mask) {       // valid_mask_full = zeros((H, W)); [v1:v2, u1:u2] = valid_mask   (recognition.py:175-176)
+            unsigned char* dst = opt.valid_mask + (size_t)o * opt.mask_stride;
+            memset(dst, 0, (size_t)opt.mask_stride);
+            const p2p_pose& P = s.host_poses[i];
+            if (P.status == P2P_POSE_OK) {
+                const int v1 = P.bbox_t[0], v2 = P.bbox_t[1], u1 = P.bbox_t[2], u2 = P.bbox_t[3], w = u2 - u1, W = s.img_w[i];
+                const unsigned char* src = s.h_mask.as<unsigned char>() + (size_t)i * s.cmask_stride;
+                for (int r = 0; r < v2 - v1 && (long long)(r + 1) * w <= s.cmask_stride; ++r) memcpy(dst + (size_t)(v1 + r) * W + u1, src + (size_t)r * w, (size_t)w);
+            }
         }
-        if (opt.img_pred) memcpy(opt.img_pred + (size_t)o * opt.pred_stride, s.h_pred.as<unsigned char>() + (size_t)i * opt.pred_stride, (size_t)opt.pred_stride);
+        if (opt.img_pred) {
+            unsigned char* dst = opt.img_pred + (size_t)o * opt.pred_stride;
+            memcpy(dst, s.h_pred.as<unsigned char>() + (size_t)i * s.cpred_stride, (size_t)s.cpred_stride);
+            if (opt.pred_stride > s.cpred_stride) memset(dst + s.cpred_stride, 0, (size_t)(opt.pred_stride - s.cpred_stride));
+        }
         if (opt.det_mask && opt.mask_stats) {
             const long long inter = (long long)hstat[3 * i], dc = (long long)hstat[3 * i + 1], vc = (long long)hstat[3 * i + 2];
             opt.mask_stats[3 * o] = inter; opt.mask_stats[3 * o + 1] = dc + vc - inter; opt.mask_stats[3 * o + 2] = vc;
@@ -1118,8 +1131,10 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         if (want_mask && hw > opt.mask_stride) { set_error("mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
         if (want_iou && hw > opt.det_mask_stride) { set_error("det_mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
     }
-    if (want_mask && ((rc = SL.mask.reserve((size_t)opt.mask_stride * n)) || (rc = SL.h_mask.reserve((size_t)opt.mask_stride * n)))) return rc;
-    if (want_pred && ((rc = SL.pred.reserve((size_t)opt.pred_stride * n)) || (rc = SL.h_pred.reserve((size_t)opt.pred_stride * n)))) return rc;
+    // compact strides: a candidate's clipped box never exceeds the largest stage-1 square of the batch
+    const long long cms = std::max(1LL, (long long)max_side * max_side), cps = std::max(1LL, std::min<long long>(opt.pred_stride, cms * 3));
+    if (want_mask && ((rc = SL.mask.reserve((size_t)cms * n)) || (rc = SL.h_mask.reserve((size_t)cms * n)))) return rc;
+    if (want_pred && ((rc = SL.pred.reserve((size_t)cps * n)) || (rc = SL.h_pred.reserve((size_t)cps * n)))) return rc;
     if (want_iou) {
         if ((rc = SL.dmask.reserve((size_t)opt.det_mask_stride * n)) || (rc = SL.mstat.reserve(sizeof(unsigned long long) * 3 * n)) ||
             (rc = SL.h_stat.reserve(sizeof(unsigned long long) * 3 * n))) return rc;
@@ -1171,14 +1186,14 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     // -- optional outputs of the reference's return tuple (recognition.py:189-193: img_pred_f, valid_mask_full) and the
     //    score_type-2 mask sums: rendered on the tail stream, landed in the slot's pinned buffers, handed over by finish_batch()
     if (want_mask || want_pred) {
-        if (want_mask) HIP_TRY(hipMemsetAsync(SL.mask.p, 0, (size_t)opt.mask_stride * n, ts));
-        if (want_pred) HIP_TRY(hipMemsetAsync(SL.pred.p, 0, (size_t)opt.pred_stride * n, ts));
+        if (want_mask) HIP_TRY(hipMemsetAsync(SL.mask.p, 0, (size_t)cms * n, ts));
+        if (want_pred) HIP_TRY(hipMemsetAsync(SL.pred.p, 0, (size_t)cps * n, ts));
         hipLaunchKernelGGL(render_best_kernel, dim3(64, n), dim3(256), 0, ts, d_det, d_s1, SL.poses.as<p2p_pose>(), y2, K,
-                           want_mask ? SL.mask.as<unsigned char>() : nullptr, (long long)opt.mask_stride,
-                           want_pred ? SL.pred.as<unsigned char>() : nullptr, (long long)opt.pred_stride, d_cr, aa);
+                           want_mask ? SL.mask.as<unsigned char>() : nullptr, cms,
+                           want_pred ? SL.pred.as<unsigned char>() : nullptr, cps, d_cr, aa);
         HIP_TRY(hipGetLastError());
-        if (want_mask) HIP_TRY(hipMemcpyAsync(SL.h_mask.p, SL.mask.p, (size_t)opt.mask_stride * n, hipMemcpyDeviceToHost, ts));
-        if (want_pred) HIP_TRY(hipMemcpyAsync(SL.h_pred.p, SL.pred.p, (size_t)opt.pred_stride * n, hipMemcpyDeviceToHost, ts));
+        if (want_mask) HIP_TRY(hipMemcpyAsync(SL.h_mask.p, SL.mask.p, (size_t)cms * n, hipMemcpyDeviceToHost, ts));
+        if (want_pred) HIP_TRY(hipMemcpyAsync(SL.h_pred.p, SL.pred.p, (size_t)cps * n, hipMemcpyDeviceToHost, ts));
     }
     if (want_iou) {
         HIP_TRY(hipMemsetAsync(SL.mstat.p, 0, sizeof(unsigned long long) * 3 * n, ts));
@@ -1191,7 +1206,10 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     SL.n = n;
     SL.opt = opt;
     SL.img_hw.resize(n);
-    for (int i = 0; i < n; ++i) SL.img_hw[i] = hd[i].H * hd[i].W;
+    SL.img_w.resize(n);
+    for (int i = 0; i < n; ++i) { SL.img_hw[i] = hd[i].H * hd[i].W; SL.img_w[i] = hd[i].W; }
+    SL.cmask_stride = cms;
+    SL.cpred_stride = cps;
     if (async) {
         HIP_TRY(hipEventRecord(SL.done, ts));
         // the slot's buffers are rewritten by the batch after next on the context stream

@@ -202,10 +202,16 @@ def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_m
             im = images[detections[i][0]]
             return (im[1], im[2]) if isinstance(im, tuple) else np.asarray(im).shape[:2]
         mstride = max(hw(i)[0] * hw(i)[1] for i in range(n))
+
+        def side(i):      # stage-1 square of the detection (get_boxes, recognition.py:28-43): the stage-2 crop never exceeds it
+            _, oi, b, _ = detections[i]
+            bs = objects[oi].box_size if 0 <= oi < len(objects) else 1.5
+            return 2 * int(min(9999, max((b[3] - b[1]) * bs, (b[2] - b[0]) * bs)) / 2)
+        pstride = 3 * min(mstride, max(max(side(i), 1) ** 2 for i in range(n)))
         extras["valid_mask"] = np.zeros((n, mstride), np.uint8)
-        extras["img_pred"] = np.zeros((n, mstride * 3), np.uint8)
+        extras["img_pred"] = np.zeros((n, pstride), np.uint8)
         opts.valid_mask, opts.mask_stride = extras["valid_mask"].ctypes.data, mstride
-        opts.img_pred, opts.pred_stride = extras["img_pred"].ctypes.data, mstride * 3
+        opts.img_pred, opts.pred_stride = extras["img_pred"].ctypes.data, pstride
     if det_masks is not None and n:
         # score_type 2: IoU of each detector mask with valid_mask_full, computed on the device
         dms = max(int(np.asarray(m).size) for m in det_masks)

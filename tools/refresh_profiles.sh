@@ -1,31 +1,43 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ (run from the repo root in the build container).
 #   1. on the GPU box: full GPU test suite, rocprofv3 kernel trace of `bench.py --blocking` (one batch on the GPU at a time,
-#      so kernel durations are the kernels' own; the default stream mode overlaps two batches), two PMC passes
-#      (FETCH_SIZE / WRITE_SIZE separately, MI355X_MICROARCH.md), and a plain bench run
+#      so kernel durations are the kernels' own; the default stream mode overlaps two batches), PMC passes -- HBM traffic
+#      (FETCH_SIZE / WRITE_SIZE separately, MI355X_MICROARCH.md) and SQ counters in three passes (never together with a
+#      --sys-trace / HIP trace domain) -- and the bench lines (default, 30 objects, strict fp32, 2 ranks on one device)
 #   2. here: summarise the rocpd databases into profiles/
 set -e
-R=${1:-r01}
+R=${1:-r02}
+PROF="--steps 3 --warmup 1 --blocking --no-legs"
+PMC="--steps 1 --warmup 1 --blocking --no-legs"
 /usr/local/graft/bin/gpurun --timeout 2400 -- '
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/gpu_tests.log
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/gpu_tests.log
 cd /tmp && export TMPDIR=/tmp
 G=$GRAFT_REPO_ROOT/gpurun_out
-rm -rf $G/prof_final $G/pmc_fetch2 $G/pmc_write2
-rocprofv3 --kernel-trace --stats -d $G/prof_final -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --blocking > $G/bench_final_prof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $G/pmc_fetch2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 --blocking > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $G/pmc_write2 -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-sample 0 --blocking > /dev/null 2>&1
+B=$GRAFT_REPO_ROOT/bench.py
+rm -rf $G/prof_final $G/pmc_fetch2 $G/pmc_write2 $G/pmc_sq1 $G/pmc_sq2 $G/pmc_sq3
+rocprofv3 --kernel-trace --stats -d $G/prof_final -o bench -- python $B '"$PROF"' > $G/bench_final_prof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $G/pmc_fetch2 -o x -- python $B '"$PMC"' > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $G/pmc_write2 -o x -- python $B '"$PMC"' > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $G/pmc_sq1 -o x -- python $B '"$PMC"' > $G/pmc_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d $G/pmc_sq2 -o x -- python $B '"$PMC"' > $G/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS -d $G/pmc_sq3 -o x -- python $B '"$PMC"' > $G/pmc_sq3.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/'"$R"'_traffic.json > /dev/null   # bench.py reads it
 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-python bench.py --steps 5 --warmup 2 --objects 30 --cpu-sample 0 > gpurun_out/bench_objects30.json 2>> gpurun_out/bench_final.err
-python bench.py --steps 5 --warmup 2 --precision f32 --cpu-sample 0 > gpurun_out/bench_f32.json 2>> gpurun_out/bench_final.err
-cat gpurun_out/gpu_tests.log; tail -c 400 gpurun_out/bench_final.json
+python bench.py --steps 5 --warmup 2 --objects 30 --no-legs > gpurun_out/bench_objects30.json 2>> gpurun_out/bench_final.err
+python bench.py --steps 5 --warmup 2 --precision f32 --no-legs > gpurun_out/bench_f32.json 2>> gpurun_out/bench_final.err
+python bench.py --steps 5 --warmup 2 --masks --no-legs > gpurun_out/bench_masks.json 2>> gpurun_out/bench_final.err
+python bench.py --gpus 2 --backend gloo --same-device --steps 3 --warmup 1 --no-legs > gpurun_out/bench_2ranks_same_device.json 2>> gpurun_out/bench_final.err
+cat gpurun_out/gpu_tests.log; tail -c 300 gpurun_out/bench_final.json
 ' 2>&1 | tail -8
 python tools/rocprof_summary.py gpurun_out/prof_final/bench_results.db > profiles/${R}_bench_kernel_stats.txt
 python tools/layer_times.py gpurun_out/prof_final/bench_results.db > profiles/${R}_layer_times.txt
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/${R}_traffic.json | head -4
-cp gpurun_out/bench_final.json profiles/${R}_bench_line.json
-cp gpurun_out/bench_objects30.json profiles/${R}_bench_line_objects30.json
-cp gpurun_out/bench_f32.json profiles/${R}_bench_line_f32mode.json
+python tools/pmc_sq.py gpurun_out/pmc_sq1/x_results.db gpurun_out/pmc_sq2/x_results.db gpurun_out/pmc_sq3/x_results.db > profiles/${R}_sq_counters.txt
+for f in bench_final:bench_line bench_objects30:bench_line_objects30 bench_f32:bench_line_f32mode bench_masks:bench_line_masks bench_2ranks_same_device:bench_line_2ranks_same_device; do
+    grep '^{' gpurun_out/${f%%:*}.json | tail -1 > profiles/${R}_${f##*:}.json
+done
 cp gpurun_out/gpu_tests.log profiles/${R}_gpu_tests.log
+[ -f gpurun_out/pnp_exact_match.json ] && cp gpurun_out/pnp_exact_match.json profiles/${R}_pnp_exact_match.json
+[ -f gpurun_out/precision_report.json ] && cp gpurun_out/precision_report.json profiles/${R}_precision_report.json
 head -14 profiles/${R}_bench_kernel_stats.txt | cut -c1-175
