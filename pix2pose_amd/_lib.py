@@ -59,14 +59,15 @@ class EstPoseOpts(C.Structure):
                 ("resize_anti_aliasing", C.c_int)]
 
 
-PROFILE_SLOTS = 6      # P2P_PROFILE_SLOTS
+PROFILE_SLOTS = 7      # P2P_PROFILE_SLOTS
 # kernel family of each slot: (label, substring of the rocprofv3 kernel name; %d = precision template argument)
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
                    ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
                    ("igemm_kernel 128x32 tiles", "igemm_kernel<4, 1, 1, 1, %d>"),
                    ("igemm_halo_kernel 128x128 tiles (halo-tiled stride-1 multi-tap layers)", "igemm_halo_kernel<2, 2>"),
                    ("igemm_halo_kernel 256x64 tiles (Cout = 64 layers)", "igemm_halo_kernel<4, 2>"),
-                   ("heads_halo_kernel (merged output heads)", "heads_halo_kernel")]
+                   ("heads_halo_kernel (merged output heads)", "heads_halo_kernel"),
+                   ("igemm_halo8_kernel 128x128 tiles (8x8-grid layers: conv4 through parity planes, first transposed conv)", "igemm_halo8_kernel")]
 
 
 class KernelStats(C.Structure):

@@ -81,6 +81,11 @@ int igemm_tile_m(int cfg);   // BM of a tile configuration
 bool igemm_halo_supported(const IgemmParams& p);
 hipError_t launch_igemm_halo(const IgemmParams& p, hipStream_t s);
 
+// Halo-tiled variant for the layers on an 8x8 output grid (igemm_halo8.hip): the stride-2 5x5 convolution conv4 (through parity
+// planes) and the phases of the first transposed convolution.  igemm_halo8_mode(): 0 = not for this kernel.
+int igemm_halo8_mode(const IgemmParams& p);
+hipError_t launch_igemm_halo8(const IgemmParams& p, hipStream_t s);
+
 // Halo-tiled kernel for the merged output heads (heads.hip); takes the same parameter block as the
 // generic kernel when heads_halo_supported() says so (PREC_F16X3, 64-wide grid, 128 input channels).
 bool heads_halo_supported(const IgemmParams& p);
