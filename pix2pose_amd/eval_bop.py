@@ -212,15 +212,20 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
     # detection stream: chunk i+1 is read from disk and enqueued (p2p_est_pose_submit) while chunk i is on the GPU;
     # the score_type-2 mask sums come back through the same asynchronous call
     in_flight = []
+    n_submitted = 0
     for b0 in range(0, len(tlist), batch_images):
         chunk = tlist[b0:b0 + batch_images]
         t1 = time.time()
         frames, dets, det_masks, owners = prepare(chunk)
         if not dets:
             continue
+        # est_pose_kwargs: extra arguments of the batch call (tests inject decoder maps); a callable gets (index of the chunk's
+        # first detection in stream order, number of detections) and returns them per chunk
+        extra = est_pose_kwargs(n_submitted, len(dets)) if callable(est_pose_kwargs) else (est_pose_kwargs or {})
+        n_submitted += len(dets)
         pending = runtime.est_pose_submit(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
                                           anti_aliasing=bool(cfg.get("resize_anti_aliasing", False)),     # scikit-image >= 0.15 semantics
-                                          **(est_pose_kwargs or {}))
+                                          **extra)
         in_flight.append((chunk, owners, pending, t1))
         if len(in_flight) == 2:
             finish(in_flight.pop(0))

@@ -118,3 +118,91 @@ def test_harness_end_to_end_matches_per_detection_shim(tmp_path):
             assert abs(a["score"] - b["score"]) < 1e-12
             np.testing.assert_array_equal(a["R"], b["R"])
             np.testing.assert_array_equal(a["t"], b["t"])
+
+
+@pytest.mark.gpu
+def test_harness_stream_many_images_objects_and_cli(tmp_path):
+    """BASELINE.json configs[4]'s shape on synthetic data: a BOP test_targets stream -- 24 frames, 5 objects (per-object
+    weights and obj_param), 72 detections with detector masks and scores -- goes through the harness in 6 pipelined chunks
+    (p2p_est_pose_submit / collect across chunk boundaries, score_type 2 mask sums from the device) and out as the bop19 CSV,
+    via the command-line entry point a user would run.  Every row equals what per-image BLOCKING calls give."""
+    import subprocess
+    import sys
+    from pix2pose_amd import runtime, synthetic as S, weights as W
+    rs = np.random.RandomState(5)
+    n_img, per_img, n_obj = 24, 3, 5
+    sc = S.make_scene(n_img * per_img, seed=77, n_images=n_img, bbox_side=(60, 150))
+    H, Wd = sc["images"].shape[1:3]
+    model_ids = [3, 5, 8, 13, 21]
+    images, targets = [], []
+    for fi in range(n_img):
+        np.save(tmp_path / ("f%02d.npy" % fi), sc["images"][fi])
+        ids = list(range(fi * per_img, (fi + 1) * per_img))
+        obj = [model_ids[(fi + k) % n_obj] for k in range(per_img)]
+        masks = np.zeros((H, Wd, per_img), bool)
+        for k, i in enumerate(ids):
+            b = sc["dets"][i][2]
+            masks[max(b[0], 0) + 4:b[2] - 3, max(b[1], 0) + 5:b[3] - 6, k] = True
+        np.save(tmp_path / ("m%02d.npy" % fi), masks)
+        images.append({"scene_id": 2, "im_id": fi, "rgb": "f%02d.npy" % fi, "cam_K": S.LM_K.reshape(-1).tolist(),
+                       "rois": [[int(v) for v in sc["dets"][i][2]] for i in ids], "obj_ids": obj,
+                       "scores": [float(rs.uniform(0.5, 1)) for _ in ids], "masks": "m%02d.npy" % fi})
+        for o in sorted(set(obj)):
+            targets.append({"scene_id": 2, "im_id": fi, "obj_id": o, "inst_count": 1})
+    dump = {"im_size": [Wd, H], "model_ids": model_ids, "weights": {str(m): "synthetic:paper:%d" % m for m in model_ids},
+            "norm_factor": {str(m): dict(zip(["x_scale", "y_scale", "z_scale", "x_ct", "y_ct", "z_ct"], (S.OBJ_PARAM * (1 + 0.01 * m)).tolist())) for m in model_ids},
+            "targets": targets, "images": images}
+    cfg = {"backbone": "paper", "outlier_th": [0.2, 0.3, 0.35], "inlier_th": 0.2, "score_type": 2, "task_type": 2,
+           "cand_factor": 2, "path_to_output": str(tmp_path / "out"), "generator_chunk": 64, "dataset_dir": str(tmp_path)}
+    json.dump(dump, open(tmp_path / "detections.json", "w"))
+    json.dump(cfg, open(tmp_path / "cfg.json", "w"))
+    # the command-line entry point (random weights give no usable masks, so this checks the plumbing: it runs, streams its
+    # chunks and writes the bop19 file; the row-level checks below inject decoder maps)
+    r = subprocess.run([sys.executable, "-m", "pix2pose_amd.eval_bop", "0", str(tmp_path / "cfg.json"), "ycbv", str(tmp_path / "detections.json")],
+                       capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    csv = open(tmp_path / "out" / "pix2pose-iccv19_ycbv-test.csv").read().split("\n")
+    assert csv[0] == "scene_id,im_id,obj_id,score,R,t,time"
+    # stream order of the detections = target order x select_detections order; injected decoder maps follow it
+    import torch
+    order = []
+    for scene_id, im_id, obj_t, inst in E.group_targets(targets):
+        im = images[im_id]
+        order += [im_id * per_img + k for k in E.select_detections(im["rois"], im["obj_ids"], obj_t, inst, 2.0)]
+    j1 = torch.from_numpy(sc["inject1"][order]).cuda()
+    j2 = torch.from_numpy(sc["inject2"][order]).cuda()
+    torch.cuda.synchronize()
+    inject = lambda start, n: dict(inject1=j1[start:start + n].data_ptr(), inject2=j2[start:start + n].data_ptr(), inject_slots=3)
+    # the same stream in 6 pipelined chunks, in ONE chunk, and image by image through the blocking call
+    cfg_q = dict(cfg, path_to_output=str(tmp_path / "out6"))
+    rows6 = E.run(cfg_q, "ycbv", dump, base_dir=str(tmp_path), batch_images=4, est_pose_kwargs=inject)
+    rows1 = E.run(dict(cfg, path_to_output=None), "ycbv", dump, base_dir=str(tmp_path), batch_images=64, est_pose_kwargs=inject)
+    csv = open(tmp_path / "out6" / "pix2pose-iccv19_ycbv-test.csv").read().split("\n")
+    assert len(csv) - 1 == len(rows6) == len(rows1) and len(rows6) >= 40
+    ctx = runtime.Context(0, max_batch=64)
+    specs = [runtime.ObjectSpec(runtime.Generator(W.load_weights("synthetic:paper:%d" % m, "paper"), "paper", ctx),
+                                E.model_params_to_obj_param(dump["norm_factor"][str(m)]), cfg["outlier_th"], cfg["inlier_th"]) for m in model_ids]
+    exp, pos = [], 0
+    for scene_id, im_id, obj_t, inst in E.group_targets(targets):
+        im = images[im_id]
+        masks = np.load(tmp_path / im["masks"])
+        sel = E.select_detections(im["rois"], im["obj_ids"], obj_t, inst, 2.0)
+        dets = [(0, model_ids.index(im["obj_ids"][k]), im["rois"][k], S.LM_K) for k in sel]
+        poses, ex = runtime.est_pose_batch(ctx, specs, [sc["images"][im_id]], dets, det_masks=[masks[:, :, k] for k in sel], **inject(pos, len(sel)))
+        pos += len(sel)
+        res = [{"obj_id": im["obj_ids"][k], "score": E.detection_score(im["scores"][k], p.frac_inlier, (int(ex["mask_stats"][j, 0]), int(ex["mask_stats"][j, 1])), 2, "rcnn"),
+                "R": np.array(p.R).reshape(3, 3), "t": np.array(p.t)} for j, (k, p) in enumerate(zip(sel, poses)) if p.status == 0]
+        exp += E.rank_image_results(res, obj_t, inst, 2, scene_id, im_id, 0.0)
+    for rows in (rows6, rows1):
+        assert len(rows) == len(exp)
+        for a, b in zip(rows, exp):
+            assert (a["scene_id"], a["im_id"], a["obj_id"]) == (b["scene_id"], b["im_id"], b["obj_id"])
+            assert abs(a["score"] - b["score"]) < 1e-12
+            np.testing.assert_array_equal(a["R"], b["R"])
+            np.testing.assert_array_equal(a["t"], b["t"])
+    # the CSV holds the same rows (text round trip of the floats)
+    for line, b in zip(csv[1:], exp):
+        f = line.split(",")
+        assert [int(f[0]), int(f[1]), int(f[2])] == [b["scene_id"], b["im_id"], b["obj_id"]]
+        assert np.allclose([float(v) for v in f[4].split()], np.asarray(b["R"]).flatten(), rtol=0, atol=1e-12)
+        assert np.allclose([float(v) for v in f[5].split()], np.asarray(b["t"]).flatten(), rtol=0, atol=1e-9)
