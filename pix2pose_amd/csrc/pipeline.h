@@ -127,6 +127,20 @@ struct PinnedBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// anti-aliased resizes (resize_aa.hip): descriptor arrays per image kind, all null when the option is off
+struct AaPtrs {
+    AaItem* k0;   // [n]        stage-1 canvases           (side > 128)
+    AaItem* k1;   // [n*K]      stage-2 canvases           (side > 128)
+    AaItem* k2;   // [n*K]      keep masks, 128x128        (stage-1 side < 128)
+    AaItem* k3;   // [n*K*5]    prob, pred r/g/b, non_gray (stage-2 side < 128)
+};
+struct AaBufs {
+    double *cv, *cv_tmp;      // canvases: per detection (1 + K) x corr_cap x 3 doubles at DetInfo::cv_off
+    double *kp, *kp_tmp;      // keep masks: [n*K][128*128]
+    double *bk, *bk_tmp;      // back-resize planes: [n*K][5][128*128]
+};
+struct BatchGroup { int obj, begin, end; };   // detections [begin, end) of the sorted batch belong to object `obj`
+
 // Per-batch buffers: double buffered.  Asynchronous batches alternate between two generator lanes (stream +
 // activation workspace, Ctx::lane[0/1]) so that the passes of batch i+1 fill the launch tails of batch i, and
 // their PnP-RANSAC tails run on a third stream.
@@ -139,7 +153,18 @@ struct Slot {
     p2p_pose* host_poses = nullptr;     // pinned
     size_t host_cap = 0;
     PinnedBuf h_mask, h_pred, h_stat;   // pinned landing buffers of the optional outputs (sorted order)
+    // host-side description of the batch (kept from submit to collect: the stage-2 pass of an asynchronous batch is enqueued
+    // by the NEXT submit, merged with that batch's stage-1 pass, or by collect)
     std::vector<int> perm;
+    std::vector<DetInfo> hd;
+    std::vector<BatchGroup> groups;
+    std::vector<p2p_object> objs;
+    int K = 0;
+    bool identity = true, use_aa = false, same_backbone = true;
+    bool stage2_pending = false;        // stage-2 inputs are built, the stage-2 generator pass and the tail are not enqueued yet
+    int tail_cap = 0;                   // network inputs of a following batch that fit behind this batch's stage-2 inputs
+    int max_side = 0;
+    AaPtrs aa = {nullptr, nullptr, nullptr, nullptr};
     std::vector<int> img_hw, img_w;     // H*W and W of each detection's frame (sorted order)
     long long cmask_stride = 0, cpred_stride = 0;   // bytes per detection of the compact mask / image landing buffers
     p2p_est_pose_opts opt;              // the caller's output pointers (host), filled at collect time

@@ -173,14 +173,6 @@ __device__ inline double clip_warp(double v, double lo, double hi, double cval)
     return v < lo ? lo : (v > hi ? hi : v);
 }
 
-// anti-aliased resizes (resize_aa.hip): descriptor arrays per image kind, all null when the option is off
-struct AaPtrs {
-    AaItem* k0;   // [n]        stage-1 canvases           (side > 128)
-    AaItem* k1;   // [n*K]      stage-2 canvases           (side > 128)
-    AaItem* k2;   // [n*K]      keep masks, 128x128        (stage-1 side < 128)
-    AaItem* k3;   // [n*K*5]    prob, pred r/g/b, non_gray (stage-2 side < 128)
-};
-
 // (pixel - 128) / 128 of frame pixel (y, x), channel ch
 __device__ inline double frame_px(const DetInfo& D, int y, int x, int ch)
 {
@@ -684,12 +676,6 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict
 // ------------------------------------------------------------------------------------------
 // anti-aliased resizes (p2p_est_pose_opts.resize_anti_aliasing; filter itself: resize_aa.hip)
 // ------------------------------------------------------------------------------------------
-struct AaBufs {
-    double *cv, *cv_tmp;      // canvases: per detection (1 + K) x corr_cap x 3 doubles at DetInfo::cv_off
-    double *kp, *kp_tmp;      // keep masks: [n*K][128*128]
-    double *bk, *bk_tmp;      // back-resize planes: [n*K][5][128*128]
-};
-
 __device__ inline void aa_item_off(AaItem& I)
 {
     I.a = I.tmp = nullptr; I.w = nullptr;
@@ -845,9 +831,18 @@ __global__ void aa_back_range_kernel(CandRange* __restrict__ crange, int n_cand,
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
-// async_ticket == nullptr: blocking call, results in `poses`.  Otherwise the batch is only enqueued:
-// generator passes and glue on the context stream, PnP-RANSAC + selection + D2H on the tail stream,
-// and p2p_est_pose_collect() picks the poses up.
+// The work of a batch falls into four pieces, all enqueued without ever returning to the host in between:
+//   front   per-detection constants, frames, stage-1 network inputs                          (enqueue_front)
+//   pass 1  generator over the n stage-1 inputs
+//   mid     stage-1 reductions, stage-2 geometry, stage-2 network inputs                      (enqueue_mid)
+//   pass 2  generator over the n*K stage-2 inputs
+//   tail    correspondences, PnP-RANSAC, selection, optional outputs, D2H                     (enqueue_tail)
+// A blocking call runs them back to back.  Asynchronous batches (submit / collect) run as a STREAM: batch k's pass 2 is
+// not enqueued by its own submit but by the next one, MERGED with batch k+1's pass 1 into one generator pass over
+// [x2(k) | x1(k+1)] -- one 1024-input pass per step instead of a 256- and a 768-input pass (the small pass fills the chip
+// badly: 32.2 vs 30.1 us per input), and batch k's latency-bound tail runs on the tail stream under batch k+1's next
+// pass.  collect(k) enqueues pass 2 of k by itself if no later submit did.
+
 // Hand a finished batch over to the caller: sorted order -> caller order, pinned landing buffers -> the caller's
 // (pageable) output arrays named in the options of the submit / blocking call.
 static void finish_batch(const Slot& s, p2p_pose* poses)
@@ -879,47 +874,61 @@ static void finish_batch(const Slot& s, p2p_pose* poses)
     }
 }
 
-static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
-                        const p2p_detection* dets, int n, p2p_pose* poses, const p2p_est_pose_opts& opt, int* async_ticket)
+static int forward_parts(Ctx& X, hipStream_t st, const Slot* const* parts, const int* per_det, int n_parts, const float* xin, float* yout)
+{
+    // (model, count) runs of the concatenated, object-sorted parts
+    std::vector<const Model*> ms;
+    std::vector<int> cnt;
+    bool same_backbone = true;
+    for (int k = 0; k < n_parts; ++k)
+        for (const BatchGroup& g : parts[k]->groups) {
+            const Model* m = reinterpret_cast<const Model*>(parts[k]->objs[g.obj].model);
+            const int c = (g.end - g.begin) * per_det[k];
+            if (!ms.empty() && ms.back() == m) { cnt.back() += c; continue; }      // the same network on both sides of a part boundary: one run
+            ms.push_back(m);
+            cnt.push_back(c);
+            same_backbone = same_backbone && m->backbone == ms[0]->backbone;
+        }
+    X.cur = &X.lane[0];
+    if (ms.size() == 1) return forward_async(X, *ms[0], xin, cnt[0], yout);
+    if (same_backbone) return forward_grouped(X, ms, cnt, xin, yout);      // one grouped pass: every M-tile uses its object's weights
+    // mixed backbones: per-object passes round-robin over the context's lanes (stream + private activation workspace) so that
+    // the small per-object launch sequences overlap; fork/join with events around them
+    const int nl = std::min<int>((int)ms.size(), Ctx::N_LANES);
+    for (int l = 1; l < nl; ++l) { int r = X.ensure_lane(l); if (r) return r; }
+    HIP_TRY(hipEventRecord(X.fork, st));
+    for (int l = 1; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(X.lane[l].stream, X.fork, 0));
+    int r = P2P_OK;
+    size_t off = 0;
+    for (size_t gi = 0; gi < ms.size() && !r; ++gi) {
+        X.cur = &X.lane[gi % nl];
+        r = forward_async(X, *ms[gi], xin + off * 16384 * 3, cnt[gi], yout + off * 16384 * 4);
+        off += cnt[gi];
+    }
+    X.cur = &X.lane[0];
+    if (r) return r;
+    for (int l = 1; l < nl; ++l) {
+        HIP_TRY(hipEventRecord(X.lane[l].done, X.lane[l].stream));
+        HIP_TRY(hipStreamWaitEvent(st, X.lane[l].done, 0));
+    }
+    return P2P_OK;
+}
+
+static int inject_maps(const Slot& SL, hipStream_t st, const float* src, float* dst, size_t per_det)
+{
+    if (SL.identity) {
+        HIP_TRY(hipMemcpyAsync(dst, src, per_det * SL.n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else
+        for (int i = 0; i < SL.n; ++i)
+            HIP_TRY(hipMemcpyAsync(dst + per_det * i, src + per_det * SL.perm[i], per_det * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return P2P_OK;
+}
+
+// front: validation, frames, per-detection constants, buffers, stage-1 network inputs into x1_dst (null: the slot's own x1)
+static int enqueue_front(Ctx& X, Slot& SL, hipStream_t st, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
+                         const p2p_detection* dets, int n, const p2p_est_pose_opts& opt, float* x1_dst)
 {
     int rc;
-    if (!X.pipe) X.pipe = new Pipeline();
-    Pipeline& P = *X.pipe;
-    if ((rc = X.ensure_workspace())) return rc;
-    const bool async = async_ticket != nullptr;
-    // generator lane of this batch: asynchronous batches alternate between lanes 0 and 1
-    static const bool two_lanes = getenv("P2P_ONE_LANE") == nullptr;
-    bool one_backbone = true;            // (mixed-backbone batches spread over the lanes themselves)
-    for (int o = 1; o < n_obj; ++o)
-        one_backbone = one_backbone && objects[o].model && objects[0].model &&
-                       reinterpret_cast<const Model*>(objects[o].model)->backbone == reinterpret_cast<const Model*>(objects[0].model)->backbone;
-    const int bl = async && two_lanes && one_backbone ? (P.next_ticket % Pipeline::N_SLOTS) : 0;
-    if (bl && (rc = X.ensure_lane(bl))) return rc;
-    hipStream_t st = X.lane[bl].stream;
-    if (!P.tail_stream) {
-        HIP_TRY(hipStreamCreate(&P.tail_stream));
-        HIP_TRY(hipEventCreateWithFlags(&P.corr_ready, hipEventDisableTiming));
-        for (Slot& s : P.slot) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    }
-    Slot& SL = P.slot[async ? (P.next_ticket % Pipeline::N_SLOTS) : 0];
-    if (SL.ticket >= 0) {
-        if (async) { set_error("%d batches are already in flight: collect ticket %d first", Pipeline::N_SLOTS, SL.ticket); return P2P_ERR_CAPACITY; }
-        set_error("an asynchronous batch (ticket %d) is in flight: collect it before a blocking call", SL.ticket);
-        return P2P_ERR_CAPACITY;
-    }
-    if (async && (opt.dbg_x1 || opt.dbg_x2 || opt.dbg_boxes2 || opt.dbg_cand)) {
-        set_error("the debug taps are only available from the blocking call");
-        return P2P_ERR_INVALID_ARG;
-    }
-    if (opt.ransac_iterations > P2P_MAX_RANSAC_ITERATIONS) {
-        set_error("ransac_iterations %d exceeds P2P_MAX_RANSAC_ITERATIONS (%d)", opt.ransac_iterations, P2P_MAX_RANSAC_ITERATIONS);
-        return P2P_ERR_INVALID_ARG;
-    }
-    if ((opt.det_mask != nullptr) != (opt.mask_stats != nullptr)) {
-        set_error("det_mask and mask_stats go together");
-        return P2P_ERR_INVALID_ARG;
-    }
-
     // -- validate, order detections by object (weights locality; one generator pass per group)
     int K = 0;
     for (int o = 0; o < n_obj; ++o) {
@@ -929,7 +938,9 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         }
         K = std::max(K, objects[o].n_outlier_th);
     }
-    std::vector<int> perm(n);
+    if (opt.inject2 && opt.inject_slots != K) { set_error("inject_slots (%d) must equal the largest n_outlier_th (%d)", opt.inject_slots, K); return P2P_ERR_INVALID_ARG; }
+    std::vector<int>& perm = SL.perm;
+    perm.resize(n);
     std::iota(perm.begin(), perm.end(), 0);
     for (int i = 0; i < n; ++i) {
         if (dets[i].object < 0 || dets[i].object >= n_obj || dets[i].image < 0 || dets[i].image >= n_img) {
@@ -938,8 +949,13 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         }
     }
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return dets[a].object < dets[b].object; });
-    bool identity = true;
-    for (int i = 0; i < n; ++i) identity = identity && perm[i] == i;
+    SL.identity = true;
+    for (int i = 0; i < n; ++i) SL.identity = SL.identity && perm[i] == i;
+    SL.n = n;
+    SL.K = K;
+    SL.opt = opt;
+    SL.objs.assign(objects, objects + n_obj);
+    SL.use_aa = opt.resize_anti_aliasing != 0;
 
     // -- frames
     std::vector<const void*> img_dev(n_img, nullptr);
@@ -963,10 +979,11 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     }
 
     // -- per-detection constants + stage-1 geometry (recognition.py:71-79)
-    std::vector<DetInfo> hd(n);
+    std::vector<DetInfo>& hd = SL.hd;
+    hd.resize(n);
     long long corr_total = 0, cv_total = 0;
     int max_side = 0;
-    const bool use_aa = opt.resize_anti_aliasing != 0;
+    const bool use_aa = SL.use_aa;
     for (int i = 0; i < n; ++i) {
         const p2p_detection& dt = dets[perm[i]];
         const p2p_object& ob = objects[dt.object];
@@ -999,6 +1016,23 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         }
         if (D.ok1) max_side = std::max(max_side, (int)side);
     }
+    SL.max_side = max_side;
+    SL.img_hw.resize(n);
+    SL.img_w.resize(n);
+    for (int i = 0; i < n; ++i) { SL.img_hw[i] = hd[i].H * hd[i].W; SL.img_w[i] = hd[i].W; }
+    // object groups (contiguous in the sorted order)
+    SL.groups.clear();
+    SL.same_backbone = true;
+    for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && hd[j].obj == hd[i].obj) ++j;
+        SL.groups.push_back({hd[i].obj, i, j});
+        SL.same_backbone = SL.same_backbone && reinterpret_cast<const Model*>(objects[hd[i].obj].model)->backbone ==
+                                                    reinterpret_cast<const Model*>(objects[hd[0].obj].model)->backbone;
+        i = j;
+    }
+    // the stage-2 buffers leave room for the stage-1 inputs / outputs of a following batch of up to the same size (merged pass)
+    SL.tail_cap = n;
     if ((rc = SL.det.reserve(sizeof(DetInfo) * n))) return rc;
     if ((rc = SL.s1.reserve(sizeof(Stage1) * n))) return rc;
     if ((rc = SL.cand.reserve(sizeof(CandStat) * n * K))) return rc;
@@ -1008,123 +1042,23 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     if ((rc = SL.poses.reserve(sizeof(p2p_pose) * n))) return rc;
     if ((rc = SL.x1.reserve(sizeof(float) * 16384 * 3 * (size_t)n))) return rc;
     if ((rc = SL.y1.reserve(sizeof(float) * 16384 * 4 * (size_t)n))) return rc;
-    if ((rc = SL.x2.reserve(sizeof(float) * 16384 * 3 * (size_t)n * K))) return rc;
-    if ((rc = SL.y2.reserve(sizeof(float) * 16384 * 4 * (size_t)n * K))) return rc;
+    if ((rc = SL.x2.reserve(sizeof(float) * 16384 * 3 * ((size_t)n * K + SL.tail_cap)))) return rc;
+    if ((rc = SL.y2.reserve(sizeof(float) * 16384 * 4 * ((size_t)n * K + SL.tail_cap)))) return rc;
     if ((rc = SL.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
     if ((rc = SL.crange.reserve(sizeof(CandRange) * (size_t)n * K))) return rc;
-    AaPtrs aa = {nullptr, nullptr, nullptr, nullptr};
+    SL.aa = {nullptr, nullptr, nullptr, nullptr};
     AaBufs aab = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     AaTable aat;
-    const int aa_n_items = n + 7 * n * K;
     if (use_aa) {
         if ((rc = aa_table_get(X.device, &aat))) return rc;
         const size_t cvb = sizeof(double) * (size_t)std::max<long long>(cv_total, 1), plane = sizeof(double) * 16384 * (size_t)n * K;
-        if ((rc = SL.aa_items.reserve(sizeof(AaItem) * (size_t)aa_n_items)) || (rc = SL.aa_cv.reserve(cvb)) || (rc = SL.aa_cv_tmp.reserve(cvb)) ||
+        if ((rc = SL.aa_items.reserve(sizeof(AaItem) * (size_t)(n + 7 * n * K))) || (rc = SL.aa_cv.reserve(cvb)) || (rc = SL.aa_cv_tmp.reserve(cvb)) ||
             (rc = SL.aa_kp.reserve(plane)) || (rc = SL.aa_kp_tmp.reserve(plane)) || (rc = SL.aa_bk.reserve(plane * 5)) || (rc = SL.aa_bk_tmp.reserve(plane * 5))) return rc;
         AaItem* it = SL.aa_items.as<AaItem>();
-        aa = {it, it + n, it + n + n * K, it + n + 2 * n * K};
+        SL.aa = {it, it + n, it + n + n * K, it + n + 2 * n * K};
         aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_kp.as<double>(), SL.aa_kp_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
     }
-    const int canvas_elems = max_side * max_side * 3;
-    HIP_TRY(hipMemcpyAsync(SL.det.p, hd.data(), sizeof(DetInfo) * n, hipMemcpyHostToDevice, st));
-
-    const DetInfo* d_det = SL.det.as<DetInfo>();
-    Stage1* d_s1 = SL.s1.as<Stage1>();
-    float *x1 = SL.x1.as<float>(), *y1 = SL.y1.as<float>(), *x2 = SL.x2.as<float>(), *y2 = SL.y2.as<float>();
-
-    // object groups (contiguous in the sorted order)
-    struct Group { int obj, begin, end; };
-    std::vector<Group> groups;
-    for (int i = 0; i < n;) {
-        int j = i;
-        while (j < n && hd[j].obj == hd[i].obj) ++j;
-        groups.push_back({hd[i].obj, i, j});
-        i = j;
-    }
-    // Generator passes of the object groups.  One group: the context stream.  Several groups (mixed
-    // batch): round-robin over the context's lanes (stream + private activation workspace) so that the
-    // small per-object launch sequences overlap; fork/join with events around them.
-    auto forward_groups = [&](int per_det, const float* xin, float* yout) -> int {
-        bool same_backbone = true;
-        for (const Group& g : groups)
-            same_backbone = same_backbone && reinterpret_cast<const Model*>(objects[g.obj].model)->backbone ==
-                                                 reinterpret_cast<const Model*>(objects[groups[0].obj].model)->backbone;
-        if (groups.size() > 1 && same_backbone) {
-            // one grouped pass: each layer is a single launch, every M-tile uses its object's weights
-            std::vector<const Model*> ms;
-            std::vector<int> cnt;
-            for (const Group& g : groups) { ms.push_back(reinterpret_cast<const Model*>(objects[g.obj].model)); cnt.push_back((g.end - g.begin) * per_det); }
-            X.cur = &X.lane[bl];
-            const int r = forward_grouped(X, ms, cnt, xin, yout);
-            X.cur = &X.lane[0];
-            return r;
-        }
-        const int nl = groups.size() > 1 ? std::min<int>((int)groups.size(), Ctx::N_LANES) : 1;
-        if (nl > 1) {
-            for (int l = 1; l < nl; ++l) { int r = X.ensure_lane(l); if (r) return r; }
-            HIP_TRY(hipEventRecord(X.fork, st));
-            for (int l = 1; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(X.lane[l].stream, X.fork, 0));
-        }
-        int r = P2P_OK;
-        for (size_t gi = 0; gi < groups.size() && !r; ++gi) {
-            const Group& g = groups[gi];
-            const Model& M = *reinterpret_cast<const Model*>(objects[g.obj].model);
-            X.cur = &X.lane[nl > 1 ? gi % nl : bl];
-            r = forward_async(X, M, xin + (size_t)g.begin * per_det * 16384 * 3, (g.end - g.begin) * per_det,
-                              yout + (size_t)g.begin * per_det * 16384 * 4);
-        }
-        X.cur = &X.lane[0];
-        if (r) return r;
-        for (int l = 1; l < nl; ++l) {
-            HIP_TRY(hipEventRecord(X.lane[l].done, X.lane[l].stream));
-            HIP_TRY(hipStreamWaitEvent(st, X.lane[l].done, 0));
-        }
-        return P2P_OK;
-    };
-    auto inject = [&](const float* src, float* dst, size_t per_det) -> int {
-        if (identity) {
-            HIP_TRY(hipMemcpyAsync(dst, src, per_det * n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        } else
-            for (int i = 0; i < n; ++i)
-                HIP_TRY(hipMemcpyAsync(dst + per_det * i, src + per_det * perm[i], per_det * sizeof(float), hipMemcpyDeviceToDevice, st));
-        return P2P_OK;
-    };
-
-    // -- stage 1
-    if (use_aa) {      // anti-aliased stage-1 canvases (sides > 128): build, filter in place
-        hipLaunchKernelGGL(aa_plan_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_det, d_s1, n, K, 0, aat, aab, aa);
-        hipLaunchKernelGGL(aa_canvas1_kernel, dim3(64, n), dim3(256), 0, st, d_det, aa);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(launch_aa_filter(aa.k0, n, canvas_elems, st));
-    }
-    hipLaunchKernelGGL(stage1_input_kernel, dim3(n * 64), dim3(256), 0, st, d_det, x1, aa);
-    HIP_TRY(hipGetLastError());
-    if ((rc = forward_groups(1, x1, y1))) return rc;
-    if (opt.inject1 && (rc = inject(opt.inject1, y1, 16384 * 4))) return rc;
-    hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(256), 0, st, d_det, y1, d_s1);
-    HIP_TRY(hipGetLastError());
-
-    // -- stage 2
-    if (use_aa) {      // anti-aliased keep masks (stage-1 sides < 128) and stage-2 canvases (sides > 128)
-        hipLaunchKernelGGL(aa_plan_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_det, d_s1, n, K, 1, aat, aab, aa);
-        hipLaunchKernelGGL(aa_keep_fill_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, y1, K, aa);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(launch_aa_filter(aa.k2, n * K, 16384, st));
-        hipLaunchKernelGGL(aa_keep_range_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_s1, n, K, aa);
-        hipLaunchKernelGGL(aa_canvas2_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, d_s1, y1, K, aa);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(launch_aa_filter(aa.k1, n * K, canvas_elems, st));
-    }
-    hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, x2, aa);
-    HIP_TRY(hipGetLastError());
-    if ((rc = forward_groups(K, x2, y2))) return rc;
-    if (opt.inject2) {
-        if (opt.inject_slots != K) { set_error("inject_slots (%d) must equal the largest n_outlier_th (%d)", opt.inject_slots, K); return P2P_ERR_INVALID_ARG; }
-        if ((rc = inject(opt.inject2, y2, (size_t)K * 16384 * 4))) return rc;
-    }
-
-    // -- optional outputs: argument checks and the detector-mask upload come first (context stream), so that the
-    //    tail below only has kernels and D2H copies
+    // -- optional outputs: argument checks, landing buffers and the detector-mask upload (read during submit)
     const bool want_mask = opt.valid_mask != nullptr, want_pred = opt.img_pred != nullptr, want_iou = opt.det_mask != nullptr;
     for (int i = 0; i < n; ++i) {
         const long long hw = (long long)hd[i].H * hd[i].W;
@@ -1132,9 +1066,10 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         if (want_iou && hw > opt.det_mask_stride) { set_error("det_mask_stride too small for detection %d", perm[i]); return P2P_ERR_CAPACITY; }
     }
     // compact strides: a candidate's clipped box never exceeds the largest stage-1 square of the batch
-    const long long cms = std::max(1LL, (long long)max_side * max_side), cps = std::max(1LL, std::min<long long>(opt.pred_stride, cms * 3));
-    if (want_mask && ((rc = SL.mask.reserve((size_t)cms * n)) || (rc = SL.h_mask.reserve((size_t)cms * n)))) return rc;
-    if (want_pred && ((rc = SL.pred.reserve((size_t)cps * n)) || (rc = SL.h_pred.reserve((size_t)cps * n)))) return rc;
+    SL.cmask_stride = std::max(1LL, (long long)max_side * max_side);
+    SL.cpred_stride = std::max(1LL, std::min<long long>(opt.pred_stride, SL.cmask_stride * 3));
+    if (want_mask && ((rc = SL.mask.reserve((size_t)SL.cmask_stride * n)) || (rc = SL.h_mask.reserve((size_t)SL.cmask_stride * n)))) return rc;
+    if (want_pred && ((rc = SL.pred.reserve((size_t)SL.cpred_stride * n)) || (rc = SL.h_pred.reserve((size_t)SL.cpred_stride * n)))) return rc;
     if (want_iou) {
         if ((rc = SL.dmask.reserve((size_t)opt.det_mask_stride * n)) || (rc = SL.mstat.reserve(sizeof(unsigned long long) * 3 * n)) ||
             (rc = SL.h_stat.reserve(sizeof(unsigned long long) * 3 * n))) return rc;
@@ -1143,12 +1078,73 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
                                    opt.det_mask + (size_t)perm[i] * opt.det_mask_stride, (size_t)hd[i].H * hd[i].W,
                                    hipMemcpyHostToDevice, st));
     }
+    if (SL.host_cap < (size_t)n) {
+        if (SL.host_poses) (void)hipHostFree(SL.host_poses);
+        SL.host_poses = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&SL.host_poses, sizeof(p2p_pose) * (size_t)n * 2, hipHostMallocDefault));
+        SL.host_cap = (size_t)n * 2;
+    }
+    HIP_TRY(hipMemcpyAsync(SL.det.p, hd.data(), sizeof(DetInfo) * n, hipMemcpyHostToDevice, st));
+
+    // -- stage-1 network inputs
+    const DetInfo* d_det = SL.det.as<DetInfo>();
+    if (use_aa) {      // anti-aliased stage-1 canvases (sides > 128): build, filter in place
+        hipLaunchKernelGGL(aa_plan_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_det, SL.s1.as<Stage1>(), n, K, 0, aat, aab, SL.aa);
+        hipLaunchKernelGGL(aa_canvas1_kernel, dim3(64, n), dim3(256), 0, st, d_det, SL.aa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_aa_filter(SL.aa.k0, n, max_side * max_side * 3, st));
+    }
+    hipLaunchKernelGGL(stage1_input_kernel, dim3(n * 64), dim3(256), 0, st, d_det, x1_dst ? x1_dst : SL.x1.as<float>(), SL.aa);
+    HIP_TRY(hipGetLastError());
+    return P2P_OK;
+}
+
+// mid: stage-1 network output y1 -> reductions, stage-2 geometry, stage-2 network inputs (into the slot's x2)
+static int enqueue_mid(Ctx& X, Slot& SL, hipStream_t st, float* y1)
+{
+    int rc;
+    const int n = SL.n, K = SL.K;
+    const DetInfo* d_det = SL.det.as<DetInfo>();
+    Stage1* d_s1 = SL.s1.as<Stage1>();
+    if (SL.opt.inject1 && (rc = inject_maps(SL, st, SL.opt.inject1, y1, 16384 * 4))) return rc;
+    hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(256), 0, st, d_det, y1, d_s1);
+    HIP_TRY(hipGetLastError());
+    if (SL.use_aa) {      // anti-aliased keep masks (stage-1 sides < 128) and stage-2 canvases (sides > 128)
+        AaTable aat;
+        if ((rc = aa_table_get(X.device, &aat))) return rc;
+        AaBufs aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_kp.as<double>(), SL.aa_kp_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
+        hipLaunchKernelGGL(aa_plan_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_det, d_s1, n, K, 1, aat, aab, SL.aa);
+        hipLaunchKernelGGL(aa_keep_fill_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, y1, K, SL.aa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_aa_filter(SL.aa.k2, n * K, 16384, st));
+        hipLaunchKernelGGL(aa_keep_range_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_s1, n, K, SL.aa);
+        hipLaunchKernelGGL(aa_canvas2_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, d_s1, y1, K, SL.aa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_aa_filter(SL.aa.k1, n * K, SL.max_side * SL.max_side * 3, st));
+    }
+    hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, SL.x2.as<float>(), SL.aa);
+    HIP_TRY(hipGetLastError());
+    return P2P_OK;
+}
+
+// tail: stage-2 network output (the slot's y2) -> correspondences, PnP-RANSAC, selection, optional outputs, D2H.
+// async: PnP and everything after it go to the tail stream and the slot's `done` event is recorded there.
+static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
+{
+    int rc;
+    const int n = SL.n, K = SL.K;
+    const p2p_est_pose_opts& opt = SL.opt;
+    const DetInfo* d_det = SL.det.as<DetInfo>();
+    Stage1* d_s1 = SL.s1.as<Stage1>();
+    float* y2 = SL.y2.as<float>();
+    const AaPtrs aa = SL.aa;
+    if (opt.inject2 && (rc = inject_maps(SL, st, opt.inject2, y2, (size_t)K * 16384 * 4))) return rc;
 
     // -- ranges of the back-resize inputs (clip=True), anti-aliased maps where the stage-2 side is < 128
     CandRange* d_cr = SL.crange.as<CandRange>();
     hipLaunchKernelGGL(cand_range_kernel, dim3(n * K), dim3(256), 0, st, y2, d_cr);
     HIP_TRY(hipGetLastError());
-    if (use_aa) {
+    if (SL.use_aa) {
         hipLaunchKernelGGL(aa_back_fill_kernel, dim3(64, n * K), dim3(256), 0, st, y2, aa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(launch_aa_filter(aa.k3, 5 * n * K, 16384, st));
@@ -1164,7 +1160,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     const double rerr = opt.reprojection_error > 0 ? opt.reprojection_error : 5.0;
     const double conf = opt.confidence > 0 ? opt.confidence : 0.99;
     hipStream_t ts = st;
-    if (async) {      // the latency-bound PnP tail runs beside the next batch's generator passes
+    if (async) {      // the latency-bound PnP tail runs beside the next generator pass
         ts = P.tail_stream;
         HIP_TRY(hipEventRecord(P.corr_ready, st));
         HIP_TRY(hipStreamWaitEvent(ts, P.corr_ready, 0));
@@ -1173,18 +1169,12 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     hipLaunchKernelGGL(select_kernel, dim3((n + 63) / 64), dim3(64), 0, ts, d_det, d_s1, SL.cand.as<CandStat>(),
                        SL.results.as<PnpResult>(), K, n, SL.poses.as<p2p_pose>());
     HIP_TRY(hipGetLastError());
-
-    if (SL.host_cap < (size_t)n) {
-        if (SL.host_poses) (void)hipHostFree(SL.host_poses);
-        SL.host_poses = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&SL.host_poses, sizeof(p2p_pose) * (size_t)n * 2, hipHostMallocDefault));
-        SL.host_cap = (size_t)n * 2;
-    }
-    p2p_pose* hp = SL.host_poses;
-    HIP_TRY(hipMemcpyAsync(hp, SL.poses.p, sizeof(p2p_pose) * n, hipMemcpyDeviceToHost, ts));
+    HIP_TRY(hipMemcpyAsync(SL.host_poses, SL.poses.p, sizeof(p2p_pose) * n, hipMemcpyDeviceToHost, ts));
 
     // -- optional outputs of the reference's return tuple (recognition.py:189-193: img_pred_f, valid_mask_full) and the
     //    score_type-2 mask sums: rendered on the tail stream, landed in the slot's pinned buffers, handed over by finish_batch()
+    const bool want_mask = opt.valid_mask != nullptr, want_pred = opt.img_pred != nullptr, want_iou = opt.det_mask != nullptr;
+    const long long cms = SL.cmask_stride, cps = SL.cpred_stride;
     if (want_mask || want_pred) {
         if (want_mask) HIP_TRY(hipMemsetAsync(SL.mask.p, 0, (size_t)cms * n, ts));
         if (want_pred) HIP_TRY(hipMemsetAsync(SL.pred.p, 0, (size_t)cps * n, ts));
@@ -1202,39 +1192,123 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(SL.h_stat.p, SL.mstat.p, sizeof(unsigned long long) * 3 * n, hipMemcpyDeviceToHost, ts));
     }
-    SL.perm = perm;
-    SL.n = n;
-    SL.opt = opt;
-    SL.img_hw.resize(n);
-    SL.img_w.resize(n);
-    for (int i = 0; i < n; ++i) { SL.img_hw[i] = hd[i].H * hd[i].W; SL.img_w[i] = hd[i].W; }
-    SL.cmask_stride = cms;
-    SL.cpred_stride = cps;
+    if (async) HIP_TRY(hipEventRecord(SL.done, ts));
+    SL.stage2_pending = false;
+    return P2P_OK;
+}
+
+// pass 2 + tail of a batch whose stage-2 inputs are waiting (no later batch to merge with)
+static int flush_stage2(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, bool async)
+{
+    int rc;
+    const Slot* parts[1] = {&SL};
+    const int per[1] = {SL.K};
+    if ((rc = forward_parts(X, st, parts, per, 1, SL.x2.as<float>(), SL.y2.as<float>()))) return rc;
+    return enqueue_tail(P, SL, st, async);
+}
+
+// async_ticket == nullptr: blocking call, results in `poses`.  Otherwise the batch is only enqueued and
+// p2p_est_pose_collect() picks the results up.
+static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
+                        const p2p_detection* dets, int n, p2p_pose* poses, const p2p_est_pose_opts& opt, int* async_ticket)
+{
+    int rc;
+    if (!X.pipe) X.pipe = new Pipeline();
+    Pipeline& P = *X.pipe;
+    if ((rc = X.ensure_workspace())) return rc;
+    const bool async = async_ticket != nullptr;
+    hipStream_t st = X.lane[0].stream;           // the chain pass 1 -> mid -> pass 2 of consecutive batches is serial: one stream
+    if (!P.tail_stream) {
+        HIP_TRY(hipStreamCreate(&P.tail_stream));
+        HIP_TRY(hipEventCreateWithFlags(&P.corr_ready, hipEventDisableTiming));
+        for (Slot& s : P.slot) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    const int slot_idx = async ? (P.next_ticket % Pipeline::N_SLOTS) : 0;
+    Slot& SL = P.slot[slot_idx];
+    if (SL.ticket >= 0) {
+        if (async) { set_error("%d batches are already in flight: collect ticket %d first", Pipeline::N_SLOTS, SL.ticket); return P2P_ERR_CAPACITY; }
+        set_error("an asynchronous batch (ticket %d) is in flight: collect it before a blocking call", SL.ticket);
+        return P2P_ERR_CAPACITY;
+    }
+    if (async && (opt.dbg_x1 || opt.dbg_x2 || opt.dbg_boxes2 || opt.dbg_cand)) {
+        set_error("the debug taps are only available from the blocking call");
+        return P2P_ERR_INVALID_ARG;
+    }
+    if (opt.ransac_iterations > P2P_MAX_RANSAC_ITERATIONS) {
+        set_error("ransac_iterations %d exceeds P2P_MAX_RANSAC_ITERATIONS (%d)", opt.ransac_iterations, P2P_MAX_RANSAC_ITERATIONS);
+        return P2P_ERR_INVALID_ARG;
+    }
+    if ((opt.det_mask != nullptr) != (opt.mask_stats != nullptr)) {
+        set_error("det_mask and mask_stats go together");
+        return P2P_ERR_INVALID_ARG;
+    }
+
+    // the batch whose stage-2 inputs wait for a generator pass (at most one: the previous asynchronous batch)
+    static const bool merge_on = getenv("P2P_NO_MERGE") == nullptr;
+    Slot* PS = nullptr;
+    for (Slot& s : P.slot)
+        if (&s != &SL && s.ticket >= 0 && s.stage2_pending) PS = &s;
+    // its pass 2 is merged with this batch's pass 1 when the new stage-1 inputs fit behind its stage-2 inputs
+    const bool merge = async && merge_on && PS && n <= PS->tail_cap;
+    if (PS && !merge && (rc = flush_stage2(X, P, *PS, st, true))) return rc;
+    float* x1 = merge ? PS->x2.as<float>() + (size_t)PS->n * PS->K * 16384 * 3 : nullptr;
+    if ((rc = enqueue_front(X, SL, st, objects, n_obj, images, n_img, dets, n, opt, x1))) {
+        SL.stage2_pending = false;
+        if (PS && merge) (void)flush_stage2(X, P, *PS, st, true);      // do not strand the waiting batch behind a rejected one
+        return rc;
+    }
+    const int K = SL.K;
+    float* y1 = SL.y1.as<float>();
+    if (merge) {
+        // mixed backbones inside either batch: no grouped pass over the concatenation -- fall back to two passes
+        const Model* m0 = reinterpret_cast<const Model*>(PS->objs[PS->groups[0].obj].model);
+        const Model* m1 = reinterpret_cast<const Model*>(SL.objs[SL.groups[0].obj].model);
+        if (PS->same_backbone && SL.same_backbone && m0->backbone == m1->backbone) {
+            const Slot* parts[2] = {PS, &SL};
+            const int per[2] = {PS->K, 1};
+            if ((rc = forward_parts(X, st, parts, per, 2, PS->x2.as<float>(), PS->y2.as<float>()))) return rc;
+            y1 = PS->y2.as<float>() + (size_t)PS->n * PS->K * 16384 * 4;
+            if ((rc = enqueue_tail(P, *PS, st, true))) return rc;
+        } else {
+            if ((rc = flush_stage2(X, P, *PS, st, true))) return rc;
+            const Slot* parts[1] = {&SL};
+            const int per[1] = {1};
+            y1 = PS->y2.as<float>() + (size_t)PS->n * PS->K * 16384 * 4;
+            if ((rc = forward_parts(X, st, parts, per, 1, x1, y1))) return rc;
+        }
+    } else {
+        const Slot* parts[1] = {&SL};
+        const int per[1] = {1};
+        if ((rc = forward_parts(X, st, parts, per, 1, SL.x1.as<float>(), y1))) return rc;
+    }
+    if ((rc = enqueue_mid(X, SL, st, y1))) return rc;
+    SL.stage2_pending = true;
     if (async) {
-        HIP_TRY(hipEventRecord(SL.done, ts));
-        // the slot's buffers are rewritten by the batch after next on the context stream
         SL.ticket = P.next_ticket;
         *async_ticket = P.next_ticket++;
         return P2P_OK;
     }
 
-    // -- debug taps (blocking call only)
+    // -- blocking call: pass 2 and the tail right away
+    if ((rc = flush_stage2(X, P, SL, st, false))) return rc;
+    // debug taps
+    const float *x1h = SL.x1.as<float>(), *x2h = SL.x2.as<float>();
     std::vector<float> hx1, hx2;
     std::vector<Stage1> hs1;
     std::vector<CandStat> hcs;
     std::vector<PnpResult> hres;
-    if (opt.dbg_x1) { hx1.resize((size_t)n * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx1.data(), x1, hx1.size() * 4, hipMemcpyDeviceToHost, st)); }
-    if (opt.dbg_x2) { hx2.resize((size_t)n * K * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx2.data(), x2, hx2.size() * 4, hipMemcpyDeviceToHost, st)); }
+    if (opt.dbg_x1) { hx1.resize((size_t)n * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx1.data(), x1h, hx1.size() * 4, hipMemcpyDeviceToHost, st)); }
+    if (opt.dbg_x2) { hx2.resize((size_t)n * K * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx2.data(), x2h, hx2.size() * 4, hipMemcpyDeviceToHost, st)); }
     if (opt.dbg_boxes2 || opt.dbg_cand) {
         hs1.resize(n); hcs.resize((size_t)n * K); hres.resize((size_t)n * K);
-        HIP_TRY(hipMemcpyAsync(hs1.data(), d_s1, sizeof(Stage1) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hs1.data(), SL.s1.p, sizeof(Stage1) * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(hcs.data(), SL.cand.p, sizeof(CandStat) * n * K, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(hres.data(), SL.results.p, sizeof(PnpResult) * n * K, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     finish_batch(SL, poses);
     for (int i = 0; i < n; ++i) {
-        const int o = perm[i];
+        const int o = SL.perm[i];
         if (opt.dbg_x1) memcpy(opt.dbg_x1 + (size_t)o * 16384 * 3, hx1.data() + (size_t)i * 16384 * 3, 16384 * 3 * 4);
         if (opt.dbg_x2) memcpy(opt.dbg_x2 + (size_t)o * K * 16384 * 3, hx2.data() + (size_t)i * K * 16384 * 3, (size_t)K * 16384 * 3 * 4);
         if (opt.dbg_boxes2) memcpy(opt.dbg_boxes2 + (size_t)o * 12, &hs1[i].b2, sizeof(Boxes));
@@ -1254,6 +1328,10 @@ static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses)
     if (!X.pipe) { set_error("no batch was submitted"); return P2P_ERR_INVALID_ARG; }
     for (Slot& s : X.pipe->slot)
         if (s.ticket == ticket) {
+            if (s.stage2_pending) {            // no later submit picked the stage-2 pass up: run it by itself
+                int rc = flush_stage2(X, *X.pipe, s, X.lane[0].stream, true);
+                if (rc) return rc;
+            }
             HIP_TRY(hipEventSynchronize(s.done));
             finish_batch(s, poses);
             s.ticket = -1;

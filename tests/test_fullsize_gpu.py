@@ -136,6 +136,55 @@ def test_configs3_share_30_objects_256_detections():
     assert sum(1 for p in both if p.status == 0) >= 245
 
 
+def test_stream_of_unequal_batches_equals_blocking():
+    """The detection stream merges batch k's stage-2 generator pass with batch k+1's stage-1 pass when the newcomer fits
+    (same size or smaller) and runs them separately otherwise; batches of different sizes, with two objects of different
+    threshold counts, masks and detector masks: every result equals the blocking call's."""
+    import torch
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch, est_pose_submit
+    ctx = Context(0, max_batch=48)                       # smaller than the merged passes: chunking inside them
+    specs = [ObjectSpec(Generator(W.synthetic_weights("paper", 1), "paper", ctx), S.OBJ_PARAM, TH_O, TH_I),
+             ObjectSpec(Generator(W.synthetic_weights("paper", 2), "paper", ctx), S.OBJ_PARAM * 1.1, [0.25, 0.4], 0.25)]
+    sizes = [24, 10, 30, 7, 7, 16]
+    scenes, inj, dets, dmasks = [], [], [], []
+    for k, n in enumerate(sizes):
+        sc = S.make_scene(n, seed=60 + k, bbox_side=(70, 120) if k % 2 else (86, 86))
+        scenes.append(sc)
+        inj.append((torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()))
+        dets.append([(d[0], (i + k) % 2, d[2], d[3]) for i, d in enumerate(sc["dets"])])
+        H, Wd = sc["images"].shape[1:3]
+        ms = []
+        for d in sc["dets"]:
+            m = np.zeros((H, Wd), bool)
+            m[max(d[2][0], 0) + 6:d[2][2] - 4, max(d[2][1], 0) + 3:d[2][3] - 7] = True
+            ms.append(m)
+        dmasks.append(ms)
+    torch.cuda.synchronize()
+    kw = lambda k: dict(inject1=inj[k][0].data_ptr(), inject2=inj[k][1].data_ptr(), inject_slots=3, want_masks=True, det_masks=dmasks[k])
+    ref = [est_pose_batch(ctx, specs, list(scenes[k]["images"]), dets[k], **kw(k)) for k in range(len(sizes))]
+    pend, got = [], []
+    for k in range(len(sizes)):
+        pend.append(est_pose_submit(ctx, specs, list(scenes[k]["images"]), dets[k], **kw(k)))
+        if len(pend) == 2:
+            pb = pend.pop(0)
+            got.append((pb.collect(), pb.extras))
+    while pend:
+        pb = pend.pop(0)
+        got.append((pb.collect(), pb.extras))
+    assert sum(p.status == 0 for r in ref for p in r[0]) >= 70
+    for k, ((rp, rex), (gp, gex)) in enumerate(zip(ref, got)):
+        assert [_key(x) for x in rp] == [_key(x) for x in gp], k
+        for name in ("valid_mask", "img_pred", "mask_stats"):
+            np.testing.assert_array_equal(rex[name], gex[name])
+    # a blocking call while the last submitted batch still waits for its stage-2 pass: both come out right
+    p = est_pose_submit(ctx, specs, list(scenes[1]["images"]), dets[1], **kw(1))
+    q = est_pose_submit(ctx, specs, list(scenes[3]["images"]), dets[3], **kw(3))
+    assert [_key(x) for x in p.collect()] == [_key(x) for x in ref[1][0]]
+    blk = est_pose_batch(ctx, specs, list(scenes[0]["images"]), dets[0], **kw(0))[0]       # slot 0 is free again, slot 1 pending
+    assert [_key(x) for x in blk] == [_key(x) for x in ref[0][0]]
+    assert [_key(x) for x in q.collect()] == [_key(x) for x in ref[3][0]]
+
+
 def test_async_submit_collect_equals_blocking():
     """Stream mode (two batches in flight, PnP tail on a second HIP stream) returns exactly what the
     blocking call returns, batch after batch; misuse is reported, not hung."""
