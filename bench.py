@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--f32-steps", type=int, default=3, help="steps of the strict-fp32 leg (N=1, single object; 0 = skip)")
     ap.add_argument("--host-frames", type=int, default=3, help="steps of the host-frame leg (N=1; 0 = skip)")
     ap.add_argument("--latency", type=int, default=100, help="calls of the single-detection latency leg (N=1; 0 = skip)")
+    ap.add_argument("--merge", action="store_true", help="stream mode: merge step i's stage-2 generator pass with step i+1's stage-1 pass (p2p_est_pose_opts.merge_stream_passes)")
     ap.add_argument("--no-legs", action="store_true", help="skip the f32 / host-frame / latency / CPU legs (profiling runs)")
     args = ap.parse_args()
     if args.no_legs:
@@ -235,7 +236,7 @@ def main():
             return out
         pending = []
         for i in range(k):
-            pending.append(est_pose_submit(ctx, specs, imgs(i), sc["dets"], want_masks=masks, **kw))
+            pending.append(est_pose_submit(ctx, specs, imgs(i), sc["dets"], want_masks=masks, merge_passes=args.merge, **kw))
             if len(pending) >= args.inflight:
                 out = finish(pending.pop(0).collect())
         while pending:

@@ -210,6 +210,11 @@ typedef struct {
      * (scikit-image >= 0.19 rejects the bool array of recognition.py:103, so the reference does not run there.)
      * clip=True of resize (output clamped to the input's range, cval preserved) is common to all versions and always on. */
     int resize_anti_aliasing;
+    /* p2p_est_pose_submit only: let the NEXT submit run this batch's stage-2 generator pass merged with its own stage-1
+     * pass (one pass over [x2(k) | x1(k+1)] when the newcomer is not larger; collect runs it alone otherwise).  Fewer, larger
+     * passes -- pays for small batches; at 256 detections per batch the chip is full either way (measured equal), so the
+     * default is off.  Results are identical. */
+    int merge_stream_passes;
 } p2p_est_pose_opts;
 
 /* Blocking.  poses[i] corresponds to dets[i]. */

@@ -56,7 +56,7 @@ class EstPoseOpts(C.Structure):
                 ("pred_stride", C.c_int64), ("dbg_x1", C.c_void_p), ("dbg_x2", C.c_void_p),
                 ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p),
                 ("det_mask", C.c_void_p), ("det_mask_stride", C.c_int64), ("mask_stats", C.c_void_p),
-                ("resize_anti_aliasing", C.c_int)]
+                ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int)]
 
 
 PROFILE_SLOTS = 7      # P2P_PROFILE_SLOTS

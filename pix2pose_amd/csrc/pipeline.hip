@@ -837,11 +837,12 @@ __global__ void aa_back_range_kernel(CandRange* __restrict__ crange, int n_cand,
 //   mid     stage-1 reductions, stage-2 geometry, stage-2 network inputs                      (enqueue_mid)
 //   pass 2  generator over the n*K stage-2 inputs
 //   tail    correspondences, PnP-RANSAC, selection, optional outputs, D2H                     (enqueue_tail)
-// A blocking call runs them back to back.  Asynchronous batches (submit / collect) run as a STREAM: batch k's pass 2 is
-// not enqueued by its own submit but by the next one, MERGED with batch k+1's pass 1 into one generator pass over
-// [x2(k) | x1(k+1)] -- one 1024-input pass per step instead of a 256- and a 768-input pass (the small pass fills the chip
-// badly: 32.2 vs 30.1 us per input), and batch k's latency-bound tail runs on the tail stream under batch k+1's next
-// pass.  collect(k) enqueues pass 2 of k by itself if no later submit did.
+// A blocking call runs them back to back.  Asynchronous batches (submit / collect) run as a STREAM on one HIP stream (the chain
+// pass 1 -> mid -> pass 2 of consecutive batches is serial), with every batch's latency-bound tail on the tail stream under the
+// next batch's passes.  With p2p_est_pose_opts.merge_stream_passes a batch's pass 2 is NOT enqueued by its own submit: the next
+// submit merges it with its own pass 1 into one generator pass over [x2(k) | x1(k+1)] (one 1024-input pass per step instead of
+// a 256- and a 768-input pass), or collect(k) runs it alone.  That pays for small batches; at 256 detections per batch it
+// measures equal (7570 vs 7610 crops/s) and 30-object batches lose a little to the split group table, so it is off by default.
 
 // Hand a finished batch over to the caller: sorted order -> caller order, pinned landing buffers -> the caller's
 // (pageable) output arrays named in the options of the submit / blocking call.
@@ -1244,12 +1245,11 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     }
 
     // the batch whose stage-2 inputs wait for a generator pass (at most one: the previous asynchronous batch)
-    static const bool merge_on = getenv("P2P_NO_MERGE") == nullptr;
     Slot* PS = nullptr;
     for (Slot& s : P.slot)
         if (&s != &SL && s.ticket >= 0 && s.stage2_pending) PS = &s;
     // its pass 2 is merged with this batch's pass 1 when the new stage-1 inputs fit behind its stage-2 inputs
-    const bool merge = async && merge_on && PS && n <= PS->tail_cap;
+    const bool merge = async && PS && PS->opt.merge_stream_passes && n <= PS->tail_cap;
     if (PS && !merge && (rc = flush_stage2(X, P, *PS, st, true))) return rc;
     float* x1 = merge ? PS->x2.as<float>() + (size_t)PS->n * PS->K * 16384 * 3 : nullptr;
     if ((rc = enqueue_front(X, SL, st, objects, n_obj, images, n_img, dets, n, opt, x1))) {
@@ -1284,6 +1284,8 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     if ((rc = enqueue_mid(X, SL, st, y1))) return rc;
     SL.stage2_pending = true;
     if (async) {
+        // pass 2 + tail now -- unless the caller asked for merged passes, in which case they wait for the next submit (or collect)
+        if (!opt.merge_stream_passes && (rc = flush_stage2(X, P, SL, st, true))) return rc;
         SL.ticket = P.next_ticket;
         *async_ticket = P.next_ticket++;
         return P2P_OK;

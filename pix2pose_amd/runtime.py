@@ -266,13 +266,14 @@ class PendingBatch:
 
 def est_pose_submit(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,
                     ransac_iterations=0, reprojection_error=0.0, confidence=0.0, want_masks=False, det_masks=None,
-                    anti_aliasing=False) -> PendingBatch:
+                    anti_aliasing=False, merge_passes=False) -> PendingBatch:
     """Asynchronous est_pose_batch for detection streams: enqueue and return; at most two batches in
     flight per context.  The PnP-RANSAC tail of this batch overlaps the generator passes of the next.
     ``want_masks`` / ``det_masks`` as in est_pose_batch: the arrays in ``PendingBatch.extras`` are filled by collect()."""
     n = len(detections)
     objs, imgs, dets, opts, extras, keep = _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks,
                                                     det_masks, ransac_iterations, reprojection_error, confidence, anti_aliasing)
+    opts.merge_stream_passes = 1 if merge_passes else 0       # the next submit may run this batch's stage-2 pass merged with its stage-1 pass
     ticket = C.c_int(-1)
     _lib.check(_lib.lib().p2p_est_pose_submit(ctx.handle, objs, len(objects), imgs, len(images), dets, n, C.byref(opts),
                                               C.byref(ticket)), "p2p_est_pose_submit")

@@ -136,9 +136,10 @@ def test_configs3_share_30_objects_256_detections():
     assert sum(1 for p in both if p.status == 0) >= 245
 
 
-def test_stream_of_unequal_batches_equals_blocking():
-    """The detection stream merges batch k's stage-2 generator pass with batch k+1's stage-1 pass when the newcomer fits
-    (same size or smaller) and runs them separately otherwise; batches of different sizes, with two objects of different
+@pytest.mark.parametrize("merge", [False, True])
+def test_stream_of_unequal_batches_equals_blocking(merge):
+    """The detection stream defers batch k's stage-2 generator pass to the next submit (or its collect); with merge_passes it
+    merges it with batch k+1's stage-1 pass when the newcomer fits (same size or smaller); batches of different sizes, with two objects of different
     threshold counts, masks and detector masks: every result equals the blocking call's."""
     import torch
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch, est_pose_submit
@@ -164,7 +165,7 @@ def test_stream_of_unequal_batches_equals_blocking():
     ref = [est_pose_batch(ctx, specs, list(scenes[k]["images"]), dets[k], **kw(k)) for k in range(len(sizes))]
     pend, got = [], []
     for k in range(len(sizes)):
-        pend.append(est_pose_submit(ctx, specs, list(scenes[k]["images"]), dets[k], **kw(k)))
+        pend.append(est_pose_submit(ctx, specs, list(scenes[k]["images"]), dets[k], merge_passes=merge, **kw(k)))
         if len(pend) == 2:
             pb = pend.pop(0)
             got.append((pb.collect(), pb.extras))
@@ -177,8 +178,8 @@ def test_stream_of_unequal_batches_equals_blocking():
         for name in ("valid_mask", "img_pred", "mask_stats"):
             np.testing.assert_array_equal(rex[name], gex[name])
     # a blocking call while the last submitted batch still waits for its stage-2 pass: both come out right
-    p = est_pose_submit(ctx, specs, list(scenes[1]["images"]), dets[1], **kw(1))
-    q = est_pose_submit(ctx, specs, list(scenes[3]["images"]), dets[3], **kw(3))
+    p = est_pose_submit(ctx, specs, list(scenes[1]["images"]), dets[1], merge_passes=merge, **kw(1))
+    q = est_pose_submit(ctx, specs, list(scenes[3]["images"]), dets[3], merge_passes=merge, **kw(3))
     assert [_key(x) for x in p.collect()] == [_key(x) for x in ref[1][0]]
     blk = est_pose_batch(ctx, specs, list(scenes[0]["images"]), dets[0], **kw(0))[0]       # slot 0 is free again, slot 1 pending
     assert [_key(x) for x in blk] == [_key(x) for x in ref[0][0]]
