@@ -758,60 +758,75 @@ struct PnpFit {
     int best, max_good, iters, state;   // state: 0 = refit pending, 1 = result already final, 2 = needs the lazy second hypothesis batch
 };
 
-// Kernel 1 of 2 -- hypotheses.  One workgroup (128 lanes) per problem: lane 0 replays the sampler,
+// Kernel 1 of 4 -- hypotheses.  A 16-lane group (round 0: four problems per wave) or a whole wave per problem: its first lane replays the sampler,
 // then one lane per minimal set solves the 5-point EPnP and stores the model (R from rvec, t) to
 // `hyp`.  A separate kernel because the register footprint of the inlined fp64 solver (it takes the
 // whole 512-entry file) must not be imposed on the scoring / refit phases, and so that the models of
 // ALL problems are solved in one resident round.
-constexpr int HYP_BATCH = 64;   // hypotheses per launch: RANSAC's adaptive bound stops long before 100 on good data (mean ~12 here),
-                                // so [0, 64) are solved first and [64, iterations) only for problems whose scoring ran past 63
+constexpr int SCORE_CHUNK = 8;   // hypotheses whose inlier counts are taken in one pass over the points (pnp_score_kernel)
+// Hypotheses are solved lazily in three rounds: RANSAC's adaptive bound stops long before 100 on good data (mean ~12 here), so
+// [0, 16) are solved first -- FOUR problems per wave, 16 lanes each: the inlined fp64 solver takes the whole 512-entry register
+// file, i.e. a resident wave blocks its SIMD for everything else, and a quarter of the waves blocks a quarter of the SIMD time --,
+// then [16, 64) and [64, iterations) only for the problems whose scoring ran past what it had (one problem per wave).
+constexpr int HYP_ROUND0 = 16, HYP_ROUND1 = 64;
 __global__ __launch_bounds__(64, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
-                                                            const PnpFit* __restrict__ fits, int iterations, int min_points, int h_begin)
+                                                            const PnpFit* __restrict__ fits, int n_problems, int iterations, int min_points,
+                                                            int h_begin, int h_stop, int ppb)
 {
-    __shared__ int s_idx[MAX_ITERS][5];
-    if (h_begin > 0 && fits[blockIdx.x].state != 2) return;
-    const PnpProblem pb = probs[blockIdx.x];
+    __shared__ int s_idx[MAX_ITERS][5];          // ppb == 4: rows 16 sub + it (it < 16); ppb == 1: row it
     const int tid = threadIdx.x;
+    const int lanes = 64 / ppb;                  // lanes per problem
+    const int sub = tid / lanes, lane_in = tid - sub * lanes;
+    const int prob = blockIdx.x * ppb + sub;
+    bool active = prob < n_problems && (h_begin == 0 || fits[prob].state == 2);
+    PnpProblem pb;
+    pb.n = 0; pb.cap = 0; pb.pts = nullptr; pb.mask = nullptr;
+    if (active) pb = probs[prob];
     const int n = pb.n;
-    if (n < min_points || n < 5) return;
-    const float* PX = pb.pts;
-    const float* PY = pb.pts + (size_t)pb.cap;
-    const float* PZ = pb.pts + 2 * (size_t)pb.cap;
-    const float* PU = pb.pts + 3 * (size_t)pb.cap;
-    const float* PV = pb.pts + 4 * (size_t)pb.cap;
-    Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
+    active = active && n >= min_points && n >= 5;
     if (iterations > MAX_ITERS) iterations = MAX_ITERS;
-
-    // ---- 1. replay the sampler
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
-    const int h_end = min(n_hyp, h_begin + HYP_BATCH);
-    if (h_begin >= h_end) return;
-    if (tid == 0) {
+    const int h_end = min(n_hyp, h_stop);
+    active = active && h_begin < h_end;
+    const int row0 = ppb > 1 ? sub * HYP_ROUND0 : 0;
+
+    // ---- 1. replay the sampler (one lane per problem)
+    if (active && lane_in == 0) {
         if (n == 5) {
-            for (int i = 0; i < 5; i++) s_idx[0][i] = i;
+            for (int i = 0; i < 5; i++) s_idx[row0][i] = i;
         } else {
             Rng rng(~0ULL);
-            for (int it = 0; it < h_end; it++)       // the generator state of sample `it` depends on all earlier samples
+            int cur[5];
+            for (int it = 0; it < h_end; it++) {     // the generator state of sample `it` depends on all earlier samples
                 for (int i = 0; i < 5;) {
                     int idx_i, j;
                     for (;;) {
-                        idx_i = s_idx[it][i] = rng.uniform(0, n);
-                        for (j = 0; j < i; j++) if (idx_i == s_idx[it][j]) break;
+                        idx_i = cur[i] = rng.uniform(0, n);
+                        for (j = 0; j < i; j++) if (idx_i == cur[j]) break;
                         if (j == i) break;
                     }
                     i++;
                 }
+                if (ppb == 1 || it < HYP_ROUND0)
+                    for (int i = 0; i < 5; i++) s_idx[row0 + it][i] = cur[i];
+            }
         }
     }
     __syncthreads();
 
     // ---- 2. hypotheses: one lane each
-    const double ifx = 1. / pb.K[0], ify = 1. / pb.K[4];
-    const int hi = h_begin + tid;
-    if (hi < h_end) {
+    const int hi = h_begin + lane_in;
+    if (active && hi < h_end) {
+        const float* PX = pb.pts;
+        const float* PY = pb.pts + (size_t)pb.cap;
+        const float* PZ = pb.pts + 2 * (size_t)pb.cap;
+        const float* PU = pb.pts + 3 * (size_t)pb.cap;
+        const float* PV = pb.pts + 4 * (size_t)pb.cap;
+        Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
+        const double ifx = 1. / pb.K[0], ify = 1. / pb.K[4];
         double pws[15], us[10];
         for (int i = 0; i < 5; i++) {
-            const int id = s_idx[hi][i];
+            const int id = s_idx[row0 + (ppb > 1 ? lane_in : hi)][i];
             pws[3 * i] = PX[id]; pws[3 * i + 1] = PY[id]; pws[3 * i + 2] = PZ[id];
             // undistortPoints (identity distortion) stores float32 normalised coordinates; epnp re-applies fu, uc
             const double xn = (double)(float)(((double)PU[id] - pb.K[2]) * ifx);
@@ -823,7 +838,7 @@ __global__ __launch_bounds__(64, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(c
         epnp5(cam, pws, us, R, t);
         rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
         rodrigues_v2r(rvec, R);
-        double* h = hyp + ((size_t)blockIdx.x * MAX_ITERS + hi) * 12;
+        double* h = hyp + ((size_t)prob * MAX_ITERS + hi) * 12;
         for (int k = 0; k < 9; k++) h[k] = R[k];
         for (int k = 0; k < 3; k++) h[9 + k] = t[k];
     }
@@ -834,15 +849,16 @@ __global__ __launch_bounds__(64, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(c
 // points; Gram sums).  One workgroup (256 threads) per problem.
 __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
                                                               PnpResult* __restrict__ results, PnpFit* __restrict__ fits, int iterations,
-                                                              double reproj_err, double confidence, int min_points, int pass)
+                                                              double reproj_err, double confidence, int min_points, int n_solved, int first)
 {
     PnpFit& fit = fits[blockIdx.x];
-    if (pass == 2 && fit.state != 2) return;     // second pass: only problems whose first pass ran out of hypotheses
+    if (!first && fit.state != 2) return;        // later passes: only problems whose scoring ran out of hypotheses
     __shared__ double s_R[MAX_ITERS][9];
     __shared__ double s_t[MAX_ITERS][3];
     __shared__ double s_red[4 * 56];
     __shared__ int s_ired[4];
     __shared__ int s_ctl[4];         // niters, best, max_good, iter
+    __shared__ int s_cnt[SCORE_CHUNK];
     __shared__ double s_fit[24];     // control points + inverse, thread 0 -> all
 
     const PnpProblem pb = probs[blockIdx.x];
@@ -867,7 +883,7 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
         return;
     }
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
-    const int n_avail = pass == 1 ? min(n_hyp, HYP_BATCH) : n_hyp;     // hypotheses solved so far
+    const int n_avail = min(n_hyp, n_solved);                           // hypotheses solved so far
     for (int i = tid; i < n_avail * 12; i += 256) {
         const int h = i / 12, k = i - h * 12;
         const double v = hyp[((size_t)blockIdx.x * MAX_ITERS + h) * 12 + k];
@@ -882,26 +898,49 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
         if (tid == 0) { s_ctl[1] = 0; s_ctl[2] = 5; s_ctl[3] = 0; }
         __syncthreads();
     } else {
-        for (int it = 0;; ++it) {
-            if (it >= s_ctl[0]) break;           // uniform: s_ctl[0] is read after the barrier below
-            if (it >= n_avail) {                 // (pass 1 only) the bound still asks for more: solve the rest, score again from 0
+        // OpenCV walks the hypotheses one by one: count inliers, keep the best, shrink the iteration bound.  Only the COUNT of a
+        // hypothesis enters that rule, so the counts of SCORE_CHUNK consecutive hypotheses are taken in one pass over the points
+        // (a point is loaded once and tested against the chunk's models out of LDS) and one reduction, and thread 0 then replays
+        // the sequential rule over them -- same decisions, same iteration count, a fraction of the passes and barriers (the
+        // kernel is bound by the latency of its point loops, not by arithmetic).  Counts past the stopping point are discarded.
+        for (int it0 = 0;; it0 += SCORE_CHUNK) {
+            if (it0 >= s_ctl[0]) break;          // uniform: s_ctl[0] is read after the barrier below
+            if (it0 >= n_avail) {                // (n_avail < n_hyp only) the bound still asks for more: solve the next round, score again from 0
                 if (tid == 0) fit.state = 2;
                 return;
             }
-            double R[9], t[3];
-            for (int k = 0; k < 9; k++) R[k] = s_R[it][k];
-            for (int k = 0; k < 3; k++) t[k] = s_t[it][k];
-            int cnt = 0;
-            for (int i = tid; i < n; i += 256) cnt += is_inlier(R, t, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2) ? 1 : 0;
-            const int good = block_reduce_int(cnt, s_ired);
+            const int hc = min(SCORE_CHUNK, n_avail - it0);
+            int cnt[SCORE_CHUNK];
+#pragma unroll
+            for (int h = 0; h < SCORE_CHUNK; ++h) cnt[h] = 0;
+            if (tid < SCORE_CHUNK) s_cnt[tid] = 0;
+            for (int i = tid; i < n; i += 256) {
+                const float px = PX[i], py = PY[i], pz = PZ[i], pu = PU[i], pv = PV[i];
+#pragma unroll
+                for (int h = 0; h < SCORE_CHUNK; ++h)
+                    if (h < hc) cnt[h] += is_inlier(s_R[it0 + h], s_t[it0 + h], cam, px, py, pz, pu, pv, thr2) ? 1 : 0;
+            }
+            __syncthreads();                     // s_cnt zeroed
+#pragma unroll
+            for (int h = 0; h < SCORE_CHUNK; ++h) {
+                int x = cnt[h];
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+                if ((tid & 63) == 0 && x) atomicAdd(&s_cnt[h], x);
+            }
+            __syncthreads();
             if (tid == 0) {
-                const int mg = s_ctl[2];
-                if (good > (mg > 4 ? mg : 4)) {
-                    s_ctl[2] = good;
-                    s_ctl[1] = it;
-                    s_ctl[0] = ransac_update_num_iters(confidence, (double)(n - good) / n, 5, s_ctl[0]);
+                for (int h = 0; h < hc; ++h) {
+                    const int it = it0 + h;
+                    if (it >= s_ctl[0]) break;   // the bound was reached inside the chunk
+                    const int good = s_cnt[h];
+                    const int mg = s_ctl[2];
+                    if (good > (mg > 4 ? mg : 4)) {
+                        s_ctl[2] = good;
+                        s_ctl[1] = it;
+                        s_ctl[0] = ransac_update_num_iters(confidence, (double)(n - good) / n, 5, s_ctl[0]);
+                    }
+                    s_ctl[3] = it + 1;
                 }
-                s_ctl[3] = it + 1;
             }
             __syncthreads();
         }
@@ -1155,20 +1194,21 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
 {
     if (n_problems <= 0) return hipSuccess;
     pnp::PnpFit* fits = reinterpret_cast<pnp::PnpFit*>(workspace + (size_t)n_problems * pnp::MAX_ITERS * 12);
-    hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(n_problems), dim3(64), 0, s, probs, workspace, fits, iterations, min_points, 0);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
-                       reproj_err, confidence, min_points, 1);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (iterations > pnp::HYP_BATCH) {
-        // lazy tail: problems flagged by pass 1 get hypotheses [64, iterations) and are scored again in full;
-        // everything else leaves these two launches at once
-        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(n_problems), dim3(64), 0, s, probs, workspace, fits, iterations, min_points, pnp::HYP_BATCH);
+    hipError_t e;
+    // round 0: hypotheses [0, 16), four problems per wave; later rounds only for problems whose scoring ran past what it had --
+    // everything else leaves those launches at once
+    const int stops[3] = {pnp::HYP_ROUND0, pnp::HYP_ROUND1, pnp::MAX_ITERS};
+    int h_begin = 0;
+    for (int r = 0; r < 3; ++r) {
+        const int ppb = r == 0 ? 4 : 1;
+        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems + ppb - 1) / ppb), dim3(64), 0, s, probs, workspace, fits, n_problems, iterations,
+                           min_points, h_begin, stops[r], ppb);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
-                           reproj_err, confidence, min_points, 2);
+                           reproj_err, confidence, min_points, stops[r], r == 0 ? 1 : 0);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        h_begin = stops[r];
+        if (iterations <= h_begin) break;
     }
     hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
