@@ -156,6 +156,11 @@ __device__ inline int reflect_idx(int i, int n)   // numpy-pad 'reflect' (edge s
     return i >= n ? p - i : i;
 }
 
+// A tap whose weight is exactly zero (d == 0: the source coordinate is an integer, floor == ceil, as in every resize of a
+// 128-px crop) is not evaluated: (1 - 0) * v + 0 * anything-finite == v, so its value can be any finite number.  For the
+// identity resizes of BASELINE.json configs[1-3] that is 1 tap instead of 4 -- and 1 instead of 16 where taps nest.
+#define P2P_TAP_LIVE(a, e, tr, tc) (((a) == 0 || (tr).d != 0) && ((e) == 0 || (tc).d != 0))
+
 __device__ inline double lerp2(double tl, double tr, double bl, double br, double dr, double dc)
 {
     const double top = (1 - dc) * tl + dc * tr;
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(256) void stage1_input_kernel(const DetInfo* __rest
         double v[2][2];
         for (int a = 0; a < 2; ++a)
             for (int e = 0; e < 2; ++e) {
+                if (!P2P_TAP_LIVE(a, e, tr, tc)) { v[a][e] = 0.0; continue; }
                 if (cv) { v[a][e] = cv[((size_t)r[a] * Sw + c[e]) * 3 + ch]; continue; }
                 const bool in = r[a] >= b.vv1 && r[a] < b.vv2 && c[e] >= b.uu1 && c[e] < b.uu2;
                 v[a][e] = in ? frame_px(D, b.v1 + r[a] - b.vv1, b.u1 + c[e] - b.uu1, ch) : 0.0;
@@ -291,7 +297,7 @@ __device__ inline bool keep_ori_at(const float* y1d, const double* kp, float th,
     for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 2; ++e) {
             double k = 0.0;
-            if (ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
+            if (P2P_TAP_LIVE(a, e, tr, tc) && ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
                 if (kp) k = kp[ri[a] * 128 + cj[e]];
                 else {
                     const float* q = y1d + ((size_t)ri[a] * 128 + cj[e]) * 4;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __rest
         for (int ch = 0; ch < 3; ++ch) {
             double v[2][2];
             for (int a = 0; a < 2; ++a)
-                for (int e = 0; e < 2; ++e) v[a][e] = cv[((size_t)r[a] * S2w + c[e]) * 3 + ch];
+                for (int e = 0; e < 2; ++e) v[a][e] = P2P_TAP_LIVE(a, e, tr, tc) ? cv[((size_t)r[a] * S2w + c[e]) * 3 + ch] : 0.0;
             out[ch] = (float)lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d);
         }
         return;
@@ -353,7 +359,10 @@ __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __rest
     bool fg[2][2];
     int fy[2][2], fx[2][2];
     for (int a = 0; a < 2; ++a)
-        for (int e = 0; e < 2; ++e) fg[a][e] = stage2_fg(D, S, y1d, kp, slot, r[a], c[e], &fy[a][e], &fx[a][e]);
+        for (int e = 0; e < 2; ++e) {
+            fy[a][e] = fx[a][e] = 0;
+            fg[a][e] = P2P_TAP_LIVE(a, e, tr, tc) && stage2_fg(D, S, y1d, kp, slot, r[a], c[e], &fy[a][e], &fx[a][e]);
+        }
     for (int ch = 0; ch < 3; ++ch) {
         double v[2][2];
         for (int a = 0; a < 2; ++a)
@@ -394,7 +403,10 @@ __device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const
     double prob[2][2], ng[2][2], pred[3][2][2];
     for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 2; ++e) {
-            if (ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
+            if (!P2P_TAP_LIVE(a, e, tr, tc)) {
+                prob[a][e] = 0.0; ng[a][e] = 0.0;
+                pred[0][a][e] = pred[1][a][e] = pred[2][a][e] = 0.0;
+            } else if (ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
                 const int idx = ri[a] * 128 + cj[e];
                 if (bk) {
                     prob[a][e] = bk[idx];

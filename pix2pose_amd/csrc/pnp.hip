@@ -914,11 +914,20 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
 #pragma unroll
             for (int h = 0; h < SCORE_CHUNK; ++h) cnt[h] = 0;
             if (tid < SCORE_CHUNK) s_cnt[tid] = 0;
-            for (int i = tid; i < n; i += 256) {
-                const float px = PX[i], py = PY[i], pz = PZ[i], pu = PU[i], pv = PV[i];
+            for (int i0 = tid; i0 < n; i0 += 4 * 256) {          // four points per trip: their 20 loads are in flight together
+                float px[4], py[4], pz[4], pu[4], pv[4];
 #pragma unroll
-                for (int h = 0; h < SCORE_CHUNK; ++h)
-                    if (h < hc) cnt[h] += is_inlier(s_R[it0 + h], s_t[it0 + h], cam, px, py, pz, pu, pv, thr2) ? 1 : 0;
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + 256 * u, n - 1);
+                    px[u] = PX[i]; py[u] = PY[i]; pz[u] = PZ[i]; pu[u] = PU[i]; pv[u] = PV[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + 256 * u >= n) break;
+#pragma unroll
+                    for (int h = 0; h < SCORE_CHUNK; ++h)
+                        if (h < hc) cnt[h] += is_inlier(s_R[it0 + h], s_t[it0 + h], cam, px[u], py[u], pz[u], pu[u], pv[u], thr2) ? 1 : 0;
+                }
             }
             __syncthreads();                     // s_cnt zeroed
 #pragma unroll
