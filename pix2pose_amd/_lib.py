@@ -49,6 +49,15 @@ class Pose(C.Structure):
                 ("n_candidates", C.c_int), ("ransac_iters", C.c_int)]
 
 
+import numpy as _np
+
+# numpy views of the struct arrays (same field order / alignment as the ctypes definitions; sizes asserted below)
+POSE_DTYPE = _np.dtype([("R", "<f8", (9,)), ("t", "<f8", (3,)), ("frac_inlier", "<f8"), ("n_inliers", "<i4"), ("n_init_mask", "<i4"),
+                        ("status", "<i4"), ("best_slot", "<i4"), ("bbox_t", "<i4", (4,)), ("n_candidates", "<i4"), ("ransac_iters", "<i4")], align=True)
+DETECTION_DTYPE = _np.dtype([("image", "<i4"), ("object", "<i4"), ("bbox", "<i4", (4,)), ("camK", "<f8", (9,))], align=True)
+assert POSE_DTYPE.itemsize == C.sizeof(Pose) and DETECTION_DTYPE.itemsize == C.sizeof(Detection)
+
+
 class EstPoseOpts(C.Structure):
     _fields_ = [("ransac_iterations", C.c_int), ("reprojection_error", C.c_double), ("confidence", C.c_double),
                 ("inject1", C.c_void_p), ("inject2", C.c_void_p), ("inject_slots", C.c_int),

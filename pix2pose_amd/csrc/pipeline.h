@@ -177,7 +177,9 @@ struct Pipeline {
     static constexpr int N_SLOTS = 2;   // asynchronous batches in flight (each on its own generator lane)
     Slot slot[N_SLOTS];
     hipStream_t tail_stream = nullptr;  // PnP + selection + D2H of async batches
+    hipStream_t copy_stream = nullptr;  // host frames -> HBM, under the previous batch's generator passes
     hipEvent_t corr_ready = nullptr;
+    hipEvent_t frames_ready = nullptr;
     int next_ticket = 0;
     ~Pipeline();
 };

@@ -78,7 +78,9 @@ Pipeline::~Pipeline()
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (corr_ready) (void)hipEventDestroy(corr_ready);
+    if (frames_ready) (void)hipEventDestroy(frames_ready);
     if (tail_stream) (void)hipStreamDestroy(tail_stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
 }
 void Ctx::free_pipeline()
 {
@@ -938,7 +940,7 @@ static int inject_maps(const Slot& SL, hipStream_t st, const float* src, float* 
 }
 
 // front: validation, frames, per-detection constants, buffers, stage-1 network inputs into x1_dst (null: the slot's own x1)
-static int enqueue_front(Ctx& X, Slot& SL, hipStream_t st, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
+static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2p_object* objects, int n_obj, const p2p_image* images, int n_img,
                          const p2p_detection* dets, int n, const p2p_est_pose_opts& opt, float* x1_dst)
 {
     int rc;
@@ -979,15 +981,21 @@ static int enqueue_front(Ctx& X, Slot& SL, hipStream_t st, const p2p_object* obj
             if (images[i].mem == P2P_MEM_HOST) need += ((size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1) + 255) / 256 * 256;
         }
         if ((rc = SL.images.reserve(need))) return rc;
+        // host frames (the reference's boundary: est_pose takes a numpy frame, recognition.py:70) go up on their own stream, so the
+        // PCIe transfer runs under the generator passes already queued on `st`; `st` waits for them before the first kernel
         size_t off = 0;
         for (int i = 0; i < n_img; ++i) {
             const size_t bytes = (size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1);
             if (images[i].mem == P2P_MEM_HOST) {
-                HIP_TRY(hipMemcpyAsync(SL.images.as<char>() + off, images[i].data, bytes, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(SL.images.as<char>() + off, images[i].data, bytes, hipMemcpyHostToDevice, P.copy_stream));
                 img_dev[i] = SL.images.as<char>() + off;
                 off += (bytes + 255) / 256 * 256;
             } else
                 img_dev[i] = images[i].data;
+        }
+        if (need) {
+            HIP_TRY(hipEventRecord(P.frames_ready, P.copy_stream));
+            HIP_TRY(hipStreamWaitEvent(st, P.frames_ready, 0));
         }
     }
 
@@ -1233,7 +1241,9 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     hipStream_t st = X.lane[0].stream;           // the chain pass 1 -> mid -> pass 2 of consecutive batches is serial: one stream
     if (!P.tail_stream) {
         HIP_TRY(hipStreamCreate(&P.tail_stream));
+        HIP_TRY(hipStreamCreate(&P.copy_stream));
         HIP_TRY(hipEventCreateWithFlags(&P.corr_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&P.frames_ready, hipEventDisableTiming));
         for (Slot& s : P.slot) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     const int slot_idx = async ? (P.next_ticket % Pipeline::N_SLOTS) : 0;
@@ -1264,7 +1274,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     const bool merge = async && PS && PS->opt.merge_stream_passes && n <= PS->tail_cap;
     if (PS && !merge && (rc = flush_stage2(X, P, *PS, st, true))) return rc;
     float* x1 = merge ? PS->x2.as<float>() + (size_t)PS->n * PS->K * 16384 * 3 : nullptr;
-    if ((rc = enqueue_front(X, SL, st, objects, n_obj, images, n_img, dets, n, opt, x1))) {
+    if ((rc = enqueue_front(X, P, SL, st, objects, n_obj, images, n_img, dets, n, opt, x1))) {
         SL.stage2_pending = false;
         if (PS && merge) (void)flush_stage2(X, P, *PS, st, true);      // do not strand the waiting batch behind a rejected one
         return rc;

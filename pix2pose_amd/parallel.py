@@ -27,17 +27,26 @@ def shard_detections(detections, world: int):
 
 
 def poses_to_records(poses, base_id=0, ids=None) -> np.ndarray:
-    """p2p_pose structs -> [n, REC] float64 records (float64 keeps R, t bit-exact)."""
-    out = np.zeros((len(poses), REC), np.float64)
-    for i, p in enumerate(poses):
-        out[i, 0] = (ids[i] if ids is not None else base_id + i)
-        out[i, 1] = p.status
-        out[i, 2] = p.frac_inlier
-        out[i, 3] = p.n_inliers
-        out[i, 4] = p.n_init_mask
-        out[i, 5] = p.best_slot
-        out[i, 6:15] = list(p.R)
-        out[i, 15:18] = list(p.t)
+    """p2p_pose structs -> [n, REC] float64 records (float64 keeps R, t bit-exact).  `poses` is a list of _lib.Pose or the
+    ctypes array the binding fills (one vectorised view instead of a Python loop: this runs once per step on every rank)."""
+    from . import _lib
+    n = len(poses)
+    out = np.zeros((n, REC), np.float64)
+    if n == 0:
+        return out
+    if isinstance(poses, (list, tuple)):
+        arr = (_lib.Pose * n)(*poses)
+    else:
+        arr = poses
+    v = np.frombuffer(arr, dtype=_lib.POSE_DTYPE, count=n)
+    out[:, 0] = np.asarray(ids, np.float64) if ids is not None else base_id + np.arange(n)
+    out[:, 1] = v["status"]
+    out[:, 2] = v["frac_inlier"]
+    out[:, 3] = v["n_inliers"]
+    out[:, 4] = v["n_init_mask"]
+    out[:, 5] = v["best_slot"]
+    out[:, 6:15] = v["R"]
+    out[:, 15:18] = v["t"]
     return out
 
 

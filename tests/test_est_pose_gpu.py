@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from pix2pose_amd import weights as W
-from tests import synth
+from pix2pose_amd import synthetic as synth
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,7 @@ import torch
 
 from oracle import ae_oracle as O
 from pix2pose_amd import weights as W
-from tests import torch_ref
+from oracle import ae_torch as torch_ref
 
 
 def test_same_pad_rules():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import pnp_oracle as P
-from tests import synth
+from pix2pose_amd import synthetic as synth
 
 
 def _mwc(seed, n):

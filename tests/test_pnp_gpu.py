@@ -24,7 +24,7 @@ def _log_rate(test, n_exact, n_total, mismatches):
     except OSError:
         pass
 
-from tests import synth
+from pix2pose_amd import synthetic as synth
 
 pytestmark = pytest.mark.gpu
 
