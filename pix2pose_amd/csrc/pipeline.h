@@ -153,6 +153,7 @@ struct Slot {
     p2p_pose* host_poses = nullptr;     // pinned
     size_t host_cap = 0;
     PinnedBuf h_mask, h_pred, h_stat;   // pinned landing buffers of the optional outputs (sorted order)
+    PinnedBuf h_frames;                 // pinned staging of host frames (pageable caller memory -> here -> DMA)
     // host-side description of the batch (kept from submit to collect: the stage-2 pass of an asynchronous batch is enqueued
     // by the NEXT submit, merged with that batch's stage-1 pass, or by collect)
     std::vector<int> perm;

@@ -73,7 +73,7 @@ Pipeline::~Pipeline()
     for (Slot& s : slot) {
         for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images,
                           &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_kp, &s.aa_kp_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
-        for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat}) b->release();
+        for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat, &s.h_frames}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
         if (s.done) (void)hipEventDestroy(s.done);
     }
@@ -980,20 +980,23 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
             if (!images[i].data || images[i].height <= 0 || images[i].width <= 0) { set_error("image %d is empty", i); return P2P_ERR_INVALID_ARG; }
             if (images[i].mem == P2P_MEM_HOST) need += ((size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1) + 255) / 256 * 256;
         }
-        if ((rc = SL.images.reserve(need))) return rc;
-        // host frames (the reference's boundary: est_pose takes a numpy frame, recognition.py:70) go up on their own stream, so the
-        // PCIe transfer runs under the generator passes already queued on `st`; `st` waits for them before the first kernel
+        if ((rc = SL.images.reserve(need)) || (rc = SL.h_frames.reserve(need))) return rc;
+        // host frames (the reference's boundary: est_pose takes a numpy frame, recognition.py:70): the caller's pageable memory is
+        // copied into the slot's pinned staging buffer (a plain memcpy: the frames are free again when submit returns) and goes up
+        // as ONE DMA on its own stream, under the generator passes already queued on `st`; `st` waits for it before the first kernel.
+        // (hipMemcpyAsync straight from pageable memory cost 1.6 ms per 30 MB step even on a separate stream.)
         size_t off = 0;
         for (int i = 0; i < n_img; ++i) {
             const size_t bytes = (size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1);
             if (images[i].mem == P2P_MEM_HOST) {
-                HIP_TRY(hipMemcpyAsync(SL.images.as<char>() + off, images[i].data, bytes, hipMemcpyHostToDevice, P.copy_stream));
+                memcpy(SL.h_frames.as<char>() + off, images[i].data, bytes);
                 img_dev[i] = SL.images.as<char>() + off;
                 off += (bytes + 255) / 256 * 256;
             } else
                 img_dev[i] = images[i].data;
         }
         if (need) {
+            HIP_TRY(hipMemcpyAsync(SL.images.p, SL.h_frames.p, need, hipMemcpyHostToDevice, P.copy_stream));
             HIP_TRY(hipEventRecord(P.frames_ready, P.copy_stream));
             HIP_TRY(hipStreamWaitEvent(st, P.frames_ready, 0));
         }

@@ -856,7 +856,6 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     __shared__ double s_R[MAX_ITERS][9];
     __shared__ double s_t[MAX_ITERS][3];
     __shared__ double s_red[4 * 56];
-    __shared__ int s_ired[4];
     __shared__ int s_ctl[4];         // niters, best, max_good, iter
     __shared__ int s_cnt[SCORE_CHUNK];
     __shared__ double s_fit[24];     // control points + inverse, thread 0 -> all
