@@ -122,6 +122,14 @@ def test_anti_aliased_resizes_large_crops(rig):
     assert _run_injected(rig, sc, anti_aliasing=True) >= 6
 
 
+def test_anti_aliased_resizes_sweep_with_border_clipping(rig):
+    """A denser sweep of crop sides (66..390 px: Gaussian radii 0..5 on the way in, 0..4 on the way back) on small frames, so
+    that many stage-1 / stage-2 squares hang over the frame border (zero canvas outside the paste window, 'mirror' filter
+    border) -- against the oracle, whose filter is scipy's."""
+    sc = synth.make_scene(20, seed=45, bbox_side=(44, 260), H=300, W=400, n_images=3)
+    assert _run_injected(rig, sc, anti_aliasing=True) >= 12
+
+
 def test_anti_aliasing_off_and_on_differ_and_identity_at_128(rig):
     import torch
     from pix2pose_amd.runtime import est_pose_batch
