@@ -980,22 +980,52 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     for (int k = 0; k < 3; k++) tb[k] = s_t[best][k];
     const int m = max_good;
 
+    // The three refit passes below walk the points in the same per-thread order as before (i = tid, tid + 256, ...: the partial sums
+    // and therefore the results are unchanged) but four points per trip, so that their loads are in flight together, and the
+    // inlier flags of the winning hypothesis are computed ONCE (pass A) and kept as a per-thread bit mask for the other two passes
+    // (up to 64 points per thread = 16 384 correspondences, the 128-px crop; larger problems re-evaluate the test).
+    const bool use_mask = n <= 64 * 256;
+    unsigned long long inmask = 0;
     // pass A: centroid and covariance of the inlier object points
     {
         double v[3] = {0, 0, 0};
-        for (int i = tid; i < n; i += 256) {
-            const bool in = is_inlier(Rb, tb, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2);
-            if (pb.mask) pb.mask[i] = in ? 1 : 0;
-            if (in) { v[0] += PX[i]; v[1] += PY[i]; v[2] += PZ[i]; }
+        for (int i0 = tid, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
+            float px[4], py[4], pz[4], pu[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, n - 1);
+                px[u] = PX[i]; py[u] = PY[i]; pz[u] = PZ[i]; pu[u] = PU[i]; pv[u] = PV[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                if (i >= n) break;
+                const bool in = is_inlier(Rb, tb, cam, px[u], py[u], pz[u], pu[u], pv[u], thr2);
+                if (pb.mask) pb.mask[i] = in ? 1 : 0;
+                if (in) { v[0] += px[u]; v[1] += py[u]; v[2] += pz[u]; if (use_mask) inmask |= 1ull << (k0 + u); }
+            }
         }
         block_reduce<3>(v, s_red);
         double c0[3] = {v[0] / m, v[1] / m, v[2] / m};
         double q[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = tid; i < n; i += 256)
-            if (is_inlier(Rb, tb, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2)) {
-                const double dx = PX[i] - c0[0], dy = PY[i] - c0[1], dz = PZ[i] - c0[2];
-                q[0] += dx * dx; q[1] += dx * dy; q[2] += dx * dz; q[3] += dy * dy; q[4] += dy * dz; q[5] += dz * dz;
+        for (int i0 = tid, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
+            float px[4], py[4], pz[4], pu[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, n - 1);
+                px[u] = PX[i]; py[u] = PY[i]; pz[u] = PZ[i];
+                if (!use_mask) { pu[u] = PU[i]; pv[u] = PV[i]; } else { pu[u] = pv[u] = 0.f; }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + 256 * u >= n) break;
+                const bool in = use_mask ? ((inmask >> (k0 + u)) & 1ull) != 0 : is_inlier(Rb, tb, cam, px[u], py[u], pz[u], pu[u], pv[u], thr2);
+                if (in) {
+                    const double dx = px[u] - c0[0], dy = py[u] - c0[1], dz = pz[u] - c0[2];
+                    q[0] += dx * dx; q[1] += dx * dy; q[2] += dx * dz; q[3] += dy * dy; q[4] += dy * dz; q[5] += dz * dz;
+                }
+            }
+        }
         block_reduce<6>(q, s_red);
         if (tid == 0) {
             const double ptp[9] = {q[0], q[1], q[2], q[1], q[3], q[4], q[2], q[4], q[5]};
@@ -1020,28 +1050,39 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     double g[56];
 #pragma unroll
     for (int k = 0; k < 56; k++) g[k] = 0;
-    for (int i = tid; i < n; i += 256) {
-        if (!is_inlier(Rb, tb, cam, PX[i], PY[i], PZ[i], PU[i], PV[i], thr2)) continue;
-        const double p[3] = {PX[i], PY[i], PZ[i]};
-        double a[4];
-        barycentric(ci, cws, p, a);
-        const double du = cam.uc - (double)PU[i], dv = cam.vc - (double)PV[i];
-        const double dd = du * du + dv * dv;
-        int e = 0;
+    for (int i0 = tid, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
+        float px[4], py[4], pz[4], pu[4], pv[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + 256 * u, n - 1);
+            px[u] = PX[i]; py[u] = PY[i]; pz[u] = PZ[i]; pu[u] = PU[i]; pv[u] = PV[i];
+        }
 #pragma unroll
-            for (int k = j; k < 4; k++) {
-                const double ajk = a[j] * a[k];
-                g[e] += ajk; g[10 + e] += ajk * du; g[20 + e] += ajk * dv; g[30 + e] += ajk * dd;
-                ++e;
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + 256 * u >= n) break;
+            const bool in = use_mask ? ((inmask >> (k0 + u)) & 1ull) != 0 : is_inlier(Rb, tb, cam, px[u], py[u], pz[u], pu[u], pv[u], thr2);
+            if (!in) continue;
+            const double p[3] = {px[u], py[u], pz[u]};
+            double a[4];
+            barycentric(ci, cws, p, a);
+            const double du = cam.uc - (double)pu[u], dv = cam.vc - (double)pv[u];
+            const double dd = du * du + dv * dv;
+            int e = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = j; k < 4; k++) {
+                    const double ajk = a[j] * a[k];
+                    g[e] += ajk; g[10 + e] += ajk * du; g[20 + e] += ajk * dv; g[30 + e] += ajk * dd;
+                    ++e;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                g[40 + j] += a[j];
+                g[44 + 3 * j] += a[j] * (p[0] - cws[0][0]);
+                g[45 + 3 * j] += a[j] * (p[1] - cws[0][1]);
+                g[46 + 3 * j] += a[j] * (p[2] - cws[0][2]);
             }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            g[40 + j] += a[j];
-            g[44 + 3 * j] += a[j] * (p[0] - cws[0][0]);
-            g[45 + 3 * j] += a[j] * (p[1] - cws[0][1]);
-            g[46 + 3 * j] += a[j] * (p[2] - cws[0][2]);
         }
     }
     block_reduce<56>(g, s_red);
