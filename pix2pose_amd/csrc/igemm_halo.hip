@@ -70,33 +70,40 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
     const int halo_px = HPX * HPY;
     const int PITCH = HPX * REC + ((16 - (9 * HPX) % 16) % 16) * 16;      // row pitch: a multiple of 16 slots (256 B)
 
-    if (tid < p.ntaps) s_tap[tid] = ((int)p.dy[tid] - dy0) * PITCH + ((int)p.dx[tid] - dx0) * REC;
-
-    // ---- PERSISTENT workgroups: the grid is one workgroup per resident slot of the chip and every workgroup walks several tiles.
-    //      XCD-aware order (block b runs on XCD b % 8): every XCD owns a contiguous run of tiles (n-tile fastest), which its
-    //      workgroups take round-robin.  Before the epilogue of a tile the first halo slice and weight tile of the NEXT tile are
-    //      already requested (into the loader registers, which the epilogue does not need): the 4-to-9-tap layers -- transposed-conv
-    //      phases, the 3x3 ResNet layers -- have 18 to 72 K-steps per tile, and the exposed load latency + set-up of every tile cost
-    //      them the equivalent of ~17 K-steps.
+    // XCD-aware tile order (block b runs on XCD b % 8): contiguous runs of tiles per XCD, n-tile fastest
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_x = p.Wg / TX, tiles_y = p.Hg / TY;
-    const int n_tiles = p.N * tiles_y * tiles_x * tiles_n;
-    int t, t_end;
-    const int t_step = gridDim.x >> 3;            // workgroups per XCD (the launcher makes the grid a multiple of 8)
+    int t;
     {
-        const int q = n_tiles >> 3, r = n_tiles & 7;
-        const int xcd = blockIdx.x & 7;
-        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        t = lo + (blockIdx.x >> 3);
-        t_end = lo + q + (xcd < r ? 1 : 0);
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    if (t >= t_end) return;
+    const int tile_n = t % tiles_n;
+    int tm = t / tiles_n;
+    const int tx0 = (tm % tiles_x) * TX; tm /= tiles_x;
+    const int ty0 = (tm % tiles_y) * TY;
+    const int n = tm / tiles_y;
+    const int n0 = tile_n * BN;
 
-    // ---- loaders.  halo: float4 idx = tid + 256 j -> quad idx % 8 of halo pixel perm(idx / 8).  The ds_write_b64 stores are
+    const float* gw = p.w;
+    const float* gscale = p.scale;
+    const float* gshift = p.shift;
+    if (p.n_groups > 1) {                       // groups are runs of samples
+        const int row = n * p.Hg * p.Wg;
+        int g = 0;
+        while (g + 1 < p.n_groups && p.grp[g + 1].row0 <= row) ++g;
+        gw = p.grp[g].w; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
+    }
+
+    if (tid < p.ntaps) s_tap[tid] = ((int)p.dy[tid] - dy0) * PITCH + ((int)p.dx[tid] - dx0) * REC;
+
+    // ---- halo loader: float4 idx = tid + 256 j -> quad idx % 8 of halo pixel perm(idx / 8).  The ds_write_b64 stores are
     //      served in contiguous 16-lane groups over 32 banks: two pixels per group, which collide unless they are 4 records
     //      apart (4 * 36 dwords = 16 mod 32) -- so consecutive octets of lanes take pixels hp and hp + 4.
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    unsigned h_pix[HALO_PASSES];               // pixel index into the input tensor, OOB outside the image / the halo   (per tile)
+    unsigned h_pix[HALO_PASSES];               // pixel index into the input tensor, OOB outside the image / the halo
     unsigned h_dst2[(HALO_PASSES + 1) / 2];    // LDS byte offsets, two 16-bit values per register (0xFFFF = not part of the halo)
 #pragma unroll
     for (int j = 0; j < (HALO_PASSES + 1) / 2; ++j) h_dst2[j] = 0xFFFFFFFFu;
@@ -106,48 +113,16 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
         const int t8 = idx >> 3, q = idx & 7;
         const int hp = (t8 & ~7) | ((t8 & 1) << 2) | ((t8 >> 1) & 3);
         const int hy = hp / HPX, hx = hp - hy * HPX;
+        const int iy = ty0 + dy0 + hy, ix = tx0 + dx0 + hx;
+        const bool ok = hp < halo_px && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        h_pix[j] = ok ? (unsigned)((n * p.Hin + iy) * p.Win + ix) : OOB;
         const unsigned dst = hp < halo_px ? (unsigned)(hy * PITCH + hx * REC + q * 8) : 0xFFFFu;
         h_dst2[j >> 1] = (j & 1) ? ((h_dst2[j >> 1] & 0x0000FFFFu) | (dst << 16)) : ((h_dst2[j >> 1] & 0xFFFF0000u) | dst);
     }
     const int hq4 = (tid & 7) * 4;             // channel offset of this thread's quad inside the slice
     const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].ptr, 0, p.seg_bytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.seg[1].ptr ? p.seg[1].ptr : p.seg[0].ptr), 0, p.seg_bytes[1], 0x00020000);
-    const int lrow = tid >> 3;
-    const int lcol = (tid & 7) * 4;
-    unsigned b_off[B_PASSES];                  // (per tile)
-    const float* gw = p.w;                     // (per tile: the object's panel in a grouped launch)
-
-    // coordinates of the tile the loaders are set up for
-    struct TileAt { int n, ty0, tx0, n0; const float* scale; const float* shift; };
-    auto setup_tile = [&](int tt) -> TileAt {
-        TileAt T;
-        const int tile_n = tt % tiles_n;
-        int tm = tt / tiles_n;
-        T.tx0 = (tm % tiles_x) * TX; tm /= tiles_x;
-        T.ty0 = (tm % tiles_y) * TY;
-        T.n = tm / tiles_y;
-        T.n0 = tile_n * BN;
-        gw = p.w; T.scale = p.scale; T.shift = p.shift;
-        if (p.n_groups > 1) {                       // groups are runs of samples
-            const int row = T.n * p.Hg * p.Wg;
-            int g = 0;
-            while (g + 1 < p.n_groups && p.grp[g + 1].row0 <= row) ++g;
-            gw = p.grp[g].w; T.scale = p.grp[g].scale; T.shift = p.grp[g].shift;
-        }
-#pragma unroll
-        for (int j = 0; j < HALO_PASSES; ++j) {
-            const int idx = tid + 256 * j;
-            const int t8 = idx >> 3;
-            const int hp = (t8 & ~7) | ((t8 & 1) << 2) | ((t8 >> 1) & 3);
-            const int hy = hp / HPX, hx = hp - hy * HPX;
-            const int iy = T.ty0 + dy0 + hy, ix = T.tx0 + dx0 + hx;
-            const bool ok = hp < halo_px && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            h_pix[j] = ok ? (unsigned)((T.n * p.Hin + iy) * p.Win + ix) : OOB;
-        }
-#pragma unroll
-        for (int j = 0; j < B_PASSES; ++j) b_off[j] = ((unsigned)(T.n0 + lrow + 32 * j) * (unsigned)p.K + (unsigned)lcol) * 4u;
-        return T;
-    };
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)gw, 0, p.w_bytes, 0x00020000);
 
     f32x4 rh[HALO_PASSES];
     auto hload = [&](int chunk) {
@@ -177,10 +152,14 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
     };
 
     // ---- weight loader: rows (tid >> 3) + 32 j of the n-tile, 16-byte segment (tid & 7)
+    const int lrow = tid >> 3;
+    const int lcol = (tid & 7) * 4;
+    unsigned b_off[B_PASSES];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) b_off[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)p.K + (unsigned)lcol) * 4u;
     f32x4 rb[B_PASSES];
     char* Bst = smem + HALO_BYTES;
     auto bload = [&](int tap, int chunk) {
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)gw, 0, p.w_bytes, 0x00020000);
         const int koff = (tap * p.chunks_per_tap + chunk) * (IGEMM_BK * 4);     // the panel's K order is (tap, slice)
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[j], koff, 0));
@@ -190,6 +169,14 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bst + b_dst + 32 * j * WREC) = rb[j];
     };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // A fragment of m-tile i: rows 32 i .. of this wave's 64 = patch rows wm*4 + 2i + (li >> 4), column li & 15
     const char* As = smem + (wm * 4 + (li >> 4)) * PITCH + (li & 15) * REC + lk * 16;
@@ -203,125 +190,112 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
         for (int hf = 0; hf < 2; ++hf) b_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
 
     const int n_chunks = p.chunks_per_tap;
+    hload(0);
+    bload(0, 0);
+    hstore();
+    bstore();
+    __syncthreads();
+    if (n_chunks > 1) hload(1);
+
+    int tap = 0, chunk = 0;
     const int total = n_chunks * p.ntaps;
+    for (int ks = 0; ks < total; ++ks) {
+        const int shift = __builtin_amdgcn_readfirstlane(s_tap[tap]);
+        int ntap = tap + 1, nchunk = chunk;
+        if (ntap == p.ntaps) { ntap = 0; ++nchunk; }
+        const bool more = ks + 1 < total;
+        if (more) bload(ntap, nchunk);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f16x8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(As + shift + i * a_tile + kb * 32);
+                al[i] = *reinterpret_cast<const f16x8*>(As + shift + i * a_tile + kb * 32 + 64);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * WREC + b_sw[kb][0]);
+                bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * WREC + b_sw[kb][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();                  // everyone is done reading the weight tile (and, at a slice end, the halo)
+        if (more) {
+            bstore();
+            if (nchunk != chunk) hstore();                       // next slice's halo (prefetched at the start of this one)
+            __syncthreads();
+            if (nchunk != chunk && nchunk + 1 < n_chunks) hload(nchunk + 1);
+        }
+        tap = ntap; chunk = nchunk;
+    }
+
+    // ---- epilogue (as igemm.hip): accumulators transposed through LDS, 64 GEMM rows per pass, so that a
+    //      thread owns 4 consecutive channels of one pixel.  C/D layout of the 32x32 MFMA:
+    //      col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     constexpr int CLD = BN + 4;
     constexpr int TPR = BN / 4;
     constexpr int RPP = 256 / TPR;
     float* Cs = reinterpret_cast<float*>(smem);
     const int c4 = (tid % TPR) * 4;
+    const int col = n0 + c4;
     const int r0 = tid / TPR;
-
-    TileAt nxt = setup_tile(t);
-    hload(0);
-    bload(0, 0);
-    __syncthreads();                           // tap table
-    for (;;) {
-        const TileAt cur = nxt;                // the loader registers hold this tile's first halo slice and weight tile
-        f32x16 acc[2][TN];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        hstore();
-        bstore();
-        __syncthreads();
-        if (n_chunks > 1) hload(1);
-
-        int tap = 0, chunk = 0;
-        for (int ks = 0; ks < total; ++ks) {
-            const int shift = __builtin_amdgcn_readfirstlane(s_tap[tap]);
-            int ntap = tap + 1, nchunk = chunk;
-            if (ntap == p.ntaps) { ntap = 0; ++nchunk; }
-            const bool more = ks + 1 < total;
-            if (more) bload(ntap, nchunk);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                f16x8 ah[2], al[2], bh[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    ah[i] = *reinterpret_cast<const f16x8*>(As + shift + i * a_tile + kb * 32);
-                    al[i] = *reinterpret_cast<const f16x8*>(As + shift + i * a_tile + kb * 32 + 64);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * WREC + b_sw[kb][0]);
-                    bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * WREC + b_sw[kb][1]);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
-            __syncthreads();                  // everyone is done reading the weight tile (and, at a slice end, the halo)
-            if (more) {
-                bstore();
-                if (nchunk != chunk) hstore();                       // next slice's halo (prefetched at the start of this one)
-                __syncthreads();
-                if (nchunk != chunk && nchunk + 1 < n_chunks) hload(nchunk + 1);
-            }
-            tap = ntap; chunk = nchunk;
-        }
-
-        // ---- the next tile's first loads fly under this tile's epilogue
-        t += t_step;
-        const bool has_next = t < t_end;
-        if (has_next) {
-            nxt = setup_tile(t);
-            hload(0);
-            bload(0, 0);
-        }
-
-        // ---- epilogue (as igemm.hip): accumulators transposed through LDS, 64 GEMM rows per pass, so that a
-        //      thread owns 4 consecutive channels of one pixel.  C/D layout of the 32x32 MFMA:
-        //      col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-        const int col = cur.n0 + c4;
-        const bool cok = col < p.Cout;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (cok) {
-            if (cur.scale) sc = *reinterpret_cast<const f32x4*>(cur.scale + col);
-            if (cur.shift) sh = *reinterpret_cast<const f32x4*>(cur.shift + col);
-        }
+    const bool cok = col < p.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+        if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + col);
+        if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
+    }
 #pragma unroll 1
-        for (int h = 0; h < WGM; ++h) {
-            if (wm == h) {
+    for (int h = 0; h < WGM; ++h) {
+        if (wm == h) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
-            }
-            __syncthreads();
-            if (cok) {
-                constexpr int NIT = 64 / RPP;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int row = h * 64 + r0 + it * RPP;
-                    const int gy = cur.ty0 + (row >> 4), gx = cur.tx0 + (row & 15);
-                    const size_t op = ((size_t)cur.n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + it * RPP) * CLD + c4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-                    if (p.act == ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (p.act == ACT_LEAKY) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
-                    }
-                    *reinterpret_cast<f32x4*>(p.out + op * p.out_cstride + p.out_coff + col) = v;
-                }
-            }
-            if (h + 1 < WGM || has_next) __syncthreads();      // the C tile is read out before it (or the next tile's image) is overwritten
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
         }
-        if (!has_next) break;
+        __syncthreads();
+        if (cok) {
+            constexpr int NIT = 64 / RPP;
+            int ops[NIT];
+            f32x4 rs[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = h * 64 + r0 + it * RPP;
+                const int gy = ty0 + (row >> 4), gx = tx0 + (row & 15);
+                ops[it] = (n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox;
+                rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.residual) {          // all residual loads before the first store
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) rs[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ops[it] * p.res_cstride + col);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + it * RPP) * CLD + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]) + rs[it][e];
+                if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                }
+                *reinterpret_cast<f32x4*>(p.out + (size_t)ops[it] * p.out_cstride + p.out_coff + col) = v;
+            }
+        }
+        if (h + 1 < WGM) __syncthreads();
     }
 }
 
@@ -336,7 +310,7 @@ static bool tall_patch() { static const bool on = getenv("P2P_HALO_TALL") == nul
 bool igemm_halo_supported(const IgemmParams& p)
 {
     constexpr int TY = 8;
-    if (p.prec != PREC_F16X3 || p.mode != EPI_NORMAL || p.ksplit > 1 || p.in_stride != 1 || p.ntaps < 4 || p.residual) return false;
+    if (p.prec != PREC_F16X3 || p.mode != EPI_NORMAL || p.ksplit > 1 || p.in_stride != 1 || p.ntaps < 4) return false;
     if (p.Hin != p.Hg || p.Win != p.Wg || p.Hg % TY || p.Wg % TX || p.Cout % 64) return false;
     int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
     for (int t = 0; t < p.ntaps; ++t) {
@@ -351,30 +325,15 @@ int igemm_halo_family(const IgemmParams& p)      // profile slot (p2p_mi355.h): 
     return p.Cout % 128 == 0 ? 3 : 4;
 }
 
-// resident workgroup slots of the chip for a kernel with `per_cu` workgroups per CU (persistent grids), a multiple of 8
-static int resident_slots(int per_cu)
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
-    return (cus * per_cu + 7) / 8 * 8;
-}
-
 hipError_t launch_igemm_halo(const IgemmParams& p, hipStream_t s)
 {
-    // P2P_HALO_PERSIST=0 (development switch): one tile per workgroup, as before
-    static const bool persist = getenv("P2P_HALO_PERSIST") == nullptr || atoi(getenv("P2P_HALO_PERSIST")) != 0;
     const int m_tiles = p.N * (p.Hg / 8) * (p.Wg / TX);
-    auto grid_for = [&](int tiles, int per_cu) { const int all = (tiles + 7) / 8 * 8; return persist ? std::min(all, resident_slots(per_cu)) : all; };
     if (p.Cout % 128 == 0) {
-        hipLaunchKernelGGL((igemm_halo_kernel<2, 2>), dim3(grid_for(m_tiles * (p.Cout / 128), 3)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_halo_kernel<2, 2>), dim3(m_tiles * (p.Cout / 128)), dim3(256), 0, s, p);
     } else if (tall_patch() && p.Hg % 16 == 0) {
-        hipLaunchKernelGGL((igemm_halo_kernel<4, 2>), dim3(grid_for(m_tiles / 2 * (p.Cout / 64), 2)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_halo_kernel<4, 2>), dim3(m_tiles / 2 * (p.Cout / 64)), dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((igemm_halo_kernel<2, 1>), dim3(grid_for(m_tiles * (p.Cout / 64), 3)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_halo_kernel<2, 1>), dim3(m_tiles * (p.Cout / 64)), dim3(256), 0, s, p);
     }
     return hipGetLastError();
 }
