@@ -130,6 +130,20 @@ def test_anti_aliased_resizes_sweep_with_border_clipping(rig):
     assert _run_injected(rig, sc, anti_aliasing=True) >= 12
 
 
+@pytest.mark.parametrize("aa", [False, True])
+def test_large_frames_large_crops(rig, aa):
+    """1920x1080 frames, boxes of 300-420 px (crop sides 450-630 px, 70 000 correspondences per candidate: far beyond the 128-px
+    configuration the bench runs) mixed with a 40-px box in the same batch: the correspondence storage, the RANSAC scoring and
+    refit loops (no per-thread inlier mask above 16 384 points), the resize gathers and the anti-aliasing filter (radius up to 8)
+    at sizes the reference meets on real images -- against the oracle, bit for bit as everywhere else."""
+    a = synth.make_scene(4, seed=91, bbox_side=(300, 420), H=1080, W=1920, n_images=2)
+    b = synth.make_scene(2, seed=92, bbox_side=(40, 48), H=1080, W=1920, n_images=2)
+    sc = {"images": np.concatenate([a["images"], b["images"]]), "obj_param": a["obj_param"],
+          "dets": a["dets"] + [(d[0] + 2, d[1], d[2], d[3]) for d in b["dets"]],
+          "gt": a["gt"] + b["gt"], "inject1": np.concatenate([a["inject1"], b["inject1"]]), "inject2": np.concatenate([a["inject2"], b["inject2"]])}
+    assert _run_injected(rig, sc, anti_aliasing=aa) >= 5
+
+
 def test_anti_aliasing_off_and_on_differ_and_identity_at_128(rig):
     import torch
     from pix2pose_amd.runtime import est_pose_batch
