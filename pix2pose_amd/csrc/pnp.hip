@@ -769,15 +769,27 @@ constexpr int SCORE_CHUNK = 8;   // hypotheses whose inlier counts are taken in 
 // file, i.e. a resident wave blocks its SIMD for everything else, and a quarter of the waves blocks a quarter of the SIMD time --,
 // then [16, 64) and [64, iterations) only for the problems whose scoring ran past what it had (one problem per wave).
 constexpr int HYP_ROUND0 = 16, HYP_ROUND1 = 64;
-__global__ __launch_bounds__(64, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
+// A workgroup is FOUR such waves (one per SIMD of a CU), each with its own problems: a 256-thread workgroup cannot be placed on a CU
+// one of whose SIMDs is held by a 512-register wave, so single-wave workgroups -- which the dispatcher spreads over the chip --
+// took a whole CU each away from the generator kernels of the next batch (192 of 256 CUs for the first round of a 256-detection
+// batch: the ResNet front running under it was 2.7x slower); packed four to a CU they take a quarter as many.
+__global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
                                                             const PnpFit* __restrict__ fits, int n_problems, int iterations, int min_points,
-                                                            int h_begin, int h_stop, int ppb)
+                                                            int h_begin, int h_stop, int ppb, int* __restrict__ act, int round)
 {
-    __shared__ int s_idx[MAX_ITERS][5];          // ppb == 4: rows 16 sub + it (it < 16); ppb == 1: row it
-    const int tid = threadIdx.x;
+    __shared__ int s_idx_wg[4][MAX_ITERS][5];    // per wave; ppb == 4: rows 16 sub + it (it < 16); ppb == 1: row it
+    int (*s_idx)[5] = s_idx_wg[threadIdx.x >> 6];
+    const int tid = threadIdx.x & 63;
     const int lanes = 64 / ppb;                  // lanes per problem
     const int sub = tid / lanes, lane_in = tid - sub * lanes;
-    const int prob = blockIdx.x * ppb + sub;
+    // Round 0 takes the problems in order (and clears the lists of the later rounds); rounds 1 and 2 take theirs from the list the
+    // scoring pass of the round before appended to (act: [count1, count2, list1[n], list2[n]]), so that the few problems still
+    // running are packed four to a workgroup: the waves of the other workgroups leave at once.
+    int prob = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ppb + sub;
+    if (round == 0) {
+        if (blockIdx.x == 0 && threadIdx.x < 2) act[threadIdx.x] = 0;
+    } else
+        prob = prob < act[round - 1] ? act[2 + (round - 1) * n_problems + prob] : n_problems;
     bool active = prob < n_problems && (h_begin == 0 || fits[prob].state == 2);
     PnpProblem pb;
     pb.n = 0; pb.cap = 0; pb.pts = nullptr; pb.mask = nullptr;
@@ -849,7 +861,8 @@ __global__ __launch_bounds__(64, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(c
 // points; Gram sums).  One workgroup (256 threads) per problem.
 __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
                                                               PnpResult* __restrict__ results, PnpFit* __restrict__ fits, int iterations,
-                                                              double reproj_err, double confidence, int min_points, int n_solved, int first)
+                                                              double reproj_err, double confidence, int min_points, int n_solved, int first,
+                                                              int* __restrict__ act, int round, int n_problems)
 {
     PnpFit& fit = fits[blockIdx.x];
     if (!first && fit.state != 2) return;        // later passes: only problems whose scoring ran out of hypotheses
@@ -905,7 +918,10 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
         for (int it0 = 0;; it0 += SCORE_CHUNK) {
             if (it0 >= s_ctl[0]) break;          // uniform: s_ctl[0] is read after the barrier below
             if (it0 >= n_avail) {                // (n_avail < n_hyp only) the bound still asks for more: solve the next round, score again from 0
-                if (tid == 0) fit.state = 2;
+                if (tid == 0) {
+                    fit.state = 2;
+                    if (round < 2) act[2 + round * n_problems + atomicAdd(&act[round], 1)] = blockIdx.x;      // work list of the next hypothesis round
+                }
                 return;
             }
             const int hc = min(SCORE_CHUNK, n_avail - it0);
@@ -1105,9 +1121,9 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
 
 // Kernel 3 of 4 -- the refit solve: one LANE per problem (register-resident 12x12 SVD, betas,
 // Gauss-Newton, absolute orientation for the three beta cases).
-__global__ __launch_bounds__(64, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
+__global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
 {
-    const int pi = blockIdx.x * 64 + threadIdx.x;
+    const int pi = blockIdx.x * 256 + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
     if (pi >= n_problems) return;
     PnpFit& fit = fits[pi];
     if (fit.state != 0) return;
@@ -1235,7 +1251,7 @@ __global__ __launch_bounds__(256) void pnp_fit_select_kernel(const PnpProblem* _
 
 size_t pnp_workspace_bytes(int n_problems)
 {
-    return (size_t)n_problems * (pnp::MAX_ITERS * 12 * sizeof(double) + sizeof(pnp::PnpFit));
+    return (size_t)n_problems * (pnp::MAX_ITERS * 12 * sizeof(double) + sizeof(pnp::PnpFit)) + (2 + 2 * (size_t)n_problems) * sizeof(int) + 16;
 }
 
 hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_problems, int iterations,
@@ -1243,6 +1259,7 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
 {
     if (n_problems <= 0) return hipSuccess;
     pnp::PnpFit* fits = reinterpret_cast<pnp::PnpFit*>(workspace + (size_t)n_problems * pnp::MAX_ITERS * 12);
+    int* act = reinterpret_cast<int*>(((uintptr_t)(fits + n_problems) + 15) & ~(uintptr_t)15);      // work lists of hypothesis rounds 1 and 2
     hipError_t e;
     // round 0: hypotheses [0, 16), four problems per wave; later rounds only for problems whose scoring ran past what it had --
     // everything else leaves those launches at once
@@ -1250,16 +1267,16 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
     int h_begin = 0;
     for (int r = 0; r < 3; ++r) {
         const int ppb = r == 0 ? 4 : 1;
-        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems + ppb - 1) / ppb), dim3(64), 0, s, probs, workspace, fits, n_problems, iterations,
-                           min_points, h_begin, stops[r], ppb);
+        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(((n_problems + ppb - 1) / ppb + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
+                           min_points, h_begin, stops[r], ppb, act, r);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
-                           reproj_err, confidence, min_points, stops[r], r == 0 ? 1 : 0);
+                           reproj_err, confidence, min_points, stops[r], r == 0 ? 1 : 0, act, r, n_problems);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         h_begin = stops[r];
         if (iterations <= h_begin) break;
     }
-    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, s, probs, fits, n_problems);
+    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);
     return hipGetLastError();
