@@ -87,12 +87,24 @@ _lib = None
 
 
 def _stale_reason(path):
-    """Why the library at `path` must not be used with this tree (None = fine).  Checked through a private handle so a
-    refused library is never left typed in `_lib`."""
+    """Why the library at `path` must not be used with this tree (None = fine).  Checked through a private handle that is
+    closed again: a refused library is never left typed in `_lib`, and after a rebuild the loader maps the NEW file instead of
+    handing back the image it still had open under the same path."""
     try:
         L = C.CDLL(path)
     except OSError as e:
         return "cannot load %s: %s" % (path, e)
+    try:
+        return _stale_reason_of(L)
+    finally:
+        try:
+            import _ctypes
+            _ctypes.dlclose(L._handle)
+        except Exception:  # pragma: no cover
+            pass
+
+
+def _stale_reason_of(L):
     L.p2p_abi_version.restype = C.c_int
     if L.p2p_abi_version() != ABI_VERSION:
         return "ABI version %d, binding expects %d" % (L.p2p_abi_version(), ABI_VERSION)

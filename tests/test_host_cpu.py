@@ -177,6 +177,22 @@ def test_binding_refuses_a_stale_library(monkeypatch):
     assert "sizeof(Fat)" in _lib._stale_reason(_lib.LIB_PATH)
 
 
+def test_stale_check_sees_a_rebuilt_library(tmp_path):
+    """lib() checks a library, rebuilds it when it is stale and checks again UNDER THE SAME PATH: the check must close its
+    handle, else the loader hands back the image it already mapped and the fresh build is reported stale ("... after a
+    rebuild": seen on a GPU box that received a library built from an edited tree)."""
+    import subprocess
+    from pix2pose_amd import _lib
+    path = str(tmp_path / "libprobe.so")
+    for version in (111, 222):
+        src = tmp_path / ("v%d.c" % version)
+        src.write_text("int p2p_abi_version(void) { return %d; }\n" % version)
+        tmp = str(tmp_path / ("v%d.so" % version))
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", tmp, str(src)])
+        os.replace(tmp, path)
+        assert "ABI version %d" % version in _lib._stale_reason(path)
+
+
 def test_bench_self_launch_command(monkeypatch):
     """`python bench.py --gpus N` outside a launcher re-executes itself under torch.distributed.run on 127.0.0.1."""
     import importlib
