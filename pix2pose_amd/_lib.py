@@ -86,10 +86,35 @@ class KernelStats(C.Structure):
 _lib = None
 
 
+_torch_hip_loaded = False
+
+
+def _preload_torch_hip():
+    """One process, one HIP runtime.  A PyTorch-ROCm wheel carries its own libamdhip64.so; the library links the system one under
+    the same soname.  Whichever is mapped first serves both, and torch cannot see a device through the system runtime when the
+    library came first ("No HIP GPUs are available").  So, when torch is installed, its runtime is mapped before the library is
+    -- the order in which the caller imports things no longer matters.  (Found without importing torch: that costs seconds.)"""
+    global _torch_hip_loaded
+    if _torch_hip_loaded:
+        return
+    _torch_hip_loaded = True
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        fn = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(fn):
+            C.CDLL(fn, mode=C.RTLD_GLOBAL)
+    except Exception:  # pragma: no cover -- best effort; torch-first import orders never needed it
+        pass
+
+
 def _stale_reason(path):
     """Why the library at `path` must not be used with this tree (None = fine).  Checked through a private handle that is
     closed again: a refused library is never left typed in `_lib`, and after a rebuild the loader maps the NEW file instead of
     handing back the image it still had open under the same path."""
+    _preload_torch_hip()
     try:
         L = C.CDLL(path)
     except OSError as e:
@@ -143,6 +168,7 @@ def lib():
         reason = _stale_reason(LIB_PATH)
         if reason is not None:
             raise P2PError("%s: %s after a rebuild" % (LIB_PATH, reason))
+    _preload_torch_hip()
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:

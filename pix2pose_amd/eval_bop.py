@@ -19,7 +19,16 @@ Pre-dumped detections file (JSON)::
      "weights": {"1": "path/to/obj01.npz" | "synthetic:resnet50:1", ...},
      "targets": [{"scene_id":..,"im_id":..,"obj_id":..,"inst_count":..}, ...],      # test_targets_bop19.json
      "images": [{"scene_id":..,"im_id":..,"rgb": "frame.npy|.png", "cam_K": [9 floats],
-                 "rois": [[v1,u1,v2,u2], ...], "obj_ids": [...], "scores": [...], "masks": "masks.npy" (optional, [H,W,n])}]}
+                 "rois": [[v1,u1,v2,u2], ...], "obj_ids": [...], "scores": [...], "masks": "masks.npy" (optional, [H,W,n])
+                 | "segmentations": [COCO run-length mask per detection]}]}
+
+``bop_dataset.build_dump`` writes this dict from a BOP-format dataset directory (cfg ``dataset_dir``, ``test_target``,
+``norm_factor_fn``, ``target_obj`` as in the reference) and a COCO-style detection list; the CLI takes either file.
+
+Several GPUs: under ``torch.distributed.run`` (or with RANK / WORLD_SIZE / LOCAL_RANK set) every rank takes every
+WORLD_SIZE-th image of the target list, runs the whole pipeline on its own GPU and rank 0 gathers the result rows (fixed-size
+records, one all-gather) and writes the CSV in target-list order -- images are independent in the reference
+(tools/5_evaluation_bop_basic.py:229-352), so there is no other exchange.
 """
 from __future__ import annotations
 
@@ -148,9 +157,13 @@ def _load_frame(path):
 
 # ---------------------------------------------------------------------------------- driver
 def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".", batch_images: int = 32,
-        detect_type: str = "rcnn", est_pose_kwargs=None):
+        detect_type: str = "rcnn", est_pose_kwargs=None, shard=None, write_csv: bool = True, inject=None):
     """Evaluate a pre-dumped detection stream.  Returns the result rows (also written as CSV when
-    cfg['path_to_output'] is set)."""
+    cfg['path_to_output'] is set).  shard = (rank, world): only every world-th image of the target list, starting at rank;
+    every row carries "_order" = (position of its image in the full target list, rank inside the image) so that the shards'
+    rows merge back into the single-process order.  inject (tests): {"key": [N, 2] (image position in the target list, detection
+    index in the image), "inject1": [N,128,128,4], "inject2": [N,K,128,128,4]} -- decoder maps that replace the generator output
+    of the listed detections, the way bench.py and the parity tests drive the pipeline with random-weight networks."""
     from . import runtime, weights as W
     backbone = cfg.get("backbone", "paper")                                   # :202-205
     model_ids = list(dump["model_ids"])
@@ -167,29 +180,36 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
         specs.append(runtime.ObjectSpec(gen, model_params_to_obj_param(dump["norm_factor"][str(mid)]), th_o[m], th_i))
     by_image = {(im["scene_id"], im["im_id"]): im for im in dump["images"]}
     rows = []
-    tlist = group_targets(dump["targets"])
+    tlist = [t + [gi] for gi, t in enumerate(group_targets(dump["targets"]))]
+    if shard is not None:
+        tlist = tlist[shard[0]::shard[1]]
 
     def prepare(chunk):
         frames, dets, det_masks, owners = [], [], [], []
-        for ti, (scene_id, im_id, obj_id_targets, inst_counts) in enumerate(chunk):
+        for ti, (scene_id, im_id, obj_id_targets, inst_counts, _gi) in enumerate(chunk):
             im = by_image.get((scene_id, im_id))
             if im is None:
                 continue
             frame = _load_frame(os.path.join(base_dir, im["rgb"]))
             masks = np.load(os.path.join(base_dir, im["masks"])) if im.get("masks") else None
+            segs = im.get("segmentations") if masks is None else None
             fi = len(frames)
             frames.append(frame)
             for r_id in select_detections(im["rois"], im["obj_ids"], obj_id_targets, inst_counts, cand_factor):
                 dets.append((fi, model_ids.index(im["obj_ids"][r_id]), [int(v) for v in im["rois"][r_id]], np.array(im["cam_K"], float).reshape(3, 3)))
                 owners.append((ti, r_id))
                 if score_type == 2 and detect_type == "rcnn":
-                    if masks is None:
+                    if masks is not None:
+                        det_masks.append(masks[:, :, r_id])
+                    elif segs is not None and segs[r_id] is not None:
+                        from .bop_dataset import rle_decode
+                        det_masks.append(rle_decode(segs[r_id]))
+                    else:
                         raise ValueError("score_type 2 needs detector masks for scene %s image %s" % (scene_id, im_id))
-                    det_masks.append(masks[:, :, r_id])
         return frames, dets, det_masks, owners
 
     def finish(job):
-        chunk, owners, pending, t1 = job
+        chunk, owners, pending, t1, _held = job          # _held: injected maps stay alive until the batch is collected
         poses = pending.collect()
         ex = pending.extras
         dt = time.time() - t1
@@ -198,21 +218,25 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
             p = poses[k]
             if p.status != 0:                                                 # frac_inlier == -1 (:305-306)
                 continue
-            scene_id, im_id, _, _ = chunk[ti]
+            scene_id, im_id = chunk[ti][:2]
             im = by_image[(scene_id, im_id)]
             ms = (int(ex["mask_stats"][k, 0]), int(ex["mask_stats"][k, 1])) if "mask_stats" in ex else None
             sc = detection_score(im["scores"][r_id], p.frac_inlier, ms, score_type, detect_type)
             per_image.setdefault(ti, []).append({"obj_id": im["obj_ids"][r_id], "score": sc,
                                                  "R": np.array(p.R).reshape(3, 3), "t": np.array(p.t)})
-        for ti, (scene_id, im_id, obj_id_targets, inst_counts) in enumerate(chunk):
+        for ti, (scene_id, im_id, obj_id_targets, inst_counts, gi) in enumerate(chunk):
             n_here = sum(1 for o in owners if o[0] == ti)
-            rows.extend(rank_image_results(per_image.get(ti, []), obj_id_targets, inst_counts, task_type, scene_id, im_id,
-                                           dt * n_here / max(len(owners), 1)))   # batch time amortised over its detections
+            new = rank_image_results(per_image.get(ti, []), obj_id_targets, inst_counts, task_type, scene_id, im_id,
+                                     dt * n_here / max(len(owners), 1))          # batch time amortised over its detections
+            for k, r in enumerate(new):
+                r["_order"] = (gi, k)
+            rows.extend(new)
 
     # detection stream: chunk i+1 is read from disk and enqueued (p2p_est_pose_submit) while chunk i is on the GPU;
     # the score_type-2 mask sums come back through the same asynchronous call
     in_flight = []
     n_submitted = 0
+    inject_row = {(int(a), int(b)): i for i, (a, b) in enumerate(inject["key"])} if inject is not None else None
     for b0 in range(0, len(tlist), batch_images):
         chunk = tlist[b0:b0 + batch_images]
         t1 = time.time()
@@ -223,30 +247,99 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
         # first detection in stream order, number of detections) and returns them per chunk
         extra = est_pose_kwargs(n_submitted, len(dets)) if callable(est_pose_kwargs) else (est_pose_kwargs or {})
         n_submitted += len(dets)
+        held = None
+        if inject is not None:
+            import torch
+            idx = [inject_row[(chunk[ti][4], r_id)] for ti, r_id in owners]
+            held = (torch.from_numpy(np.ascontiguousarray(inject["inject1"][idx])).cuda(device),
+                    torch.from_numpy(np.ascontiguousarray(inject["inject2"][idx])).cuda(device))
+            torch.cuda.synchronize(device)
+            extra = dict(extra, inject1=held[0].data_ptr(), inject2=held[1].data_ptr(), inject_slots=int(held[1].shape[1]))
         pending = runtime.est_pose_submit(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
                                           anti_aliasing=bool(cfg.get("resize_anti_aliasing", False)),     # scikit-image >= 0.15 semantics
                                           **extra)
-        in_flight.append((chunk, owners, pending, t1))
+        in_flight.append((chunk, owners, pending, t1, held))
         if len(in_flight) == 2:
             finish(in_flight.pop(0))
     while in_flight:
         finish(in_flight.pop(0))
     out_dir = cfg.get("path_to_output")
-    if out_dir:
+    if out_dir and write_csv:
         os.makedirs(out_dir, exist_ok=True)
         save_bop_results(os.path.join(out_dir, output_name(dataset)), rows)
     return rows
 
 
+# ---------------------------------------------------------------------------------- several GPUs
+ROW_REC = 20     # floats per gathered row: order key, scene_id, im_id, obj_id, score, R[9], t[3], time, pad (= parallel.REC)
+
+
+def rows_to_records(rows) -> np.ndarray:
+    out = np.zeros((len(rows), ROW_REC), np.float64)
+    for i, r in enumerate(rows):
+        gi, k = r["_order"]
+        out[i, 0] = gi * 4096 + k                     # < 2^53: exact in float64
+        out[i, 1:5] = r["scene_id"], r["im_id"], r["obj_id"], r["score"]
+        out[i, 5:14] = np.asarray(r["R"], np.float64).reshape(-1)
+        out[i, 14:17] = np.asarray(r["t"], np.float64).reshape(-1)
+        out[i, 17] = r["time"]
+    return out
+
+
+def records_to_rows(rec: np.ndarray):
+    return [{"scene_id": int(r[1]), "im_id": int(r[2]), "obj_id": int(r[3]), "score": float(r[4]), "R": r[5:14].reshape(3, 3).copy(),
+             "t": r[14:17].copy(), "time": float(r[17]), "_order": (int(r[0]) // 4096, int(r[0]) % 4096)} for r in rec]
+
+
+def run_distributed(cfg: dict, dataset: str, dump: dict, base_dir: str = ".", backend: str = None, same_device: bool = False, **kw):
+    """One process per GPU (torch.distributed.run): shard the images, gather the rows on every rank (one all-gather over RCCL
+    when the backend is "nccl"), rank 0 writes the CSV.  Returns the merged rows."""
+    import torch
+    import torch.distributed as dist
+    from . import parallel
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = 0 if same_device else int(os.environ.get("LOCAL_RANK", rank))
+    backend = backend or os.environ.get("P2P_EVAL_BACKEND", "nccl")
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    rows = run(cfg, dataset, dump, device=local, base_dir=base_dir, shard=(rank, world), write_csv=False, **kw)
+    assert parallel.REC == ROW_REC
+    rec = parallel.gather_poses(rows_to_records(rows), device=torch.device("cuda", local) if backend == "nccl" else None)
+    merged = records_to_rows(rec)
+    out_dir = cfg.get("path_to_output")
+    if out_dir and rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        save_bop_results(os.path.join(out_dir, output_name(dataset)), merged)
+    dist.barrier()
+    return merged
+
+
 def main(argv):
     if len(argv) < 4:
-        print("usage: python -m pix2pose_amd.eval_bop <gpu_id> <cfg.json> <dataset> [detections.json]")
+        print("usage: python -m pix2pose_amd.eval_bop <gpu_id> <cfg.json> <dataset> [detections.json]\n"
+              "  detections.json: the harness's own dump (a dict, see the module docstring) or a COCO-style detection list for the\n"
+              "  BOP directory cfg['dataset_dir'] (bop_dataset.build_dump).  Under torch.distributed.run the images are sharded\n"
+              "  over the ranks (gpu_id is ignored: rank i uses GPU LOCAL_RANK) and rank 0 writes the CSV.")
         return 2
     device, cfg_fn, dataset = int(argv[1]), argv[2], argv[3]
     cfg = json.load(open(cfg_fn))
     det_fn = argv[4] if len(argv) > 4 else os.path.join(cfg["dataset_dir"], dataset, "detections_mi355.json")
     dump = json.load(open(det_fn))
-    rows = run(cfg, dataset, dump, device=device, base_dir=os.path.dirname(os.path.abspath(det_fn)))
+    base_dir = os.path.dirname(os.path.abspath(det_fn))
+    if isinstance(dump, list):                        # COCO-style detections for a BOP directory
+        from . import bop_dataset
+        dump = bop_dataset.build_dump(cfg, dataset, dump)
+    inject = None
+    if os.environ.get("P2P_EVAL_INJECT"):             # test hook, see run()
+        with np.load(os.environ["P2P_EVAL_INJECT"]) as z:
+            inject = {k: z[k] for k in ("key", "inject1", "inject2")}
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rows = run_distributed(cfg, dataset, dump, base_dir=base_dir, same_device=bool(os.environ.get("P2P_EVAL_SAME_DEVICE")), inject=inject)
+        if int(os.environ["RANK"]) != 0:
+            return 0
+    else:
+        rows = run(cfg, dataset, dump, device=device, base_dir=base_dir, inject=inject)
     print("Saving %d results to %s" % (len(rows), os.path.join(cfg.get("path_to_output", "."), output_name(dataset))))
     return 0
 

@@ -230,7 +230,8 @@ def save_weights(path: str, backbone: str, w: dict) -> None:
 
 
 def load_weights(weight_fn: str, backbone: str) -> dict:
-    """``weight_fn`` is a ``.npz`` artefact or ``synthetic:<backbone>:<seed>``."""
+    """``weight_fn`` is a ``.npz`` artefact, ``synthetic:<backbone>:<seed>`` / ``trained-like:<backbone>:<seed>``, or the
+    reference's Keras ``.hdf5`` / ``.h5`` inference weights (read through convert_keras; needs h5py)."""
     if weight_fn.startswith("trained-like:"):
         _, bb, seed = weight_fn.split(":")
         if bb != backbone:
@@ -243,6 +244,9 @@ def load_weights(weight_fn: str, backbone: str) -> dict:
             raise ValueError("weight spec %r does not match backbone %r" % (weight_fn, backbone))
         seed = int(parts[2]) if len(parts) > 2 else 1
         return synthetic_weights(backbone, seed)
+    if weight_fn.endswith((".hdf5", ".h5")):
+        from . import convert_keras
+        return convert_keras.convert_named(convert_keras.read_hdf5(weight_fn), backbone)
     with np.load(weight_fn, allow_pickle=False) as z:
         bb = str(z["__backbone__"]) if "__backbone__" in z.files else backbone
         if bb != backbone:

@@ -2,6 +2,7 @@
 one batch, 1 and 4 outlier thresholds (cfg_tless_paper / ros_config), device-pointer predict,
 argument validation."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -81,3 +82,20 @@ def test_predict_device_pointers_and_argument_validation(rig):
     assert L.p2p_model_create(ctx.handle, t, 1, 0, C.byref(h)) == -3                                          # P2P_ERR_WEIGHTS
     assert b"conv1_1.kernel" in L.p2p_last_error()
     assert L.p2p_model_create(ctx.handle, t, 1, 5, C.byref(h)) == -1                                          # unknown backbone
+
+
+@pytest.mark.gpu
+def test_library_first_then_torch_in_one_process():
+    """The library links the system HIP runtime, a PyTorch-ROCm wheel brings its own under the same soname: whichever is mapped
+    first serves both, and torch sees no device through the system one.  The binding maps torch's runtime first when torch is
+    installed, so a caller may create a context BEFORE touching torch.cuda (the harness does, eval_bop.run)."""
+    import subprocess
+    import sys
+    code = ("from pix2pose_amd import runtime\n"
+            "ctx = runtime.Context(0, max_batch=4)\n"
+            "import torch\n"
+            "x = torch.arange(8, dtype=torch.float32).cuda()\n"
+            "print('sum', float((x * 2).sum()))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "sum 56.0" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
