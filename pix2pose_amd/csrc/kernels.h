@@ -86,6 +86,11 @@ hipError_t launch_igemm_halo(const IgemmParams& p, hipStream_t s);
 int igemm_halo8_mode(const IgemmParams& p);
 hipError_t launch_igemm_halo8(const IgemmParams& p, hipStream_t s);
 
+// Halo-tiled variant for Conv2D 5x5 stride 2 'SAME' on 16x16 and larger output grids (igemm_halo_s2.hip; parity planes like
+// igemm_halo8.hip, 8x16 patches like igemm_halo.hip): the "paper" encoder's conv2 / conv3.
+bool igemm_halo_s2_supported(const IgemmParams& p);
+hipError_t launch_igemm_halo_s2(const IgemmParams& p, hipStream_t s);
+
 // Halo-tiled kernel for the merged output heads (heads.hip); takes the same parameter block as the
 // generic kernel when heads_halo_supported() says so (PREC_F16X3, 64-wide grid, 128 input channels).
 bool heads_halo_supported(const IgemmParams& p);

@@ -569,9 +569,11 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     const bool halo = specialised_kernels() && heads_halo_supported(p);            // the output heads have their own kernel (heads.hip)
     const bool halo_conv = !halo && specialised_kernels() && igemm_halo_supported(p);   // stride-1 multi-tap layers (igemm_halo.hip)
     const bool halo8 = !halo && !halo_conv && specialised_kernels() && igemm_halo8_mode(p) != 0;   // 8x8-grid layers (igemm_halo8.hip)
-    auto launch = [&]() { return halo ? launch_heads_halo(p, st) : halo_conv ? launch_igemm_halo(p, st) : halo8 ? launch_igemm_halo8(p, st) : launch_igemm(p, cfg, st); };
+    const bool halo_s2 = !halo && !halo_conv && !halo8 && specialised_kernels() && igemm_halo_s2_supported(p);   // 5x5 stride 2 on larger grids (igemm_halo_s2.hip)
+    auto launch = [&]() { return halo ? launch_heads_halo(p, st) : halo_conv ? launch_igemm_halo(p, st) : halo8 ? launch_igemm_halo8(p, st) :
+                                 halo_s2 ? launch_igemm_halo_s2(p, st) : launch_igemm(p, cfg, st); };
     if (X.profiling) {
-        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : halo8 ? 6 : cfg,
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : halo8 ? 6 : halo_s2 ? 7 : cfg,
                           2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
         if (!ev.a || !ev.b) return P2P_ERR_HIP;
         HIP_TRY(hipEventRecord(ev.a, st));
