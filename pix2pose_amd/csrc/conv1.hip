@@ -22,20 +22,26 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int C1_KH = 7, C1_PAD = 3, C1_COUT = 64;
+// The same kernel serves the first layer of the "paper" encoder (conv1_1 || conv1_2: Conv2D 5x5/2 'SAME', 3 -> 64 + 64, BatchNorm,
+// LeakyReLU; reference ae_model.py:74-78): KH = 5 kernel rows of 5 taps (20 + 12 zero-weighted halves per K block), TF 'SAME' at
+// stride 2 pads ONE pixel before, and the 128 output channels are two workgroup columns of 64 (blockIdx.y), each with its own
+// half of the weight panel in LDS.
+constexpr int C1_COUT = 64;                                      // output channels per workgroup
 constexpr int C1_HIN = 128, C1_HOUT = 64;
 constexpr int C1_ROWS_OUT = 2;                                   // output rows per tile
-constexpr int C1_ROWS_IN = (C1_ROWS_OUT - 1) * 2 + C1_KH;        // 9 input rows
-constexpr int C1_ROW_PX = C1_HIN + 2 * C1_PAD;                   // 134 staged pixels per row (pixel -3 first)
+constexpr int C1_ROW_PX = C1_HIN + 6;                            // 134 staged pixels per row (pixel -PAD first; the last run ends at 133)
 constexpr int C1_ROW_BYTES = C1_ROW_PX * 8;                      // 4 halves per pixel; 1072 B, 16-B aligned
-constexpr int C1_PLANE = C1_ROWS_IN * C1_ROW_BYTES;              // hi plane, then lo plane
-constexpr int C1_W_BYTES = C1_KH * 2 * 4 * C1_COUT * 16;         // [kh][hi,lo][k-group][cout][8 halves] = 57344
 constexpr int C1_TILES_PER_WG = 8;                               // 16 output rows per workgroup
-constexpr int C1_PASSES = (C1_ROWS_IN * C1_HIN + 255) / 256;     // pixel loads per thread per tile (5)
 
+template <int C1_KH, int C1_PAD, int NCO>
 __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __restrict__ x, int N, const Conv1Groups G,
                                                              int act, float alpha, float* __restrict__ out)
 {
+    constexpr int C1_ROWS_IN = (C1_ROWS_OUT - 1) * 2 + C1_KH;        // 9 / 7 input rows
+    constexpr int C1_PLANE = C1_ROWS_IN * C1_ROW_BYTES;              // hi plane, then lo plane
+    constexpr int C1_W_BYTES = C1_KH * 2 * 4 * C1_COUT * 16;         // [kh][hi,lo][k-group][cout][8 halves] = 57344 / 40960
+    constexpr int C1_PASSES = (C1_ROWS_IN * C1_HIN + 255) / 256;     // pixel loads per thread per tile (5 / 4)
+    const int co0 = blockIdx.y * C1_COUT;                            // this workgroup's output channels
     __shared__ __attribute__((aligned(16))) char smem[C1_W_BYTES + 2 * C1_PLANE];
     char* ws = smem;
     char* xs = smem + C1_W_BYTES;
@@ -46,9 +52,9 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
     const int oy_base = (blockIdx.x - n * wgs_per_img) * C1_ROWS_OUT * C1_TILES_PER_WG;
     int g = 0;                                  // object of this sample (mixed batches: groups are runs of samples)
     while (g + 1 < G.n_groups && G.start[g + 1] <= n) ++g;
-    const float* __restrict__ w_alt = G.w[g];
-    const float* __restrict__ scale = G.scale[g];
-    const float* __restrict__ shift = G.shift[g];
+    const float* __restrict__ w_alt = G.w[g] + (size_t)blockIdx.y * (C1_W_BYTES / 4);
+    const float* __restrict__ scale = G.scale[g] + co0;
+    const float* __restrict__ shift = G.shift[g] + co0;
 
     // weights -> LDS (linear copy), zero the staging planes once (the padding pixels stay zero)
     for (int i = tid; i < C1_W_BYTES / 16; i += 256)
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
         // lane: channels 16 q + 4 lg .. +3 of output pixel (oy0 + orow, ox0 + 16 m + li)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            float* op = out + (((size_t)n * C1_HOUT + oy0 + orow) * C1_HOUT + ox0 + 16 * m + li) * C1_COUT + lg * 4;
+            float* op = out + (((size_t)n * C1_HOUT + oy0 + orow) * C1_HOUT + ox0 + 16 * m + li) * NCO + co0 + lg * 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 16 + lg * 4);
@@ -153,22 +159,26 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
 
 }  // namespace
 
-size_t conv1_f16x3_panel_floats() { return C1_W_BYTES / 4; }
+size_t conv1_f16x3_panel_floats(int KH, int Cout) { return (size_t)(Cout / C1_COUT) * KH * 2 * 4 * C1_COUT * 16 / 4; }
 
-// k within a kernel row: kk = kw * 4 + c (c < 3), group = kk / 8; layout [kh][hi,lo][group][cout][8 halves]
-size_t conv1_f16x3_panel_index(int kh, int plane, int kw, int c, int cout)
+// k within a kernel row: kk = kw * 4 + c (c < 3), group = kk / 8; layout [cout / 64][kh][hi,lo][group][cout % 64][8 halves]
+size_t conv1_f16x3_panel_index(int KH, int kh, int plane, int kw, int c, int cout)
 {
     const int kk = kw * 4 + c;
-    return ((((size_t)kh * 2 + plane) * 4 + (kk >> 3)) * C1_COUT + cout) * 8 + (kk & 7);
+    return (((((size_t)(cout / C1_COUT) * KH + kh) * 2 + plane) * 4 + (kk >> 3)) * C1_COUT + cout % C1_COUT) * 8 + (kk & 7);
 }
 
-hipError_t launch_conv1_f16x3(const float* x, int N, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s)
+bool conv1_f16x3_supported(int KH, int Cout) { return (KH == 7 && Cout == 64) || (KH == 5 && Cout == 128); }
+
+// KH = 7: ZeroPadding2D(3) + 7x7/2 'valid', 3 -> 64 (resnet50 front); KH = 5: 5x5/2 'SAME' (one pixel before), 3 -> 128 (paper encoder)
+hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s)
 {
     if (N <= 0) return hipSuccess;
-    if (G.n_groups < 1 || G.n_groups > IGEMM_MAX_GROUPS) return hipErrorInvalidValue;
+    if (!conv1_f16x3_supported(KH, Cout) || G.n_groups < 1 || G.n_groups > IGEMM_MAX_GROUPS) return hipErrorInvalidValue;
     if ((size_t)N * C1_HIN * C1_HIN * 12 >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG));
-    hipLaunchKernelGGL(conv1_f16x3_kernel, dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out);
+    if (KH == 7) hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out);
+    else hipLaunchKernelGGL((conv1_f16x3_kernel<5, 1, 128>), dim3(wgs, 2), dim3(256), 0, s, x, N, G, act, alpha, out);
     return hipGetLastError();
 }
 

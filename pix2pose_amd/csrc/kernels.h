@@ -110,11 +110,12 @@ hipError_t launch_conv_first(const float* x, int N, int H, int W, const float* w
                              int stride, int pad, int Cout, const float* scale, const float* shift,
                              int act, float alpha, float* out, int Ho, int Wo, hipStream_t s);
 
-// The same layer for PREC_F16X3 ResNet-50 models on the f16 matrix cores (conv1.hip): 7x7/2, pad 3, 3 -> 64,
-// 128x128 input.  w_alt: split-f16 panel, conv1_f16x3_panel_floats() floats, element (kh, hi/lo plane, kw, c, cout)
-// at half index conv1_f16x3_panel_index().
-size_t conv1_f16x3_panel_floats();
-size_t conv1_f16x3_panel_index(int kh, int plane, int kw, int c, int cout);
+// The same layer for PREC_F16X3 models on the f16 matrix cores (conv1.hip), 128x128 input: 7x7/2, pad 3, 3 -> 64 (resnet50 front)
+// or 5x5/2 'SAME', 3 -> 128 (paper encoder).  w_alt: split-f16 panel, conv1_f16x3_panel_floats() floats, element
+// (kh, hi/lo plane, kw, c, cout) at half index conv1_f16x3_panel_index().
+bool conv1_f16x3_supported(int KH, int Cout);
+size_t conv1_f16x3_panel_floats(int KH, int Cout);
+size_t conv1_f16x3_panel_index(int KH, int kh, int plane, int kw, int c, int cout);
 // Mixed-object batches: samples [start[g], start[g+1]) use panel g (one launch for the whole batch).
 struct Conv1Groups {
     int n_groups;
@@ -123,7 +124,7 @@ struct Conv1Groups {
     const float* scale[IGEMM_MAX_GROUPS];
     const float* shift[IGEMM_MAX_GROUPS];
 };
-hipError_t launch_conv1_f16x3(const float* x, int N, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s);
+hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s);
 
 // MaxPooling2D 3x3 stride 2, TF 'SAME' (pad 0 before / 1 after), NHWC, C % 4 == 0.
 hipError_t launch_maxpool3s2(const float* x, int N, int H, int W, int C, float* out, hipStream_t s);

@@ -235,21 +235,22 @@ static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& n
         int rc = fold_bn(T, names[b], cout_each, true, scale, shift);
         if (rc) return rc;
     }
-    if (g_pack_prec == PREC_F16X3 && KH == 7 && L.Cout == 64 && specialised_kernels()) {
+    if (g_pack_prec == PREC_F16X3 && conv1_f16x3_supported(KH, L.Cout) && specialised_kernels()) {
         // matrix-core variant (conv1.hip): split-f16 panel in that kernel's own layout; L.prec marks it
-        std::vector<float> panel(conv1_f16x3_panel_floats(), 0.f), sc(scale), ws(64);
-        for (int co = 0; co < 64; ++co) ws[co] = f16x3_row_scale(w.data() + co, (size_t)L.K, (size_t)L.Cout);   // per output channel
+        const int Cout = L.Cout;
+        std::vector<float> panel(conv1_f16x3_panel_floats(KH, Cout), 0.f), sc(scale), ws(Cout);
+        for (int co = 0; co < Cout; ++co) ws[co] = f16x3_row_scale(w.data() + co, (size_t)L.K, (size_t)Cout);   // per output channel
         uint16_t* o = reinterpret_cast<uint16_t*>(panel.data());
-        for (int kh = 0; kh < 7; ++kh)
-            for (int kw = 0; kw < 7; ++kw)
+        for (int kh = 0; kh < KH; ++kh)
+            for (int kw = 0; kw < KH; ++kw)
                 for (int c = 0; c < 3; ++c)
-                    for (int co = 0; co < 64; ++co) {
-                        const float v = w[(size_t)((kh * 7 + kw) * 3 + c) * L.Cout + co] * ws[co];
+                    for (int co = 0; co < Cout; ++co) {
+                        const float v = w[(size_t)((kh * KH + kw) * 3 + c) * Cout + co] * ws[co];
                         const uint16_t hi = f32_to_f16(v);
-                        o[conv1_f16x3_panel_index(kh, 0, kw, c, co)] = hi;
-                        o[conv1_f16x3_panel_index(kh, 1, kw, c, co)] = f32_to_f16(v - f16_to_f32(hi));
+                        o[conv1_f16x3_panel_index(KH, kh, 0, kw, c, co)] = hi;
+                        o[conv1_f16x3_panel_index(KH, kh, 1, kw, c, co)] = f32_to_f16(v - f16_to_f32(hi));
                     }
-        for (int co = 0; co < 64; ++co) sc[co] *= 1.f / ws[co];
+        for (int co = 0; co < Cout; ++co) sc[co] *= 1.f / ws[co];
         L.prec = PREC_F16X3;
         int rc;
         if ((rc = upload(panel, &L.w))) return rc;
@@ -681,7 +682,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
                 G.start[g] = g0(g); G.w[g] = c1.w; G.scale[g] = c1.scale; G.shift[g] = c1.shift;
             }
             G.start[n_grp] = n;
-            HIP_TRY(launch_conv1_f16x3(x, n, G, ACT_RELU, LEAKY, A["f1"], st));
+            HIP_TRY(launch_conv1_f16x3(x, n, 7, 64, G, ACT_RELU, LEAKY, A["f1"], st));
         } else
         for (int g = 0; g < n_grp; ++g) {      // VALU first layer: one launch per object (tiny)
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
@@ -704,6 +705,18 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
     } else {
         // ae_model.py:74-106: each level = two parallel 5x5/2 convs concatenated [_1 || _2];
         // the skip is the _2 half, i.e. the upper channels of the merged output.
+        if (M.L.at("conv1").prec == PREC_F16X3) {       // matrix-core first layer (conv1.hip): one launch, per-sample panel lookup
+            if (n_grp > IGEMM_MAX_GROUPS) { set_error("forward: %d object groups exceed IGEMM_MAX_GROUPS", n_grp); return P2P_ERR_CAPACITY; }
+            Conv1Groups G;
+            G.n_groups = n_grp;
+            for (int g = 0; g < n_grp; ++g) {
+                const ConvLayer& c1 = grp_model(g).L.at("conv1");
+                if (c1.prec != PREC_F16X3) { set_error("forward: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
+                G.start[g] = g0(g); G.w[g] = c1.w; G.scale[g] = c1.scale; G.shift[g] = c1.shift;
+            }
+            G.start[n_grp] = n;
+            HIP_TRY(launch_conv1_f16x3(x, n, 5, 128, G, ACT_LEAKY, LEAKY, A["f1"], st));
+        } else
         for (int g = 0; g < n_grp; ++g) {
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
             HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 5, 2, 1, 128, c1.scale, c1.shift,
