@@ -33,6 +33,7 @@ struct DetInfo {
     int corr_cap;           // points per candidate (stage-1 side squared)
     int aa;                 // anti-aliased resizes (scikit-image 0.15 - 0.18 default), p2p_est_pose_opts.resize_anti_aliasing
     long long cv_off;       // double offset of this detection's (1 + K) canvases of corr_cap * 3 doubles each (aa, side > 128)
+    int src_index;          // index of this detection in the caller's array (detections are processed sorted by object)
 };
 
 // One image of an anti-aliased resize (skimage: ndi.gaussian_filter before the warp): filtered in place.
