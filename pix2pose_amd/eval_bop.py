@@ -155,6 +155,33 @@ def _load_frame(path):
     return a[:, :, :3]
 
 
+class FramePrefetcher:
+    """Decodes the frames of upcoming chunks on a few threads (PNG decoding releases the GIL; one 640x480 frame costs ~5 ms,
+    a 32-image chunk 160 ms on one thread -- more than the GPU needs for its 256 detections).  request() schedules,
+    get() returns the decoded frame (decoding it now if it was never requested) and forgets it."""
+
+    def __init__(self, threads: int = 8):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(threads))) if threads and threads > 0 else None
+        self._pending = {}
+
+    def request(self, paths):
+        if self._pool is None:
+            return
+        for p in paths:
+            if p not in self._pending:
+                self._pending[p] = self._pool.submit(_load_frame, p)
+
+    def get(self, path):
+        f = self._pending.pop(path, None)
+        return f.result() if f is not None else _load_frame(path)
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=False, cancel_futures=True)
+            self._pool = None
+
+
 # ---------------------------------------------------------------------------------- driver
 def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".", batch_images: int = 32,
         detect_type: str = "rcnn", est_pose_kwargs=None, shard=None, write_csv: bool = True, inject=None):
@@ -190,7 +217,7 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
             im = by_image.get((scene_id, im_id))
             if im is None:
                 continue
-            frame = _load_frame(os.path.join(base_dir, im["rgb"]))
+            frame = loader.get(os.path.join(base_dir, im["rgb"]))
             masks = np.load(os.path.join(base_dir, im["masks"])) if im.get("masks") else None
             segs = im.get("segmentations") if masks is None else None
             fi = len(frames)
@@ -234,12 +261,19 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
 
     # detection stream: chunk i+1 is read from disk and enqueued (p2p_est_pose_submit) while chunk i is on the GPU;
     # the score_type-2 mask sums come back through the same asynchronous call
+    loader = FramePrefetcher(int(cfg.get("loader_threads", 8)))
+
+    def frame_paths(chunk):
+        return [os.path.join(base_dir, by_image[(c[0], c[1])]["rgb"]) for c in chunk if (c[0], c[1]) in by_image]
+
+    loader.request(frame_paths(tlist[:batch_images]))
     in_flight = []
     n_submitted = 0
     inject_row = {(int(a), int(b)): i for i, (a, b) in enumerate(inject["key"])} if inject is not None else None
     for b0 in range(0, len(tlist), batch_images):
         chunk = tlist[b0:b0 + batch_images]
         t1 = time.time()
+        loader.request(frame_paths(tlist[b0 + batch_images:b0 + 2 * batch_images]))      # decoded while this chunk is prepared and runs
         frames, dets, det_masks, owners = prepare(chunk)
         if not dets:
             continue
@@ -263,6 +297,7 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
             finish(in_flight.pop(0))
     while in_flight:
         finish(in_flight.pop(0))
+    loader.close()
     out_dir = cfg.get("path_to_output")
     if out_dir and write_csv:
         os.makedirs(out_dir, exist_ok=True)

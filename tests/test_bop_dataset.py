@@ -145,6 +145,29 @@ def test_build_dump_from_a_bop_directory(tmp_path):
         B.build_dump(cfg, "ycbv", dets)
 
 
+def test_frame_prefetcher_returns_what_a_direct_load_returns(tmp_path):
+    from PIL import Image
+    rs = np.random.RandomState(2)
+    paths, imgs = [], []
+    for i in range(7):
+        a = rs.randint(0, 255, (48, 64, 3)).astype(np.uint8) if i != 3 else rs.randint(0, 255, (48, 64)).astype(np.uint8)   # one gray frame
+        fn = str(tmp_path / ("%d.png" % i))
+        Image.fromarray(a).save(fn)
+        paths.append(fn); imgs.append(a)
+    np.save(tmp_path / "n.npy", imgs[0])
+    for threads in (0, 3):
+        pf = E.FramePrefetcher(threads)
+        pf.request(paths[:4])
+        pf.request(paths[2:6])                       # overlapping requests are decoded once
+        for i in (1, 0, 3, 2, 6, 5, 4):              # any order, requested or not
+            got = pf.get(paths[i])
+            exp = imgs[i] if imgs[i].ndim == 3 else np.repeat(imgs[i][:, :, None], 3, axis=2)
+            np.testing.assert_array_equal(got, exp)
+        np.testing.assert_array_equal(pf.get(str(tmp_path / "n.npy")), imgs[0])
+        assert not pf._pending
+        pf.close()
+
+
 def test_rows_survive_the_gather_records():
     rs = np.random.RandomState(0)
     rows = [{"scene_id": 48 + i % 2, "im_id": 7 * i, "obj_id": 3 + i, "score": float(rs.uniform()), "R": rs.normal(size=(3, 3)),
