@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--host-frames", type=int, default=3, help="steps of the host-frame leg (N=1; 0 = skip)")
     ap.add_argument("--latency", type=int, default=100, help="calls of the single-detection latency leg (N=1; 0 = skip)")
     ap.add_argument("--merge", action="store_true", help="stream mode: merge step i's stage-2 generator pass with step i+1's stage-1 pass (p2p_est_pose_opts.merge_stream_passes)")
+    ap.add_argument("--anti-aliasing", action="store_true", help="scikit-image 0.15 - 0.18 resize semantics (Gaussian pre-filter whenever a resize shrinks)")
     ap.add_argument("--no-legs", action="store_true", help="skip the f32 / host-frame / latency / CPU legs (profiling runs)")
     args = ap.parse_args()
     if args.no_legs:
@@ -232,11 +233,11 @@ def main():
         out = None
         if blocking:
             for i in range(k):
-                out = finish(est_pose_batch(ctx, specs, imgs(i), sc["dets"], want_masks=masks, **kw)[0])
+                out = finish(est_pose_batch(ctx, specs, imgs(i), sc["dets"], want_masks=masks, anti_aliasing=args.anti_aliasing, **kw)[0])
             return out
         pending = []
         for i in range(k):
-            pending.append(est_pose_submit(ctx, specs, imgs(i), sc["dets"], want_masks=masks, merge_passes=args.merge, **kw))
+            pending.append(est_pose_submit(ctx, specs, imgs(i), sc["dets"], want_masks=masks, merge_passes=args.merge, anti_aliasing=args.anti_aliasing, **kw))
             if len(pending) >= args.inflight:
                 out = finish(pending.pop(0).collect())
         while pending:
