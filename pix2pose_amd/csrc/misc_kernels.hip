@@ -108,7 +108,12 @@ __global__ void maxpool3s2_kernel(const float* __restrict__ x, int N, int H, int
                                   float* __restrict__ out, int Ho, int Wo)
 {
     const size_t total = (size_t)N * Ho * Wo * C4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // Workgroup b runs on XCD b % 8 and each XCD has its own L2: give every XCD a contiguous run of output (whole images), so that
+    // the input rows two output rows share are re-read from the SAME L2 (in launch order the two rows sat on different XCDs and
+    // the kernel fetched 1.5x its input).
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    for (size_t i = (size_t)lb * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         size_t r = i / C4;
         const int ow = (int)(r % Wo); r /= Wo;
@@ -134,7 +139,7 @@ hipError_t launch_maxpool3s2(const float* x, int N, int H, int W, int C, float* 
     if (C % 4 || H % 2 || W % 2) return hipErrorInvalidValue;
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
-    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+    const int blocks = (int)min((size_t)1 << 20, (total + 255) / 256);       // one pass: the XCD mapping above needs the whole range in one sweep
     hipLaunchKernelGGL(maxpool3s2_kernel, dim3(blocks), dim3(256), 0, s, x, N, H, W, C / 4, out, Ho, Wo);
     return hipGetLastError();
 }
