@@ -369,12 +369,14 @@ def main(argv):
     if os.environ.get("P2P_EVAL_INJECT"):             # test hook, see run()
         with np.load(os.environ["P2P_EVAL_INJECT"]) as z:
             inject = {k: z[k] for k in ("key", "inject1", "inject2")}
+    detect_type = cfg.get("detection_pipeline", "rcnn")          # tools/5_evaluation_bop_basic.py:36 ('rcnn' | 'retinanet': no masks)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        rows = run_distributed(cfg, dataset, dump, base_dir=base_dir, same_device=bool(os.environ.get("P2P_EVAL_SAME_DEVICE")), inject=inject)
+        rows = run_distributed(cfg, dataset, dump, base_dir=base_dir, same_device=bool(os.environ.get("P2P_EVAL_SAME_DEVICE")), inject=inject,
+                               detect_type=detect_type)
         if int(os.environ["RANK"]) != 0:
             return 0
     else:
-        rows = run(cfg, dataset, dump, device=device, base_dir=base_dir, inject=inject)
+        rows = run(cfg, dataset, dump, device=device, base_dir=base_dir, inject=inject, detect_type=detect_type)
     print("Saving %d results to %s" % (len(rows), os.path.join(cfg.get("path_to_output", "."), output_name(dataset))))
     return 0
 
