@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace p2p {
 
@@ -127,6 +128,24 @@ static float f16_to_f32(uint16_t h)
 static bool specialised_kernels() { static const bool on = getenv("P2P_NO_HALO") == nullptr; return on; }
 
 static thread_local int g_pack_prec = PREC_F32;   // precision of the model being packed (build_model)
+
+// Model construction is host work over 28 M weights (transposes into GEMM panels, the f16 split): rows are independent, so the big
+// loops run on a few threads (0.33 s per object on one thread; a 30-object T-LESS set is built once per process).
+template <typename F>
+static void parallel_rows(size_t n, size_t work_per_row, F fn)
+{
+    unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n * work_per_row < (size_t)1 << 18 || nt == 1 || n < 2) { fn((size_t)0, n); return; }
+    nt = (unsigned)std::min<size_t>(nt, n);
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t a = t * per, b = std::min(n, a + per);
+        if (a >= b) break;
+        th.emplace_back([=] { fn(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
 // Power-of-two pre-scale of ONE OUTPUT CHANNEL's weights for the split: the largest |w| of the row lands in
 // [2^13, 2^14) (f16 max is 65504), so the lo parts of all but vanishing weights stay in the f16 normal range.
 // Per row, not per layer: in a trained network the rows of one layer differ by orders of magnitude (BatchNorm
@@ -151,18 +170,20 @@ static std::vector<float> split_panel(const std::vector<float>& w, int K, std::v
     uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
     const size_t rows = w.size() / K;
     row_scale.assign(rows, 1.f);
-    for (size_t r = 0; r < rows; ++r) {
-        const float sc = row_scale[r] = f16x3_row_scale(w.data() + r * K, (size_t)K);
-        for (int k0 = 0; k0 < K; k0 += 32) {
-            uint16_t* blk = o + (r * K + k0) * 2;
-            for (int k = 0; k < 32; ++k) {
-                const float v = w[r * K + k0 + k] * sc;
-                const uint16_t hi = f32_to_f16(v);
-                blk[k] = hi;
-                blk[32 + k] = f32_to_f16(v - f16_to_f32(hi));
+    parallel_rows(rows, (size_t)K, [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const float sc = row_scale[r] = f16x3_row_scale(w.data() + r * K, (size_t)K);
+            for (int k0 = 0; k0 < K; k0 += 32) {
+                uint16_t* blk = o + (r * K + k0) * 2;
+                for (int k = 0; k < 32; ++k) {
+                    const float v = w[r * K + k0 + k] * sc;
+                    const uint16_t hi = f32_to_f16(v);
+                    blk[k] = hi;
+                    blk[32 + k] = f32_to_f16(v - f16_to_f32(hi));
+                }
             }
         }
-    }
+    });
     return out;
 }
 
@@ -203,10 +224,12 @@ static int pack_conv(const TensorMap& T, const std::vector<std::string>& names, 
     for (int b = 0; b < nb; ++b) {
         const float* k = T.get(names[b] + ".kernel", (int64_t)KH * KH * Cin * cout_each);
         if (!k) return P2P_ERR_WEIGHTS;
-        for (int t = 0; t < L.ntaps; ++t)
-            for (int ci = 0; ci < Cin; ++ci)
-                for (int co = 0; co < cout_each; ++co)
-                    w[(size_t)(b * cout_each + co) * L.K + (size_t)t * Cin + ci] = k[((size_t)t * Cin + ci) * cout_each + co];
+        parallel_rows((size_t)cout_each, (size_t)L.K, [&](size_t c0, size_t c1) {
+            for (int t = 0; t < L.ntaps; ++t)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (size_t co = c0; co < c1; ++co)
+                        w[(size_t)(b * cout_each + co) * L.K + (size_t)t * Cin + ci] = k[((size_t)t * Cin + ci) * cout_each + co];
+        });
         int rc = fold_bn(T, names[b], cout_each, bn, scale, shift);
         if (rc) return rc;
     }
@@ -372,8 +395,10 @@ static int pack_dense(const TensorMap& T, const std::string& name, int In, int O
     L.K = In;
     L.dy[0] = L.dx[0] = 0;
     std::vector<float> w((size_t)round_up(Out, 128) * In, 0.f), scale, shift;
-    for (int i = 0; i < In; ++i)
-        for (int o = 0; o < Out; ++o) w[(size_t)o * In + i] = k[(size_t)i * Out + o];
+    parallel_rows((size_t)Out, (size_t)In, [&](size_t o0, size_t o1) {
+        for (int i = 0; i < In; ++i)
+            for (size_t o = o0; o < o1; ++o) w[o * In + i] = k[(size_t)i * Out + o];
+    });
     int rc = fold_bn(T, name, Out, false, scale, shift);
     if (rc) return rc;
     return finish_layer(L, w, scale, shift);
