@@ -1119,11 +1119,15 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     }
 }
 
-// Kernel 3 of 4 -- the refit solve: one LANE per problem (register-resident 12x12 SVD, betas,
-// Gauss-Newton, absolute orientation for the three beta cases).
+// Kernel 3 of 4 -- the refit solve: one LANE per (problem, beta case) -- register-resident 12x12 SVD (computed by all three lanes
+// of a problem: same inputs, same bits), then this lane's betas, Gauss-Newton and absolute orientation.  The three cases used to
+// run one after the other on one lane; the kernel is a pure latency chain (the tail of a blocking call and of a single detection
+// waits for it): 0.62 -> 0.54 ms for the 768 problems of a 256-detection batch, 0.45 -> 0.39 ms for the three of one detection
+// (the 12x12 SVD dominates).
 __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
 {
-    const int pi = blockIdx.x * 256 + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
+    const int li = blockIdx.x * 256 + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
+    const int pi = li / 3, c = li - pi * 3;
     if (pi >= n_problems) return;
     PnpFit& fit = fits[pi];
     if (fit.state != 0) return;
@@ -1157,8 +1161,7 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
     double l[60], rho[6];
     compute_L_6x10(ut, l);
     compute_rho(cws, rho);
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
+    {
         double betas[4];
         if (c == 0) betas_approx_1(l, rho, betas);
         else if (c == 1) betas_approx_2(l, rho, betas);
@@ -1276,7 +1279,7 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
         h_begin = stops[r];
         if (iterations <= h_begin) break;
     }
-    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
+    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((3 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);
     return hipGetLastError();
