@@ -28,13 +28,15 @@ python bench.py --steps 5 --warmup 2 --objects 30 --no-legs > gpurun_out/bench_o
 python bench.py --steps 5 --warmup 2 --precision f32 --no-legs > gpurun_out/bench_f32.json 2>> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --masks --no-legs > gpurun_out/bench_masks.json 2>> gpurun_out/bench_final.err
 python bench.py --gpus 2 --backend gloo --same-device --steps 3 --warmup 1 --no-legs > gpurun_out/bench_2ranks_same_device.json 2>> gpurun_out/bench_final.err
+python bench.py --steps 20 --warmup 3 --no-legs > gpurun_out/bench_k20.json 2>> gpurun_out/bench_final.err
+python bench.py --backbone paper --steps 20 --warmup 3 --no-legs > gpurun_out/bench_paper.json 2>> gpurun_out/bench_final.err
 cat gpurun_out/gpu_tests.log; tail -c 300 gpurun_out/bench_final.json
 ' 2>&1 | tail -8
 python tools/rocprof_summary.py gpurun_out/prof_final/bench_results.db > profiles/${R}_bench_kernel_stats.txt
 python tools/layer_times.py gpurun_out/prof_final/bench_results.db > profiles/${R}_layer_times.txt
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/${R}_traffic.json | head -4
 python tools/pmc_sq.py gpurun_out/pmc_sq1/x_results.db gpurun_out/pmc_sq2/x_results.db gpurun_out/pmc_sq3/x_results.db > profiles/${R}_sq_counters.txt
-for f in bench_final:bench_line bench_objects30:bench_line_objects30 bench_f32:bench_line_f32mode bench_masks:bench_line_masks bench_2ranks_same_device:bench_line_2ranks_same_device; do
+for f in bench_final:bench_line bench_objects30:bench_line_objects30 bench_f32:bench_line_f32mode bench_masks:bench_line_masks bench_2ranks_same_device:bench_line_2ranks_same_device bench_k20:bench_line_k20 bench_paper:bench_line_paper_backbone; do
     grep '^{' gpurun_out/${f%%:*}.json | tail -1 > profiles/${R}_${f##*:}.json
 done
 cp gpurun_out/gpu_tests.log profiles/${R}_gpu_tests.log
