@@ -5,8 +5,11 @@ BASELINE.json configs[4]: "YCB-V full BOP test_targets stream, Mask-RCNN boxes p
 Directory conventions are the reference's (nothing here reads a model file or renders anything):
   * dataset sub-directory and test split             tools/bop_io.py:51-113  (``tless`` -> test_primesense, everything else -> test)
   * global camera: ``camera.json``, ycbv ``camera_uw.json`` -> im_size = (width, height)       tools/bop_io.py:115-120
-  * object list: the ids of ``models*/models_info.json``, narrowed by cfg ``target_obj``       tools/bop_io.py:122-135,
+  * object list: the ids of ``models*/models_info.json`` that have an ``obj_<id:06d>.ply`` next to it (all ids when the
+    directory holds no mesh at all: evaluation never reads one), narrowed by cfg ``target_obj``    tools/bop_io.py:122-135,
                                                                                                 tools/5_evaluation_bop_basic.py:139-153
+  * the script's ``bop_dir`` is the DATASET directory ``<cfg dataset_dir>/<dataset>`` (first value bop_io.get_dataset returns,
+    tools/5_evaluation_bop_basic.py:122-125), and everything below hangs off it:
   * normalisation factors ``<bop_dir>/models_xyz/<cfg norm_factor_fn>``                        tools/5_evaluation_bop_basic.py:129
   * weights ``<bop_dir>/pix2pose_weights/<id:02d>/inference[_resnet_model|_resnet50].hdf5``    tools/5_evaluation_bop_basic.py:196-205
     (here: the ``.npz`` the converter wrote next to it, or the ``.hdf5`` itself when h5py is installed)
@@ -45,9 +48,14 @@ def _models_dir(dataset_dir: str, dataset: str) -> str:
 
 
 def load_model_ids(dataset_dir: str, dataset: str, target_obj=None):
-    """Sorted object ids of the dataset, narrowed to cfg['target_obj'] when given."""
-    info = json.load(open(os.path.join(_models_dir(dataset_dir, dataset), "models_info.json")))
+    """Sorted object ids of the dataset, narrowed to cfg['target_obj'] when given.  The reference keeps an id only if its mesh
+    file exists (tools/bop_io.py:129-131); a deployment without any mesh keeps them all."""
+    mdir = _models_dir(dataset_dir, dataset)
+    info = json.load(open(os.path.join(mdir, "models_info.json")))
     ids = sorted(int(k) for k in info)
+    with_mesh = [i for i in ids if os.path.exists(os.path.join(mdir, "obj_%06d.ply" % i))]
+    if with_mesh:
+        ids = with_mesh
     if target_obj is not None:
         ids = [i for i in ids if i in set(int(t) for t in target_obj)]
     return ids
@@ -58,10 +66,10 @@ def load_im_size(dataset_dir: str, dataset: str):
     return [int(cam["width"]), int(cam["height"])]
 
 
-def weights_path(bop_dir: str, model_id: int, backbone: str) -> str:
+def weights_path(dataset_dir: str, model_id: int, backbone: str) -> str:
     """The converted ``.npz`` next to the reference's inference weights, else the ``.hdf5`` itself (read through
     convert_keras, needs h5py).  Candidate order as in the reference."""
-    wdir = os.path.join(bop_dir, "pix2pose_weights", "%02d" % model_id)
+    wdir = os.path.join(dataset_dir, "pix2pose_weights", "%02d" % model_id)
     stems = ["inference_resnet_model", "inference_resnet50"] if backbone == "resnet50" else ["inference"]
     for ext in (".npz", ".hdf5"):
         for s in stems:
@@ -144,8 +152,8 @@ def build_dump(cfg: dict, dataset: str, detections) -> dict:
     dataset_dir, test_dir = dataset_dirs(bop_dir, dataset)
     model_ids = load_model_ids(dataset_dir, dataset, cfg.get("target_obj"))
     backbone = cfg.get("backbone", "paper")
-    norm = json.load(open(os.path.join(bop_dir, "models_xyz", cfg["norm_factor_fn"])))
-    targets = json.load(open(os.path.join(bop_dir, cfg["test_target"] + ".json")))
+    norm = json.load(open(os.path.join(dataset_dir, "models_xyz", cfg["norm_factor_fn"])))
+    targets = json.load(open(os.path.join(dataset_dir, cfg["test_target"] + ".json")))
     per_image = group_detections(detections, model_ids)
     gray = dataset == "itodd"
     images, cams = [], {}
@@ -168,5 +176,5 @@ def build_dump(cfg: dict, dataset: str, detections) -> dict:
         images.append(im)
     return {"im_size": load_im_size(dataset_dir, dataset), "model_ids": model_ids,
             "norm_factor": {str(m): norm[str(m)] for m in model_ids},
-            "weights": {str(m): weights_path(bop_dir, m, backbone) for m in model_ids},
+            "weights": {str(m): weights_path(dataset_dir, m, backbone) for m in model_ids},
             "targets": targets, "images": images}

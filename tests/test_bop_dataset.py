@@ -69,13 +69,13 @@ def make_bop_dir(root, dataset="ycbv", n_scenes=2, per_scene=3, model_ids=(1, 4,
     H, Wd = 480, 640
     json.dump({"cx": 312.9869, "cy": 241.3109, "depth_scale": 0.1, "fx": 1066.778, "fy": 1067.487, "height": H, "width": Wd},
               open(os.path.join(ds, "camera_uw.json" if dataset == "ycbv" else "camera.json"), "w"))
-    os.makedirs(os.path.join(root, "models_xyz"), exist_ok=True)
+    os.makedirs(os.path.join(ds, "models_xyz"), exist_ok=True)          # the script's bop_dir is the dataset directory
     keys = ["x_scale", "y_scale", "z_scale", "x_ct", "y_ct", "z_ct"]
     json.dump({str(m): dict(zip(keys, (S.OBJ_PARAM * (1 + 0.01 * m)).tolist())) for m in list(model_ids) + [77]},
-              open(os.path.join(root, "models_xyz", "norm_factor.json"), "w"))
+              open(os.path.join(ds, "models_xyz", "norm_factor.json"), "w"))
     if weights:
         for m in model_ids:
-            wdir = os.path.join(root, "pix2pose_weights", "%02d" % m)
+            wdir = os.path.join(ds, "pix2pose_weights", "%02d" % m)
             os.makedirs(wdir, exist_ok=True)
             W.save_weights(os.path.join(wdir, ("inference_resnet_model" if backbone == "resnet50" else "inference") + ".npz"), backbone,
                            W.synthetic_weights(backbone, m))
@@ -100,7 +100,7 @@ def make_bop_dir(root, dataset="ycbv", n_scenes=2, per_scene=3, model_ids=(1, 4,
                 targets.append({"im_id": iid, "inst_count": 1, "obj_id": int(m), "scene_id": sid})
             k += 1
         json.dump(cam, open(os.path.join(sdir, "scene_camera.json"), "w"))
-    json.dump(targets, open(os.path.join(root, "test_targets_bop19.json"), "w"))
+    json.dump(targets, open(os.path.join(ds, "test_targets_bop19.json"), "w"))
     cfg = {"dataset_dir": root, "test_target": "test_targets_bop19", "norm_factor_fn": "norm_factor.json", "backbone": backbone,
            "outlier_th": [0.2, 0.3, 0.35], "inlier_th": 0.2, "score_type": 2, "task_type": 2, "cand_factor": 2,
            "path_to_output": os.path.join(root, "out"), "generator_chunk": 64}
@@ -143,6 +143,53 @@ def test_build_dump_from_a_bop_directory(tmp_path):
     os.remove(dump["weights"]["4"])
     with pytest.raises(FileNotFoundError, match="inference"):
         B.build_dump(cfg, "ycbv", dets)
+
+
+def test_directory_conventions_match_the_reference_script(tmp_path):
+    """tests/golden/reference_eval.json holds what the reference's OWN evaluation script (run unmodified on a synthetic BOP-style
+    directory, tests/golden/make_reference_eval_vectors.py) passed to every pix2pose(...) it constructed: the weight file it
+    looked for, obj_param from the norm-factor file, the frame size.  The same directory, rebuilt here from the fixture, must
+    give the same object list, weight paths, parameters, targets and per-image intrinsics through build_dump."""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_eval.json")))
+    H, Wd = fx["frame"]
+    model_ids = fx["model_ids"]
+    run = fx["runs"][0]                                # backbone resnet50, the generating script's default cfg
+    bop = str(tmp_path / "bop")
+    ds = os.path.join(bop, "lmo")
+    for d in ("models", "models_xyz"):
+        os.makedirs(os.path.join(ds, d))
+    json.dump({str(m): {"diameter": 100.0} for m in model_ids + [99]}, open(os.path.join(ds, "models", "models_info.json"), "w"))
+    for m in model_ids:                                # object 99 has no mesh: the reference drops it
+        open(os.path.join(ds, "models", "obj_%06d.ply" % m), "w").close()
+    json.dump({str(m): {"x_scale": 30.0 + m, "y_scale": 31.0 + m, "z_scale": 32.0 + m, "x_ct": 0.5 * m, "y_ct": -0.25 * m, "z_ct": 1.0}
+               for m in model_ids}, open(os.path.join(ds, "models_xyz", "norm_factor.json"), "w"))
+    json.dump(fx["targets"], open(os.path.join(ds, "targets.json"), "w"))
+    json.dump({"cx": 80.0, "cy": 60.0, "depth_scale": 1.0, "fx": 572.4, "fy": 573.6, "height": H, "width": Wd}, open(os.path.join(ds, "camera.json"), "w"))
+    K = [572.4, 0, 80.0, 0, 573.6, 60.0, 0, 0, 1]
+    for scene in sorted({t["scene_id"] for t in fx["targets"]}):
+        sdir = os.path.join(ds, "test", "%06d" % scene)
+        os.makedirs(os.path.join(sdir, "rgb"))
+        json.dump({str(im): {"cam_K": (np.array(K) + 0.001 * im).tolist(), "depth_scale": 1.0} for im in (4, 9, 17)},
+                  open(os.path.join(sdir, "scene_camera.json"), "w"))
+    for c in run["ctor"]:                              # the files the reference would open (inference_resnet_model.hdf5 first; recorded: its fallback name, relative to dataset_dir)
+        fn = os.path.join(bop, c["weight_fn"])
+        os.makedirs(os.path.dirname(fn), exist_ok=True)
+        open(fn, "w").close()
+    cfg = {"backbone": "resnet50", "dataset_dir": bop, "norm_factor_fn": "norm_factor.json", "test_target": "targets"}
+    dump = B.build_dump(cfg, "lmo", [])
+    assert dump["model_ids"] == sorted(model_ids) and len(run["ctor"]) == len(model_ids)
+    assert dump["im_size"] == run["ctor"][0]["res"]
+    for m, c in zip(dump["model_ids"], run["ctor"]):
+        assert os.path.relpath(dump["weights"][str(m)], bop) == c["weight_fn"]
+        np.testing.assert_array_equal(E.model_params_to_obj_param(dump["norm_factor"][str(m)]), c["obj_param"])
+    assert dump["targets"] == fx["targets"]
+    for im in dump["images"]:
+        np.testing.assert_array_equal(im["cam_K"], (np.array(K) + 0.001 * im["im_id"]).tolist())
+        assert im["rgb"] == os.path.join(ds, "test", "%06d" % im["scene_id"], "rgb", "%06d.png" % im["im_id"])
+    # a converted .npz next to the .hdf5 takes precedence
+    first = dump["weights"][str(dump["model_ids"][0])]
+    open(os.path.splitext(first)[0] + ".npz", "w").close()
+    assert B.build_dump(cfg, "lmo", [])["weights"][str(dump["model_ids"][0])].endswith(".npz")
 
 
 def test_frame_prefetcher_returns_what_a_direct_load_returns(tmp_path):
