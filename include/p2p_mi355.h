@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define P2P_ABI_VERSION 4
+#define P2P_ABI_VERSION 5
 
 typedef enum {
     P2P_OK = 0,
@@ -253,10 +253,12 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
  *   3  igemm_halo_kernel<2,2> (halo-tiled stride-1 multi-tap layers, 128x128 tiles)     4  igemm_halo_kernel<4,2> (Cout = 64 layers, 256x64 tiles)
  *   5  heads_halo_kernel (merged output heads)     6  igemm_halo8_kernel (layers on the 8x8 grid: conv4, first transposed conv)
  *   7  igemm_halo_s2_kernel (5x5 stride-2 convolutions on larger grids: the paper encoder's conv2 / conv3)
+ *   8  igemm_stream_kernel (small launches: one wave per 32x32 tile, same K order and bits as the batched kernels)
+ *   9  igemm_pair_kernel (two transposed-conv phases on one 128-wide tile)
  * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md
  * section 8a-L), not padded work and not the 3 MFMA products per MAC of the split-f16 arithmetic.
  * ---------------------------------------------------------------------------------------- */
-#define P2P_PROFILE_SLOTS 8
+#define P2P_PROFILE_SLOTS 10
 typedef struct {
     int64_t launches;
     double total_ms;

@@ -91,6 +91,20 @@ hipError_t launch_igemm_halo8(const IgemmParams& p, hipStream_t s);
 bool igemm_halo_s2_supported(const IgemmParams& p);
 hipError_t launch_igemm_halo_s2(const IgemmParams& p, hipStream_t s);
 
+// Small-batch variant (igemm_stream.hip): one wave per 32x32 / 64x32 output tile, operands streamed global -> registers with a deep
+// software pipeline.  Bit-identical to the batched kernel that serves the layer: every output element is the same chain of MFMAs over
+// the same K-step order, which StreamOrder describes as that kernel's loop nest -- for g in groups: for slice: for tap in group g.
+//   igemm.hip:                  (tap, slice)          = one group per tap
+//   igemm_halo.hip / halo8<0>:  (slice, tap)          = one group holding every tap
+//   halo8<1> / igemm_halo_s2:   (plane, slice, tap)   = the four parity planes' tap lists
+struct StreamOrder {
+    int n_groups;
+    int8_t gstart[IGEMM_MAX_TAPS + 3];     // group g = entries [gstart[g], gstart[g + 1]) of tap[]
+    int8_t tap[IGEMM_MAX_TAPS + 3];        // panel tap indices
+};
+bool igemm_stream_supported(const IgemmParams& p);
+hipError_t launch_igemm_stream(const IgemmParams& p, const StreamOrder& o, hipStream_t s);
+
 // Halo-tiled kernel for the merged output heads (heads.hip); takes the same parameter block as the
 // generic kernel when heads_halo_supported() says so (PREC_F16X3, 64-wide grid, 128 input channels).
 bool heads_halo_supported(const IgemmParams& p);

@@ -127,6 +127,14 @@ static float f16_to_f32(uint16_t h)
 // tests/test_halo_gpu.py compares the two paths.
 static bool specialised_kernels() { static const bool on = getenv("P2P_NO_HALO") == nullptr; return on; }
 
+// Launches whose batched kernel would run on at most this many workgroups take the streaming kernel (igemm_stream.hip) instead.
+// P2P_STREAM_WGS=0 switches the route off (tests compare the two routes bit for bit).
+static int stream_max_wgs()
+{
+    static const int v = getenv("P2P_STREAM_WGS") ? atoi(getenv("P2P_STREAM_WGS")) : 64;
+    return specialised_kernels() ? v : 0;
+}
+
 static thread_local int g_pack_prec = PREC_F32;   // precision of the model being packed (build_model)
 
 // Model construction is host work over 28 M weights (transposes into GEMM panels, the f16 split): rows are independent, so the big
@@ -596,10 +604,45 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     const bool halo_conv = !halo && specialised_kernels() && igemm_halo_supported(p);   // stride-1 multi-tap layers (igemm_halo.hip)
     const bool halo8 = !halo && !halo_conv && specialised_kernels() && igemm_halo8_mode(p) != 0;   // 8x8-grid layers (igemm_halo8.hip)
     const bool halo_s2 = !halo && !halo_conv && !halo8 && specialised_kernels() && igemm_halo_s2_supported(p);   // 5x5 stride 2 on larger grids (igemm_halo_s2.hip)
-    auto launch = [&]() { return halo ? launch_heads_halo(p, st) : halo_conv ? launch_igemm_halo(p, st) : halo8 ? launch_igemm_halo8(p, st) :
-                                 halo_s2 ? launch_igemm_halo_s2(p, st) : launch_igemm(p, cfg, st); };
+    // Small launches (one detection at a time: the reference's own caller) go to the streaming kernel, which gives every 32x32 output
+    // tile its own wave and walks K in the SAME order as the batched kernel chosen above -- so the bits do not depend on the route.
+    StreamOrder so;
+    bool stream = false;
+    if (!halo && stream_max_wgs() > 0 && igemm_stream_supported(p)) {
+        int grid;         // workgroups of the batched kernel
+        if (halo_conv) {
+            const int m_tiles = c.N * (c.Hg / 8) * (c.Wg / 16);
+            grid = L.Cout % 128 == 0 ? m_tiles * (L.Cout / 128) : (c.Hg % 16 == 0 ? m_tiles / 2 : m_tiles) * (L.Cout / 64);
+        } else if (halo8) grid = ((p.M + 127) / 128) * (L.Cout / 128);
+        else if (halo_s2) grid = c.N * (c.Hg / 8) * (c.Wg / 16) * (L.Cout / 128);
+        else grid = ((p.M + 127) / 128) * ((L.Cout + (cfg == 0 ? 127 : cfg == 1 ? 63 : 31)) / (cfg == 0 ? 128 : cfg == 1 ? 64 : 32));
+        if (grid <= stream_max_wgs()) {
+            stream = true;
+            memset(&so, 0, sizeof(so));
+            if (halo_conv || (halo8 && igemm_halo8_mode(p) == 1)) {          // (slice, tap)
+                so.n_groups = 1;
+                so.gstart[1] = (int8_t)L.ntaps;
+                for (int t = 0; t < L.ntaps; ++t) so.tap[t] = (int8_t)t;
+            } else if (halo8 || halo_s2) {                                    // (parity plane, slice, tap of the plane)
+                so.n_groups = 4;
+                int k = 0;
+                for (int g = 0; g < 4; ++g) {
+                    const int py = g >> 1, px = g & 1, ny = py ? 3 : 2, nx = px ? 3 : 2;
+                    so.gstart[g] = (int8_t)k;
+                    for (int iy = 0; iy < ny; ++iy)
+                        for (int ix = 0; ix < nx; ++ix) so.tap[k++] = (int8_t)((py ? 2 * iy : 2 * iy + 1) * 5 + (px ? 2 * ix : 2 * ix + 1));
+                }
+                so.gstart[4] = (int8_t)k;
+            } else {                                                          // (tap, slice)
+                so.n_groups = L.ntaps;
+                for (int t = 0; t <= L.ntaps; ++t) { so.gstart[t] = (int8_t)t; so.tap[t] = (int8_t)t; }
+            }
+        }
+    }
+    auto launch = [&]() { return stream ? launch_igemm_stream(p, so, st) : halo ? launch_heads_halo(p, st) : halo_conv ? launch_igemm_halo(p, st) :
+                                 halo8 ? launch_igemm_halo8(p, st) : halo_s2 ? launch_igemm_halo_s2(p, st) : launch_igemm(p, cfg, st); };
     if (X.profiling) {
-        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : halo8 ? 6 : halo_s2 ? 7 : cfg,
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), stream ? 8 : halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : halo8 ? 6 : halo_s2 ? 7 : cfg,
                           2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
         if (!ev.a || !ev.b) return P2P_ERR_HIP;
         HIP_TRY(hipEventRecord(ev.a, st));
