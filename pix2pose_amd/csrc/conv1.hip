@@ -31,11 +31,11 @@ constexpr int C1_HIN = 128, C1_HOUT = 64;
 constexpr int C1_ROWS_OUT = 2;                                   // output rows per tile
 constexpr int C1_ROW_PX = C1_HIN + 6;                            // 134 staged pixels per row (pixel -PAD first; the last run ends at 133)
 constexpr int C1_ROW_BYTES = C1_ROW_PX * 8;                      // 4 halves per pixel; 1072 B, 16-B aligned
-constexpr int C1_TILES_PER_WG = 8;                               // 16 output rows per workgroup
+constexpr int C1_TILES_PER_WG = 8;                               // 16 output rows per workgroup (large batches; small ones: one tile, 32 workgroups per image)
 
 template <int C1_KH, int C1_PAD, int NCO>
 __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __restrict__ x, int N, const Conv1Groups G,
-                                                             int act, float alpha, float* __restrict__ out)
+                                                             int act, float alpha, float* __restrict__ out, int tiles_per_wg)
 {
     constexpr int C1_ROWS_IN = (C1_ROWS_OUT - 1) * 2 + C1_KH;        // 9 / 7 input rows
     constexpr int C1_PLANE = C1_ROWS_IN * C1_ROW_BYTES;              // hi plane, then lo plane
@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
     char* xs = smem + C1_W_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wgs_per_img = C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG);
+    const int wgs_per_img = C1_HOUT / (C1_ROWS_OUT * tiles_per_wg);
     const int n = blockIdx.x / wgs_per_img;
-    const int oy_base = (blockIdx.x - n * wgs_per_img) * C1_ROWS_OUT * C1_TILES_PER_WG;
+    const int oy_base = (blockIdx.x - n * wgs_per_img) * C1_ROWS_OUT * tiles_per_wg;
     int g = 0;                                  // object of this sample (mixed batches: groups are runs of samples)
     while (g + 1 < G.n_groups && G.start[g + 1] <= n) ++g;
     const float* __restrict__ w_alt = G.w[g] + (size_t)blockIdx.y * (C1_W_BYTES / 4);
@@ -103,12 +103,12 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
     const char* wb = ws + lg * (C1_COUT * 16) + li * 16;
 
     gload(oy_base);
-    for (int t = 0; t < C1_TILES_PER_WG; ++t) {
+    for (int t = 0; t < tiles_per_wg; ++t) {
         const int oy0 = oy_base + t * C1_ROWS_OUT;
         __syncthreads();                     // previous tile's reads (and the initial fills) are done
         lstore();
         __syncthreads();
-        if (t + 1 < C1_TILES_PER_WG) gload(oy0 + C1_ROWS_OUT);
+        if (t + 1 < tiles_per_wg) gload(oy0 + C1_ROWS_OUT);
 
         f32x4 acc[2][4];
 #pragma unroll
@@ -176,9 +176,12 @@ hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Con
     if (N <= 0) return hipSuccess;
     if (!conv1_f16x3_supported(KH, Cout) || G.n_groups < 1 || G.n_groups > IGEMM_MAX_GROUPS) return hipErrorInvalidValue;
     if ((size_t)N * C1_HIN * C1_HIN * 12 >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
-    const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG));
-    if (KH == 7) hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out);
-    else hipLaunchKernelGGL((conv1_f16x3_kernel<5, 1, 128>), dim3(wgs, 2), dim3(256), 0, s, x, N, G, act, alpha, out);
+    // a handful of images (one detection at a time): one 2-row tile per workgroup so that the layer covers the chip
+    // (an output pixel is computed the same way whichever workgroup owns its row)
+    const int tpw = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG)) >= 64 ? C1_TILES_PER_WG : (N >= 4 ? 2 : 1);
+    const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * tpw));
+    if (KH == 7) hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw);
+    else hipLaunchKernelGGL((conv1_f16x3_kernel<5, 1, 128>), dim3(wgs, 2), dim3(256), 0, s, x, N, G, act, alpha, out, tpw);
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int HEADS_TH = 4;                 // grid rows per step (one per wave)
-constexpr int HEADS_TILES = 4;              // steps a workgroup walks: 16 consecutive grid rows of one sample
+constexpr int HEADS_TILES_BIG = 4;          // steps a workgroup walks: 16 consecutive grid rows of one sample (template HEADS_TILES; 1 for small launches)
 constexpr int HEADS_W = 64;                 // grid width (full rows: the x halo is the zero padding)
 constexpr int HEADS_WP = HEADS_W + 2;
 constexpr int HEADS_RING = HEADS_TH + 2;    // LDS row ring: the 6 input rows a step reads; 4 of them are replaced per step
@@ -52,6 +52,7 @@ static_assert(HEADS_P1 >= HEADS_PLANE && HEADS_P1 % 256 == 0 && (HEADS_P3 - HEAD
 
 __device__ inline int heads_plane(int c) { return c == 0 ? 0 : c == 1 ? HEADS_P1 : c == 2 ? HEADS_P2 : HEADS_P3; }
 
+template <int HEADS_TILES>
 __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[HEADS_SMEM];
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
 
 bool heads_halo_supported(const IgemmParams& p)
 {
-    return p.prec == PREC_F16X3 && p.mode == EPI_HEAD && p.ntaps == 9 && p.Cout == 16 && p.Wg == HEADS_W && p.Hg % (HEADS_TH * HEADS_TILES) == 0 &&
+    return p.prec == PREC_F16X3 && p.mode == EPI_HEAD && p.ntaps == 9 && p.Cout == 16 && p.Wg == HEADS_W && p.Hg % (HEADS_TH * HEADS_TILES_BIG) == 0 &&
            p.Hin == p.Hg && p.Win == p.Wg && p.in_stride == 1 && p.os == 2 && p.Hout == 2 * p.Hg && p.Wout == 2 * p.Wg &&
            p.seg[0].C == HEADS_CIN && p.seg[0].cstride == HEADS_CIN && p.seg[0].coff == 0 && p.seg[1].C == 0 && p.ksplit <= 1 &&
            p.dy[0] == -1 && p.dx[0] == -1 && p.dy[8] == 1 && p.dx[8] == 1;
@@ -222,9 +223,13 @@ bool heads_halo_supported(const IgemmParams& p)
 
 hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s)
 {
-    const int n_wgs = p.N * (p.Hg / (HEADS_TH * HEADS_TILES));
+    // few samples: one 4-row step per workgroup (16 workgroups per sample instead of 4); an output pixel's chain of MFMAs over
+    // (slice, tap) is the same either way
+    const bool small = p.N * (p.Hg / (HEADS_TH * HEADS_TILES_BIG)) < 64;
+    const int n_wgs = p.N * (p.Hg / (HEADS_TH * (small ? 1 : HEADS_TILES_BIG)));
     const int per_xcd = (n_wgs + 7) / 8;
-    hipLaunchKernelGGL(heads_halo_kernel, dim3(per_xcd * 8), dim3(256), 0, s, p);
+    if (small) hipLaunchKernelGGL(heads_halo_kernel<1>, dim3(per_xcd * 8), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(heads_halo_kernel<HEADS_TILES_BIG>, dim3(per_xcd * 8), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@
 // is exactly the four b128 fragments a lane needs.  K-step order comes from a table (StreamOrder) describing the batched
 // kernel's loop nest: groups of taps, and inside a group (channel slice, tap).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace p2p {
 
@@ -53,22 +54,34 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, 
 }
 
 template <int TM, int TN, int D>
-__global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, const StreamOrder o)
+__global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, const StreamMulti mp)
 {
     __shared__ int2 s_step[MAX_STEPS];         // x: byte shift of the A gather (tap shift + channel slice), y: weight K offset (bytes) | tap << 24 | segment << 31
 
     const int lane = threadIdx.x;
     const int li = lane & 31, lk = lane >> 5;
+    // blockIdx.y: the sub-problem of a merged launch (the four phases of a transposed convolution: same input, same grid, own
+    // weight panel / taps / output phase), or the K range of a split-K launch
+    const StreamPhase& P = mp.ph[mp.n > 1 ? blockIdx.y : 0];
+    const StreamOrder& o = P.o;
     const int tiles_n = p.Cout / (TN * 32);
     const int tile_n = blockIdx.x % tiles_n;
     const int tile_m = blockIdx.x / tiles_n;
     const int n0 = tile_n * TN * 32;
     const int m0 = tile_m * TM * 32;
     const int cpt = p.chunks_per_tap;
-    const int total = p.ntaps * cpt;
+    const int ntaps = P.ntaps;
+    // split-K (dense_enc): this wave walks K-steps [ks0, ks0 + total) of the layer and stores raw partial sums
+    int ks0 = 0, total = ntaps * cpt;
+    if (p.ksplit > 1) {
+        const int ks_per = (p.ksteps + p.ksplit - 1) / p.ksplit;
+        ks0 = blockIdx.y * ks_per;
+        total = max(0, min(p.ksteps, ks0 + ks_per) - ks0);
+    }
 
     // ---- K-step table: step -> (group, slice, tap of the group), the batched kernel's loop nest
-    for (int idx = lane; idx < total; idx += 64) {
+    for (int i = lane; i < total; i += 64) {
+        const int idx = ks0 + i;
         int g = 0;
         while (g + 1 < o.n_groups && (int)o.gstart[g + 1] * cpt <= idx) ++g;
         const int ng = (int)o.gstart[g + 1] - (int)o.gstart[g];
@@ -76,10 +89,10 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
         const int chunk = r / ng, k = r - chunk * ng;
         const int tap = o.tap[o.gstart[g] + k];
         const bool s1 = chunk >= p.seg0_chunks;
-        const int shift_px = p.seg1_stride && s1 ? 0 : (int)p.dy[tap] * p.Win + (int)p.dx[tap];
+        const int shift_px = p.seg1_stride && s1 ? 0 : (int)P.dy[tap] * p.Win + (int)P.dx[tap];
         const int a_toff = (shift_px * (s1 ? p.seg[1].cstride : p.seg[0].cstride) + (s1 ? chunk - p.seg0_chunks : chunk) * IGEMM_BK) * 4;
         const int koff = (tap * cpt + chunk) * (IGEMM_BK * 4);
-        s_step[idx] = make_int2(a_toff, koff | (tap << 24) | (s1 ? (int)0x80000000 : 0));
+        s_step[i] = make_int2(a_toff, koff | (tap << 24) | (s1 ? (int)0x80000000 : 0));
     }
 
     // ---- rows of this wave: lane & 31 of each 32-row sub-tile
@@ -103,20 +116,20 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
             const unsigned pix1 = p.seg1_stride ? (unsigned)((n * p.seg1_Hin + gy * p.seg1_stride) * p.seg1_Win + gx * p.seg1_stride) : pix;
             a_off1[i] = (pix1 * (unsigned)p.seg[1].cstride + (unsigned)(p.seg[1].coff + lk * 8)) * 4u;
             unsigned mk = 0;
-            for (int t = 0; t < p.ntaps; ++t) {
-                const int iy = iy0 + (int)p.dy[t], ix = ix0 + (int)p.dx[t];
+            for (int t = 0; t < ntaps; ++t) {
+                const int iy = iy0 + (int)P.dy[t], ix = ix0 + (int)P.dx[t];
                 if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) mk |= 1u << t;
             }
             a_mask[i] = mk;
-            opx[i] = (n * p.Hout + gy * p.os + p.oy) * p.Wout + gx * p.os + p.ox;
+            opx[i] = p.ksplit > 1 ? m : (n * p.Hout + gy * p.os + P.oy) * p.Wout + gx * p.os + P.ox;
         }
     }
     unsigned b_off[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b_off[j] = ((unsigned)(n0 + j * 32 + li) * (unsigned)p.K + (unsigned)(lk * 4)) * 4u;
+    for (int j = 0; j < TN; ++j) b_off[j] = ((unsigned)(n0 + j * 32 + li) * (unsigned)P.K + (unsigned)(lk * 4)) * 4u;
     const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].ptr, 0, p.seg_bytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.seg[1].ptr ? p.seg[1].ptr : p.seg[0].ptr), 0, p.seg_bytes[1], 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, P.w_bytes, 0x00020000);
 
     __syncthreads();               // one wave: orders the table writes before the reads
 
@@ -201,11 +214,23 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     //      Same expression as the batched kernels: fmaf(acc, scale, shift) + residual, activation.
+    if (p.ksplit > 1) {            // raw partial sums [split][m][Cout]; scale / shift / activation belong to the reduction
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = __shfl(opx[i], (r & 3) + 8 * (r >> 2) + 4 * lk, 64);
+                    if (m >= 0) p.partial[((size_t)blockIdx.y * p.M + m) * p.Cout + n0 + j * 32 + li] = acc[i][j][r];
+                }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + j * 32 + li;
-        const float sc = p.scale ? p.scale[col] : 1.f;
-        const float sh = p.shift ? p.shift[col] : 0.f;
+        const float sc = P.scale ? P.scale[col] : 1.f;
+        const float sh = P.shift ? P.shift[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             int ops[16];
@@ -234,11 +259,14 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
 
 }  // namespace
 
+static int stream_depth() { static const int v = getenv("P2P_STREAM_D") ? atoi(getenv("P2P_STREAM_D")) : 0; return v; }
+
 bool igemm_stream_supported(const IgemmParams& p)
 {
-    if (p.prec != PREC_F16X3 || p.mode != EPI_NORMAL || p.ksplit > 1 || p.n_groups > 1) return false;
-    if (p.Cout % 32 || p.ntaps * p.chunks_per_tap > MAX_STEPS || p.ntaps > IGEMM_MAX_TAPS) return false;
-    if (p.seg_bytes[0] >= 0x7FFFFF00u || p.seg_bytes[1] >= 0x7FFFFF00u || p.w_bytes >= 0x7FFFFF00u || p.K * 4 >= (1 << 24)) return false;
+    if (p.prec != PREC_F16X3 || p.mode != EPI_NORMAL || p.n_groups > 1) return false;
+    const int steps = p.ksplit > 1 ? (p.ksteps + p.ksplit - 1) / p.ksplit : p.ntaps * p.chunks_per_tap;
+    if (p.Cout % 32 || steps > MAX_STEPS || p.ntaps > IGEMM_MAX_TAPS) return false;
+    if (p.seg_bytes[0] >= 0x7FFFFF00u || p.seg_bytes[1] >= 0x7FFFFF00u || p.w_bytes >= 0x7FFFFF00u || (long long)p.K * 4 >= (1 << 24)) return false;
     return true;
 }
 
@@ -247,13 +275,28 @@ int igemm_stream_waves(const IgemmParams& p, int tm)
     return ((p.M + 32 * tm - 1) / (32 * tm)) * (p.Cout / 32);
 }
 
-hipError_t launch_igemm_stream(const IgemmParams& p, const StreamOrder& o, hipStream_t s)
+void stream_phase_of(const IgemmParams& p, const StreamOrder& o, StreamPhase* ph)
 {
+    ph->w = p.w; ph->scale = p.scale; ph->shift = p.shift;
+    ph->w_bytes = p.w_bytes; ph->K = p.K; ph->ntaps = p.ntaps; ph->oy = p.oy; ph->ox = p.ox;
+    for (int t = 0; t < IGEMM_MAX_TAPS + 3; ++t) { ph->dy[t] = p.dy[t]; ph->dx[t] = p.dx[t]; }
+    ph->o = o;
+}
+
+// mp.n == 1: the launch p describes (mp.ph[0] = stream_phase_of(p)); mp.n > 1: mp.n sub-problems that share p's input, grid, Cout and
+// epilogue and differ in weight panel, taps and output phase -- the phases of a transposed convolution in one launch
+hipError_t launch_igemm_stream(const IgemmParams& p, const StreamMulti& mp, hipStream_t s)
+{
+    const int ny = mp.n > 1 ? mp.n : (p.ksplit > 1 ? p.ksplit : 1);
     // 64 x 32 tiles once the 32 x 32 ones would put more than ~3 waves on every CU (the weight fragments are then shared by two row blocks)
-    if (igemm_stream_waves(p, 1) > 768) {
-        hipLaunchKernelGGL((igemm_stream_kernel<2, 1, 4>), dim3(igemm_stream_waves(p, 2)), dim3(64), 0, s, p, o);
+    if (igemm_stream_waves(p, 1) * ny > 768) {
+        hipLaunchKernelGGL((igemm_stream_kernel<2, 1, 4>), dim3(igemm_stream_waves(p, 2), ny), dim3(64), 0, s, p, mp);
+    } else if (stream_depth() == 8) {
+        hipLaunchKernelGGL((igemm_stream_kernel<1, 1, 8>), dim3(igemm_stream_waves(p, 1), ny), dim3(64), 0, s, p, mp);
+    } else if (stream_depth() == 12) {
+        hipLaunchKernelGGL((igemm_stream_kernel<1, 1, 12>), dim3(igemm_stream_waves(p, 1), ny), dim3(64), 0, s, p, mp);
     } else {
-        hipLaunchKernelGGL((igemm_stream_kernel<1, 1, 6>), dim3(igemm_stream_waves(p, 1)), dim3(64), 0, s, p, o);
+        hipLaunchKernelGGL((igemm_stream_kernel<1, 1, 6>), dim3(igemm_stream_waves(p, 1), ny), dim3(64), 0, s, p, mp);
     }
     return hipGetLastError();
 }

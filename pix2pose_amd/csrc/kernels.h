@@ -102,8 +102,24 @@ struct StreamOrder {
     int8_t gstart[IGEMM_MAX_TAPS + 3];     // group g = entries [gstart[g], gstart[g + 1]) of tap[]
     int8_t tap[IGEMM_MAX_TAPS + 3];        // panel tap indices
 };
+// What differs between the sub-problems of a merged launch (the four phases of a transposed convolution).
+struct StreamPhase {
+    const float* w;
+    const float* scale;
+    const float* shift;
+    unsigned w_bytes;
+    int K, ntaps, oy, ox;
+    int8_t dy[IGEMM_MAX_TAPS + 3];
+    int8_t dx[IGEMM_MAX_TAPS + 3];
+    StreamOrder o;
+};
+struct StreamMulti {
+    int n;
+    StreamPhase ph[4];
+};
 bool igemm_stream_supported(const IgemmParams& p);
-hipError_t launch_igemm_stream(const IgemmParams& p, const StreamOrder& o, hipStream_t s);
+void stream_phase_of(const IgemmParams& p, const StreamOrder& o, StreamPhase* ph);
+hipError_t launch_igemm_stream(const IgemmParams& p, const StreamMulti& mp, hipStream_t s);
 
 // Halo-tiled kernel for the merged output heads (heads.hip); takes the same parameter block as the
 // generic kernel when heads_halo_supported() says so (PREC_F16X3, 64-wide grid, 128 input channels).

@@ -541,10 +541,18 @@ struct ConvCall {
     int s1_Hin = 0, s1_Win = 0, s1_stride = 0;   // segment 1 on its own (strided) grid; 1-tap layers only
 };
 
-static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
-{
-    hipStream_t st = X.cur->stream;
+// A launch ready to go: parameter block, route and (streaming route) K-step order.
+struct PreparedConv {
     IgemmParams p;
+    StreamOrder so;
+    bool stream = false, halo = false, halo_conv = false, halo8 = false, halo_s2 = false;
+    int cfg = 0, prof_slot = 0;
+    double flops = 0;
+};
+
+static int prepare_conv(Ctx& X, const ConvLayer& L, const ConvCall& c, PreparedConv& pc)
+{
+    IgemmParams& p = pc.p;
     memset(&p, 0, sizeof(p));
     p.seg[0] = {c.s0.ptr, c.s0.C, c.s0.cstride, c.s0.coff};
     p.seg[1] = {c.s1.ptr, c.s1.C, c.s1.cstride, c.s1.coff};
@@ -606,8 +614,9 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     const bool halo_s2 = !halo && !halo_conv && !halo8 && specialised_kernels() && igemm_halo_s2_supported(p);   // 5x5 stride 2 on larger grids (igemm_halo_s2.hip)
     // Small launches (one detection at a time: the reference's own caller) go to the streaming kernel, which gives every 32x32 output
     // tile its own wave and walks K in the SAME order as the batched kernel chosen above -- so the bits do not depend on the route.
-    StreamOrder so;
+    StreamOrder& so = pc.so;
     bool stream = false;
+    memset(&so, 0, sizeof(so));
     if (!halo && stream_max_wgs() > 0 && igemm_stream_supported(p)) {
         int grid;         // workgroups of the batched kernel
         if (halo_conv) {
@@ -615,10 +624,11 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
             grid = L.Cout % 128 == 0 ? m_tiles * (L.Cout / 128) : (c.Hg % 16 == 0 ? m_tiles / 2 : m_tiles) * (L.Cout / 64);
         } else if (halo8) grid = ((p.M + 127) / 128) * (L.Cout / 128);
         else if (halo_s2) grid = c.N * (c.Hg / 8) * (c.Wg / 16) * (L.Cout / 128);
-        else grid = ((p.M + 127) / 128) * ((L.Cout + (cfg == 0 ? 127 : cfg == 1 ? 63 : 31)) / (cfg == 0 ? 128 : cfg == 1 ? 64 : 32));
+        else grid = ((p.M + 127) / 128) * ((L.Cout + (cfg == 0 ? 127 : cfg == 1 ? 63 : 31)) / (cfg == 0 ? 128 : cfg == 1 ? 64 : 32)) * std::max(1, c.ksplit);
+        // split-K launches keep their K partition (it is a property of the layer, so the partial sums and their reduction order
+        // are the same on both routes); the streaming route only changes who computes a partial tile
         if (grid <= stream_max_wgs()) {
             stream = true;
-            memset(&so, 0, sizeof(so));
             if (halo_conv || (halo8 && igemm_halo8_mode(p) == 1)) {          // (slice, tap)
                 so.n_groups = 1;
                 so.gstart[1] = (int8_t)L.ntaps;
@@ -639,11 +649,29 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
             }
         }
     }
-    auto launch = [&]() { return stream ? launch_igemm_stream(p, so, st) : halo ? launch_heads_halo(p, st) : halo_conv ? launch_igemm_halo(p, st) :
-                                 halo8 ? launch_igemm_halo8(p, st) : halo_s2 ? launch_igemm_halo_s2(p, st) : launch_igemm(p, cfg, st); };
+    pc.stream = stream; pc.halo = halo; pc.halo_conv = halo_conv; pc.halo8 = halo8; pc.halo_s2 = halo_s2; pc.cfg = cfg;
+    pc.prof_slot = stream ? 8 : halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : halo8 ? 6 : halo_s2 ? 7 : cfg;
+    pc.flops = 2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K);
+    return P2P_OK;
+}
+
+// n == 1: the prepared launch; n > 1 (streaming route only): the launches share input, grid and epilogue -- one merged launch
+static int launch_prepared(Ctx& X, const PreparedConv* pc, int n)
+{
+    hipStream_t st = X.cur->stream;
+    const PreparedConv& c0 = pc[0];
+    StreamMulti mp;
+    if (c0.stream) {
+        mp.n = n;
+        for (int i = 0; i < n; ++i) stream_phase_of(pc[i].p, pc[i].so, &mp.ph[i]);
+    } else if (n != 1) { set_error("launch_prepared: only streaming launches merge"); return P2P_ERR_INVALID_ARG; }
+    const IgemmParams& p = c0.p;
+    auto launch = [&]() { return c0.stream ? launch_igemm_stream(p, mp, st) : c0.halo ? launch_heads_halo(p, st) : c0.halo_conv ? launch_igemm_halo(p, st) :
+                                 c0.halo8 ? launch_igemm_halo8(p, st) : c0.halo_s2 ? launch_igemm_halo_s2(p, st) : launch_igemm(p, c0.cfg, st); };
     if (X.profiling) {
-        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), stream ? 8 : halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : halo8 ? 6 : halo_s2 ? 7 : cfg,
-                          2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K)};
+        double fl = 0;
+        for (int i = 0; i < n; ++i) fl += pc[i].flops;
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), c0.prof_slot, fl};
         if (!ev.a || !ev.b) return P2P_ERR_HIP;
         HIP_TRY(hipEventRecord(ev.a, st));
         HIP_TRY(launch());
@@ -653,6 +681,14 @@ static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
     }
     HIP_TRY(launch());
     return P2P_OK;
+}
+
+static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
+{
+    PreparedConv pc;
+    int rc = prepare_conv(X, L, c, pc);
+    if (rc) return rc;
+    return launch_prepared(X, &pc, 1);
 }
 
 // stride-1/2 Conv2D on a full tensor `in` [N,H,W,C] -> out [N,H/s,W/s,Cout]
@@ -684,6 +720,8 @@ static int concat_conv(Ctx& X, const ConvLayer& L, const float* a, int Ca, const
 static int deconv_layer(Ctx& X, const Model& M, const char* name, const float* in, int N, int H, int C,
                         float* out)
 {
+    PreparedConv pc[4];
+    bool all_stream = true;
     for (int ph = 0; ph < 4; ++ph) {
         const ConvLayer& L = M.L.at(std::string(name) + "_p" + std::to_string(ph));
         ConvCall c;
@@ -692,7 +730,13 @@ static int deconv_layer(Ctx& X, const Model& M, const char* name, const float* i
         c.out = out; c.Hout = 2 * H; c.Wout = 2 * H; c.os = 2; c.oy = ph >> 1; c.ox = ph & 1;
         c.out_cstride = L.Cout;
         c.act = ACT_LEAKY;
-        int rc = run_conv(X, L, c);
+        int rc = prepare_conv(X, L, c, pc[ph]);
+        if (rc) return rc;
+        all_stream = all_stream && pc[ph].stream;
+    }
+    if (all_stream) return launch_prepared(X, pc, 4);          // small launches: the four phases in ONE launch (blockIdx.y = phase)
+    for (int ph = 0; ph < 4; ++ph) {
+        int rc = launch_prepared(X, &pc[ph], 1);
         if (rc) return rc;
     }
     return P2P_OK;

@@ -1,4 +1,2 @@
-set -x
-timeout 900 python -m pytest tests/test_stream_gpu.py tests/test_ae_gpu.py -x -q 2>&1 | tail -15
-timeout 300 python tools/time_small.py resnet50 50 2>&1 | tail -12
-P2P_STREAM_WGS=0 timeout 300 python tools/time_small.py resnet50 50 2>&1 | tail -12
+timeout 1200 python -m pytest tests/test_pnp_gpu.py tests/test_est_pose_gpu.py tests/test_golden_gpu.py -x -q 2>&1 | tail -5
+python tools/single_det.py 100
