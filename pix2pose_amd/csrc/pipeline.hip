@@ -228,8 +228,10 @@ __global__ __launch_bounds__(256) void stage1_input_kernel(const DetInfo* __rest
 // ------------------------------------------------------------------------------------------
 // K3: stage-1 reductions + stage-2 geometry  (recognition.py:89-110)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stage1_stats_kernel(const DetInfo* __restrict__ dets, const float* __restrict__ y1,
-                                                           Stage1* __restrict__ s1)
+// (blockDim.x = 256, or 1024 for a handful of detections: one workgroup per detection walks 16 384 pixels, and with one detection at a
+// time -- the reference's caller -- its 64 trips were 50 us of the call)
+__global__ __launch_bounds__(1024) void stage1_stats_kernel(const DetInfo* __restrict__ dets, const float* __restrict__ y1,
+                                                            Stage1* __restrict__ s1)
 {
     __shared__ int s_n, s_minv, s_minu, s_maxv, s_maxu, s_sv, s_su;
     __shared__ int s_keep[MAX_TH];
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void stage1_stats_kernel(const DetInfo* __rest
 #pragma unroll
     for (int k = 0; k < MAX_TH; ++k) keep[k] = 0;
     const float* y = y1 + (size_t)d * 16384 * 4;
-    for (int p = tid; p < 16384; p += 256) {
+    for (int p = tid; p < 16384; p += blockDim.x) {
         const float4 q = reinterpret_cast<const float4*>(y)[p];
         const float v4[4] = {q.x, q.y, q.z, q.w};
         if (!non_gray_at(v4)) continue;
@@ -436,12 +438,12 @@ __device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const
 }
 
 // [min, max] of the raw 128x128 maps of every candidate (the warp inputs when no anti-aliasing filter ran)
-__global__ __launch_bounds__(256) void cand_range_kernel(const float* __restrict__ y2, CandRange* __restrict__ out)
+__global__ __launch_bounds__(1024) void cand_range_kernel(const float* __restrict__ y2, CandRange* __restrict__ out)
 {
-    __shared__ double s_v[4][6];
+    __shared__ double s_v[16][6];
     const float* y2c = y2 + (size_t)blockIdx.x * 16384 * 4;
     double v[6] = {1e300, -1e300, 1e300, -1e300, 1e300, -1e300};
-    for (int p = threadIdx.x; p < 16384; p += 256) {
+    for (int p = threadIdx.x; p < 16384; p += blockDim.x) {
         double prob, ng, pred[3];
         cand_raw(y2c + (size_t)p * 4, &prob, &ng, pred);
         v[0] = fmin(v[0], prob); v[1] = fmax(v[1], prob);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256) void cand_range_kernel(const float* __restrict
         for (int k = 0; k < 6; ++k) s_v[threadIdx.x >> 6][k] = v[k];
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
             for (int k = 0; k < 6; ++k) v[k] = (k & 1) ? fmax(v[k], s_v[w][k]) : fmin(v[k], s_v[w][k]);
         CandRange R;
         R.pmin = v[0]; R.pmax = v[1]; R.qmin = v[2]; R.qmax = v[3]; R.gmin = v[4]; R.gmax = v[5];
@@ -468,12 +470,13 @@ __global__ __launch_bounds__(256) void cand_range_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 // K6: correspondences per candidate, compacted in row-major order  (recognition.py:134-151,196-213)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cand_corr_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
-                                                        const float* __restrict__ y2, int K, float* __restrict__ corr,
-                                                        CandStat* __restrict__ cstat, PnpProblem* __restrict__ probs,
-                                                        const CandRange* __restrict__ crange, AaPtrs aa)
+__global__ __launch_bounds__(1024) void cand_corr_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
+                                                         const float* __restrict__ y2, int K, float* __restrict__ corr,
+                                                         CandStat* __restrict__ cstat, PnpProblem* __restrict__ probs,
+                                                         const CandRange* __restrict__ crange, AaPtrs aa)
 {
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[16];
+    const int NT = blockDim.x, n_waves = NT >> 6;      // 256 threads, or 1024 for a handful of candidates (a 128-px candidate = 64 trips of 256)
     __shared__ int s_ng;
     __shared__ unsigned long long s_sv, s_su;
     const int cand = blockIdx.x;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void cand_corr_kernel(const DetInfo* __restric
         unsigned long long sv = 0, su = 0;
         float* PX = pts; float* PY = pts + D.corr_cap; float* PZ = pts + 2 * (size_t)D.corr_cap;
         float* PU = pts + 3 * (size_t)D.corr_cap; float* PV = pts + 4 * (size_t)D.corr_cap;
-        for (int base = 0; base < npx; base += 256) {
+        for (int base = 0; base < npx; base += NT) {
             const int p = base + tid;
             bool valid = false;
             CandPixel cp;
@@ -512,9 +515,11 @@ __global__ __launch_bounds__(256) void cand_corr_kernel(const DetInfo* __restric
             const int before = __popcll(bal & ((1ULL << lane) - 1ULL));
             if (lane == 0) s_wave[wave] = __popcll(bal);
             __syncthreads();
-            int off = total;
-            for (int k = 0; k < wave; ++k) off += s_wave[k];
-            const int chunk = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            int off = total, chunk = 0;
+            for (int k = 0; k < n_waves; ++k) {
+                if (k < wave) off += s_wave[k];
+                chunk += s_wave[k];
+            }
             if (valid) {
                 const int o = off + before;       // o < corr_cap: the clipped stage-2 region fits the stage-1 square
                 for (int ch = 0; ch < 3; ++ch) {
@@ -1145,7 +1150,7 @@ static int enqueue_mid(Ctx& X, Slot& SL, hipStream_t st, float* y1)
     const DetInfo* d_det = SL.det.as<DetInfo>();
     Stage1* d_s1 = SL.s1.as<Stage1>();
     if (SL.opt.inject1 && (rc = inject_maps(SL, st, SL.opt.inject1, y1, 16384 * 4))) return rc;
-    hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(256), 0, st, d_det, y1, d_s1);
+    hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(n <= 64 ? 1024 : 256), 0, st, d_det, y1, d_s1);
     HIP_TRY(hipGetLastError());
     if (SL.use_aa) {      // anti-aliased keep masks (stage-1 sides < 128) and stage-2 canvases (sides > 128)
         AaTable aat;
@@ -1180,7 +1185,8 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
 
     // -- ranges of the back-resize inputs (clip=True), anti-aliased maps where the stage-2 side is < 128
     CandRange* d_cr = SL.crange.as<CandRange>();
-    hipLaunchKernelGGL(cand_range_kernel, dim3(n * K), dim3(256), 0, st, y2, d_cr);
+    const int glue_nt = n * K <= 64 ? 1024 : 256;      // per-candidate workgroups: wide when there are few of them
+    hipLaunchKernelGGL(cand_range_kernel, dim3(n * K), dim3(glue_nt), 0, st, y2, d_cr);
     HIP_TRY(hipGetLastError());
     if (SL.use_aa) {
         hipLaunchKernelGGL(aa_back_fill_kernel, dim3(64, n * K), dim3(256), 0, st, y2, aa);
@@ -1191,7 +1197,7 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
     }
 
     // -- correspondences, PnP-RANSAC, selection
-    hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
+    hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(glue_nt), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
                        SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>(), d_cr, aa);
     HIP_TRY(hipGetLastError());
     const int iters = opt.ransac_iterations > 0 ? opt.ransac_iterations : 100;

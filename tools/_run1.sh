@@ -1,2 +1,2 @@
-timeout 1200 python -m pytest tests/test_pnp_gpu.py tests/test_est_pose_gpu.py tests/test_golden_gpu.py -x -q 2>&1 | tail -5
+timeout 1500 python -m pytest tests/test_est_pose_gpu.py tests/test_golden_gpu.py tests/test_reference_vectors_gpu.py tests/test_misc_gpu.py -x -q 2>&1 | tail -3
 python tools/single_det.py 100
