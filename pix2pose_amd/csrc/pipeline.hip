@@ -990,35 +990,8 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
     SL.objs.assign(objects, objects + n_obj);
     SL.use_aa = opt.resize_anti_aliasing != 0;
 
-    // -- frames
-    std::vector<const void*> img_dev(n_img, nullptr);
-    {
-        size_t need = 0;
-        for (int i = 0; i < n_img; ++i) {
-            if (!images[i].data || images[i].height <= 0 || images[i].width <= 0) { set_error("image %d is empty", i); return P2P_ERR_INVALID_ARG; }
-            if (images[i].mem == P2P_MEM_HOST) need += ((size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1) + 255) / 256 * 256;
-        }
-        if ((rc = SL.images.reserve(need)) || (rc = SL.h_frames.reserve(need))) return rc;
-        // host frames (the reference's boundary: est_pose takes a numpy frame, recognition.py:70): the caller's pageable memory is
-        // copied into the slot's pinned staging buffer (a plain memcpy: the frames are free again when submit returns) and goes up
-        // as ONE DMA on its own stream, under the generator passes already queued on `st`; `st` waits for it before the first kernel.
-        // (hipMemcpyAsync straight from pageable memory cost 1.6 ms per 30 MB step even on a separate stream.)
-        size_t off = 0;
-        for (int i = 0; i < n_img; ++i) {
-            const size_t bytes = (size_t)images[i].height * images[i].width * 3 * (images[i].dtype ? 4 : 1);
-            if (images[i].mem == P2P_MEM_HOST) {
-                memcpy(SL.h_frames.as<char>() + off, images[i].data, bytes);
-                img_dev[i] = SL.images.as<char>() + off;
-                off += (bytes + 255) / 256 * 256;
-            } else
-                img_dev[i] = images[i].data;
-        }
-        if (need) {
-            HIP_TRY(hipMemcpyAsync(SL.images.p, SL.h_frames.p, need, hipMemcpyHostToDevice, P.copy_stream));
-            HIP_TRY(hipEventRecord(P.frames_ready, P.copy_stream));
-            HIP_TRY(hipStreamWaitEvent(st, P.frames_ready, 0));
-        }
-    }
+    for (int i = 0; i < n_img; ++i)
+        if (!images[i].data || images[i].height <= 0 || images[i].width <= 0) { set_error("image %d is empty", i); return P2P_ERR_INVALID_ARG; }
 
     // -- per-detection constants + stage-1 geometry (recognition.py:71-79)
     std::vector<DetInfo>& hd = SL.hd;
@@ -1032,7 +1005,7 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
         const p2p_image& im = images[dt.image];
         DetInfo& D = hd[i];
         memset(&D, 0, sizeof(D));
-        D.img = img_dev[dt.image];
+        D.img = nullptr;                    // set below, once the row ranges of the frames are known
         D.H = im.height; D.W = im.width; D.img_f32 = im.dtype == P2P_IMG_F32;
         D.obj = dt.object;
         D.src_index = perm[i];
@@ -1058,6 +1031,43 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
             cv_total += (long long)(1 + K) * D.corr_cap * 3;
         }
         if (D.ok1) max_side = std::max(max_side, (int)side);
+    }
+    // -- frames.  Host frames (the reference's boundary: est_pose takes a numpy frame, recognition.py:70): only the rows some detection's
+    // stage-1 crop covers are ever read (the stage-2 canvas is zero outside the stage-1 crop, recognition.py:105-106), so only those rows
+    // of the caller's pageable memory are copied into the slot's pinned staging buffer (a plain memcpy: the frames are free again when
+    // submit returns) -- packed, one row range per image -- and go up as ONE DMA on its own stream, under the generator passes already
+    // queued on `st`; `st` waits for it before the first kernel.  (hipMemcpyAsync straight from pageable memory cost 1.6 ms per 30 MB
+    // step even on a separate stream; whole frames instead of row ranges made one 128-px detection move 0.9 MB instead of 0.25.)
+    {
+        std::vector<int> r0(n_img, 1 << 30), r1(n_img, 0);
+        for (int i = 0; i < n; ++i) {
+            if (!hd[i].ok1) continue;
+            const int im = dets[perm[i]].image;
+            r0[im] = std::min(r0[im], hd[i].b1.v1);
+            r1[im] = std::max(r1[im], hd[i].b1.v2);
+        }
+        std::vector<const char*> img_dev(n_img, nullptr);
+        std::vector<size_t> off(n_img, 0);
+        size_t need = 0;
+        for (int i = 0; i < n_img; ++i) {
+            if (images[i].mem != P2P_MEM_HOST) { img_dev[i] = reinterpret_cast<const char*>(images[i].data); continue; }
+            if (r1[i] <= r0[i]) { r0[i] = r1[i] = 0; }
+            off[i] = need;
+            need += ((size_t)(r1[i] - r0[i]) * images[i].width * 3 * (images[i].dtype ? 4 : 1) + 255) / 256 * 256;
+        }
+        if ((rc = SL.images.reserve(need)) || (rc = SL.h_frames.reserve(need))) return rc;
+        for (int i = 0; i < n_img; ++i) {
+            if (images[i].mem != P2P_MEM_HOST) continue;
+            const size_t row = (size_t)images[i].width * 3 * (images[i].dtype ? 4 : 1);
+            memcpy(SL.h_frames.as<char>() + off[i], reinterpret_cast<const char*>(images[i].data) + (size_t)r0[i] * row, (size_t)(r1[i] - r0[i]) * row);
+            img_dev[i] = SL.images.as<char>() + off[i] - (size_t)r0[i] * row;      // address of the frame's row 0 (rows outside [r0, r1) are never read)
+        }
+        for (int i = 0; i < n; ++i) hd[i].img = img_dev[dets[perm[i]].image];
+        if (need) {
+            HIP_TRY(hipMemcpyAsync(SL.images.p, SL.h_frames.p, need, hipMemcpyHostToDevice, P.copy_stream));
+            HIP_TRY(hipEventRecord(P.frames_ready, P.copy_stream));
+            HIP_TRY(hipStreamWaitEvent(st, P.frames_ready, 0));
+        }
     }
     SL.max_side = max_side;
     SL.img_hw.resize(n);

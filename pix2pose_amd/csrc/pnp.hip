@@ -208,6 +208,148 @@ __device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N]
     }
 }
 
+// ---------------------------------------------------------------- 12x12 SVD on a LANE PAIR
+// The 12x12 Jacobi SVD of M^T M is most of an EPnP solve, and on one lane it is bound by instruction issue: the matrix alone is 288
+// registers -- more than the 256 architectural VGPRs, so every rotation shuffles rows through the accumulation registers -- and a
+// sweep is 66 pairs x ~600 instructions.  Here lanes (2h, 2h + 1) share one solve: lane `half` holds columns [6 half, 6 half + 6) of
+// every row (72 registers).  Products and rotations are per column (half the work per lane); the three sums of a pair -- the dot
+// product and the two squared norms -- are OpenCV's sequential sums over k = 0..11, so they stay ONE chain of additions in the
+// same order: lane 0 adds its six terms, hands the partial to lane 1 (DPP), which adds its six and hands the total back.  Same
+// operations on the same values in the same order => the same bits as jacobi_svd_t<12, 12, false>.
+__device__ __forceinline__ double xlane1(double v)          // the partner lane's value (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// s = 0; for k = 0..11: s += x_k   with x_k on lane k / 6 (x[k % 6]); both lanes get the result
+__device__ __forceinline__ double chain12(const double (&x)[6], const int half)
+{
+    double s = 0;
+#pragma unroll
+    for (int e = 0; e < 6; e++) s += x[e];          // meaningful on lane 0
+    double s2 = xlane1(s);                            // lane 1 continues from lane 0's partial
+#pragma unroll
+    for (int e = 0; e < 6; e++) s2 += x[e];         // meaningful on lane 1
+    const double t = xlane1(s2);
+    return half ? s2 : t;
+}
+
+// two such chains at once (independent: the additions interleave)
+__device__ __forceinline__ void chain12x2(const double (&x)[6], const double (&y)[6], const int half, double& sx, double& sy)
+{
+    double a = 0, b = 0;
+#pragma unroll
+    for (int e = 0; e < 6; e++) { a += x[e]; b += y[e]; }
+    double a2 = xlane1(a), b2 = xlane1(b);
+#pragma unroll
+    for (int e = 0; e < 6; e++) { a2 += x[e]; b2 += y[e]; }
+    const double ta = xlane1(a2), tb = xlane1(b2);
+    sx = half ? a2 : ta;
+    sy = half ? b2 : tb;
+}
+
+// A[i * 6 + e] = element (i, 6 half + e) of the row image (a symmetric matrix: rows == columns).  On exit the rows are the left singular
+// vectors (this lane's columns of them), W the singular values, descending.  Returns false when a singular value is (numerically) zero:
+// OpenCV then fills in pseudo-random directions -- the caller redoes the solve on the single-lane path, which implements that.
+__device__ __forceinline__ bool jacobi12_pair(double (&A)[72], double (&W)[12], const int half)
+{
+    const double eps = kDblEps * 10;
+    constexpr int max_iter = 30;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        double x[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) { const double t = A[i * 6 + e]; x[e] = t * t; }
+        W[i] = chain12(x, half);
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 11; i++)
+#pragma unroll
+            for (int j = i + 1; j < 12; j++) {
+                double a = W[i], b = W[j];
+                double x[6], y[6];
+#pragma unroll
+                for (int e = 0; e < 6; e++) x[e] = A[i * 6 + e] * A[j * 6 + e];
+                double p = chain12(x, half);
+                if (fabs(p) <= eps * sqrt_cr(a * b)) continue;           // the same decision on both lanes: p, a, b are the same values
+                p *= 2;
+                const double beta = a - b, gamma = sqrt_cr(p * p + beta * beta);
+                double c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt_cr(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt_cr((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+                    const double t0 = c * A[i * 6 + e] + s * A[j * 6 + e];
+                    const double t1 = -s * A[i * 6 + e] + c * A[j * 6 + e];
+                    A[i * 6 + e] = t0; A[j * 6 + e] = t1;
+                    x[e] = t0 * t0; y[e] = t1 * t1;
+                }
+                chain12x2(x, y, half, a, b);
+                W[i] = a; W[j] = b;
+                changed = true;
+            }
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        double x[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) { const double t = A[i * 6 + e]; x[e] = t * t; }
+        W[i] = sqrt_cr(chain12(x, half));
+    }
+    // selection sort, descending, as predicated swaps (see jacobi_svd_t); W is the same on both lanes, so are the swaps
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < 12; k++)
+            if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k = i + 1; k < 12; k++)
+            if (j == k) {
+                double t = W[i]; W[i] = W[k]; W[k] = t;
+#pragma unroll
+                for (int e = 0; e < 6; e++) { t = A[i * 6 + e]; A[i * 6 + e] = A[k * 6 + e]; A[k * 6 + e] = t; }
+            }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const double sd = W[i];
+        if (sd <= kDblMin) ok = false;
+        const double s = sd > kDblMin ? 1 / sd : 0.;
+#pragma unroll
+        for (int e = 0; e < 6; e++) A[i * 6 + e] *= s;
+    }
+    return ok;
+}
+
+// rows 8..11 of the left singular vectors with all twelve columns on both lanes: u8[r * 12 + k] = row 8 + r
+__device__ __forceinline__ void gather_rows8(const double (&A)[72], const int half, double (&u8)[48])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+            const double mine = A[(8 + r) * 6 + e], other = xlane1(mine);
+            u8[r * 12 + e] = half ? other : mine;
+            u8[r * 12 + 6 + e] = half ? mine : other;
+        }
+}
+
 // x = V diag(1/w) U^T b, singular values below sum(w)*2*eps dropped (OpenCV SVD back-substitution)
 template <int M, int N>
 __device__ __forceinline__ void svd_backsubst_t(const double (&w)[N], const double (&ut)[N * M], const double (&vt)[N * N],
@@ -364,9 +506,10 @@ __device__ void barycentric(const double* ci, const double cws[4][3], const doub
     a[0] = 1.0 - a[1] - a[2] - a[3];
 }
 
-__device__ void compute_L_6x10(const double* ut, double* l)
+// u8: rows 8..11 of the 12x12 left singular vectors (the four smallest singular values), 12 values each
+__device__ void compute_L_6x10(const double* u8, double* l)
 {
-    const double* v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    const double* v[4] = {u8 + 12 * 3, u8 + 12 * 2, u8 + 12 * 1, u8};
     double dv[4][6][3];
     #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -535,13 +678,13 @@ __device__ void gauss_newton(const double* l, const double* rho, double* betas)
     }
 }
 
-__device__ void compute_ccs(const double* betas, const double* ut, double ccs[4][3])
+__device__ void compute_ccs(const double* betas, const double* u8, double ccs[4][3])
 {
     #pragma unroll
     for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0.0;
     #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const double* v = ut + 12 * (11 - i);
+        const double* v = u8 + 12 * (3 - i);
         #pragma unroll
         for (int j = 0; j < 4; j++)
             #pragma unroll
@@ -573,7 +716,10 @@ __device__ void orientation(const double* abt, const double* pc0, const double* 
 
 // ---------------------------------------------------------------- 5-point EPnP, one lane, sequential
 // pws[15] (object, mm), us[10] (pixels).  Sequential summation order = OpenCV's.
-__device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout)
+// PAIR: lanes (2h, 2h + 1) run this together on the same inputs; the 12x12 SVD is shared between them (jacobi12_pair), everything
+// else is computed by both (same inputs, same bits).  half = lane & 1.
+template <bool PAIR>
+__device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout, const int half)
 {
     const int n = 5;
     double cws[4][3], c0[3] = {0, 0, 0}, ptp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -593,38 +739,82 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
             #pragma unroll
             for (int b = 0; b < 3; b++) ptp[a * 3 + b] += d[a] * d[b];
     }
+#ifdef P2P_PNP_TIMING
+    long long tk[8]; int nk = 0;
+    tk[nk++] = clock64();
+#endif
     control_points(c0, ptp, n, cws);
     double ci[9], alphas[20];
     cc_inverse(cws, ci);
+#ifdef P2P_PNP_TIMING
+    tk[nk++] = clock64();
+#endif
     #pragma unroll
     for (int i = 0; i < n; i++) barycentric(ci, cws, pws + 3 * i, alphas + 4 * i);
 
-    double mtm[144];
-    #pragma unroll
-    for (int k = 0; k < 144; k++) mtm[k] = 0;
-    #pragma unroll
-    for (int i = 0; i < n; i++) {
-        const double* a = alphas + 4 * i;
-        double m1[12], m2[12];
-        const double u = us[2 * i], v = us[2 * i + 1];
+    double u8[48];          // rows 8..11 of the left singular vectors of M^T M
+    bool solved = false;
+    if (PAIR) {
+        double A[72];       // this lane's six columns of M^T M (symmetric: rows == columns, the row image of A^T is the matrix itself)
         #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            m1[3 * j] = a[j] * cam.fu; m1[3 * j + 1] = 0.0; m1[3 * j + 2] = a[j] * (cam.uc - u);
-            m2[3 * j] = 0.0; m2[3 * j + 1] = a[j] * cam.fv; m2[3 * j + 2] = a[j] * (cam.vc - v);
+        for (int k = 0; k < 72; k++) A[k] = 0;
+        #pragma unroll
+        for (int i = 0; i < n; i++) {
+            const double* a = alphas + 4 * i;
+            double m1[12], m2[12], m1q[6], m2q[6];
+            const double u = us[2 * i], v = us[2 * i + 1];
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                m1[3 * j] = a[j] * cam.fu; m1[3 * j + 1] = 0.0; m1[3 * j + 2] = a[j] * (cam.uc - u);
+                m2[3 * j] = 0.0; m2[3 * j + 1] = a[j] * cam.fv; m2[3 * j + 2] = a[j] * (cam.vc - v);
+            }
+            #pragma unroll
+            for (int e = 0; e < 6; e++) { m1q[e] = half ? m1[6 + e] : m1[e]; m2q[e] = half ? m2[6 + e] : m2[e]; }
+            #pragma unroll
+            for (int p = 0; p < 12; p++)
+                #pragma unroll
+                for (int e = 0; e < 6; e++) A[p * 6 + e] += m1[p] * m1q[e];
+            #pragma unroll
+            for (int p = 0; p < 12; p++)
+                #pragma unroll
+                for (int e = 0; e < 6; e++) A[p * 6 + e] += m2[p] * m2q[e];
         }
-        #pragma unroll
-        for (int p = 0; p < 12; p++)
-            #pragma unroll
-            for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m1[p] * m1[q];
-        #pragma unroll
-        for (int p = 0; p < 12; p++)
-            #pragma unroll
-            for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m2[p] * m2[q];
+        double w12[12];
+        solved = jacobi12_pair(A, w12, half);
+        if (solved) gather_rows8(A, half, u8);
     }
-    double w12[12];
-    // symmetric matrix: rows == columns, so the row image of A^T is the matrix itself
-    jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
-    const double* ut = mtm;
+    if (!solved) {          // single-lane solve (not PAIR, or a zero singular value: OpenCV's random fill-in lives in jacobi_svd_t)
+        double mtm[144];
+        #pragma unroll
+        for (int k = 0; k < 144; k++) mtm[k] = 0;
+        #pragma unroll
+        for (int i = 0; i < n; i++) {
+            const double* a = alphas + 4 * i;
+            double m1[12], m2[12];
+            const double u = us[2 * i], v = us[2 * i + 1];
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                m1[3 * j] = a[j] * cam.fu; m1[3 * j + 1] = 0.0; m1[3 * j + 2] = a[j] * (cam.uc - u);
+                m2[3 * j] = 0.0; m2[3 * j + 1] = a[j] * cam.fv; m2[3 * j + 2] = a[j] * (cam.vc - v);
+            }
+            #pragma unroll
+            for (int p = 0; p < 12; p++)
+                #pragma unroll
+                for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m1[p] * m1[q];
+            #pragma unroll
+            for (int p = 0; p < 12; p++)
+                #pragma unroll
+                for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m2[p] * m2[q];
+        }
+        double w12[12];
+        jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
+        #pragma unroll
+        for (int k = 0; k < 48; k++) u8[k] = mtm[96 + k];
+    }
+    const double* ut = u8;
+#ifdef P2P_PNP_TIMING
+    tk[nk++] = clock64();
+#endif
 
     double l[60], rho[6];
     compute_L_6x10(ut, l);
@@ -677,6 +867,9 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
             const double u = us[2 * i], v = us[2 * i + 1];
             sum2 += sqrt_cr((u - ue) * (u - ue) + (v - ve) * (v - ve));
         }
+#ifdef P2P_PNP_TIMING
+        tk[nk++] = clock64();
+#endif
         const double err = sum2 / n;
         if (c == 1 || err < best_err) {
             best_err = err;
@@ -688,6 +881,10 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
             }
         }
     }
+#ifdef P2P_PNP_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("epnp5 cycles: setup %lld  mtm+svd12 %lld  case1 %lld  case2 %lld  case3 %lld\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
+#endif
 }
 
 // ---------------------------------------------------------------- workgroup reductions
@@ -765,7 +962,7 @@ struct PnpFit {
 // ALL problems are solved in one resident round.
 constexpr int SCORE_CHUNK = 8;   // hypotheses whose inlier counts are taken in one pass over the points (pnp_score_kernel)
 // Hypotheses are solved lazily in three rounds: RANSAC's adaptive bound stops long before 100 on good data (mean ~12 here), so
-// [0, 16) are solved first -- FOUR problems per wave, 16 lanes each: the inlined fp64 solver takes the whole 512-entry register
+// [0, 16) are solved first -- TWO problems per wave, 32 lanes (16 lane pairs) each: the inlined fp64 solver takes the whole 512-entry register
 // file, i.e. a resident wave blocks its SIMD for everything else, and a quarter of the waves blocks a quarter of the SIMD time --,
 // then [16, 64) and [64, iterations) only for the problems whose scoring ran past what it had (one problem per wave).
 constexpr int HYP_ROUND0 = 16, HYP_ROUND1 = 64;
@@ -780,7 +977,7 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     __shared__ int s_idx_wg[4][MAX_ITERS][5];    // per wave; ppb == 4: rows 16 sub + it (it < 16); ppb == 1: row it
     int (*s_idx)[5] = s_idx_wg[threadIdx.x >> 6];
     const int tid = threadIdx.x & 63;
-    const int lanes = 64 / ppb;                  // lanes per problem
+    const int lanes = 64 / ppb;                  // lanes per problem: TWO per hypothesis (lane pairs share the 12x12 SVD, jacobi12_pair)
     const int sub = tid / lanes, lane_in = tid - sub * lanes;
     // Round 0 takes the problems in order (and clears the lists of the later rounds); rounds 1 and 2 take theirs from the list the
     // scoring pass of the round before appended to (act: [count1, count2, list1[n], list2[n]]), so that the few problems still
@@ -826,8 +1023,10 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     }
     __syncthreads();
 
-    // ---- 2. hypotheses: one lane each
-    const int hi = h_begin + lane_in;
+    // ---- 2. hypotheses: one lane PAIR each; a wave's lane group walks its range in passes of lanes / 2
+    const int half = lane_in & 1;
+    for (int h0 = h_begin; h0 < h_end; h0 += lanes >> 1) {
+    const int hi = h0 + (lane_in >> 1);
     if (active && hi < h_end) {
         const float* PX = pb.pts;
         const float* PY = pb.pts + (size_t)pb.cap;
@@ -838,7 +1037,7 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
         const double ifx = 1. / pb.K[0], ify = 1. / pb.K[4];
         double pws[15], us[10];
         for (int i = 0; i < 5; i++) {
-            const int id = s_idx[row0 + (ppb > 1 ? lane_in : hi)][i];
+            const int id = s_idx[row0 + (ppb > 1 ? hi - h_begin : hi)][i];
             pws[3 * i] = PX[id]; pws[3 * i + 1] = PY[id]; pws[3 * i + 2] = PZ[id];
             // undistortPoints (identity distortion) stores float32 normalised coordinates; epnp re-applies fu, uc
             const double xn = (double)(float)(((double)PU[id] - pb.K[2]) * ifx);
@@ -847,12 +1046,15 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
             us[2 * i + 1] = yn * pb.K[4] + pb.K[5];
         }
         double R[9], t[3], rvec[3];
-        epnp5(cam, pws, us, R, t);
+        epnp5<true>(cam, pws, us, R, t, half);
         rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
         rodrigues_v2r(rvec, R);
-        double* h = hyp + ((size_t)prob * MAX_ITERS + hi) * 12;
-        for (int k = 0; k < 9; k++) h[k] = R[k];
-        for (int k = 0; k < 3; k++) h[9 + k] = t[k];
+        if (half == 0) {
+            double* h = hyp + ((size_t)prob * MAX_ITERS + hi) * 12;
+            for (int k = 0; k < 9; k++) h[k] = R[k];
+            for (int k = 0; k < 3; k++) h[9 + k] = t[k];
+        }
+    }
     }
 }
 
@@ -1119,6 +1321,18 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     }
 }
 
+// element (p, q) of M^T M from the Gram sums of pass B (p, q compile-time after unrolling)
+__device__ __forceinline__ double mtm_entry(const double (&g)[56], const Cam& cam, const int p, const int q)
+{
+    // pair index of (j,k), j <= k, in the order pass B enumerates them
+    constexpr int PAIR[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+    const int j = p / 3, rp = p - 3 * j, k = q / 3, rq = q - 3 * k, e = PAIR[j][k];
+    const double s0 = g[e], s1 = g[10 + e], s2 = g[20 + e], s3 = g[30 + e];
+    if (rp == 0) return rq == 0 ? cam.fu * cam.fu * s0 : rq == 1 ? 0.0 : cam.fu * s1;
+    if (rp == 1) return rq == 0 ? 0.0 : rq == 1 ? cam.fv * cam.fv * s0 : cam.fv * s2;
+    return rq == 0 ? cam.fu * s1 : rq == 1 ? cam.fv * s2 : s3;
+}
+
 // Kernel 3 of 4 -- the refit solve: one LANE per (problem, beta case) -- register-resident 12x12 SVD (computed by all three lanes
 // of a problem: same inputs, same bits), then this lane's betas, Gauss-Newton and absolute orientation.  The three cases used to
 // run one after the other on one lane; the kernel is a pure latency chain (the tail of a blocking call and of a single detection
@@ -1127,7 +1341,8 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
 __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
 {
     const int li = blockIdx.x * 256 + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
-    const int pi = li / 3, c = li - pi * 3;
+    const int half = li & 1, q = li >> 1;               // a lane PAIR per (problem, beta case): the pair shares the 12x12 SVD
+    const int pi = q / 3, c = q - pi * 3;
     if (pi >= n_problems) return;
     PnpFit& fit = fits[pi];
     if (fit.state != 0) return;
@@ -1141,23 +1356,31 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
 #pragma unroll
         for (int j = 0; j < 3; j++) cws[i][j] = fit.cws[3 * i + j];
     const int m = fit.max_good;
-    double mtm[144];
-    // pair index of (j,k), j <= k, in the order pass B enumerates them
-    constexpr int PAIR[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+    double u8[48];          // rows 8..11 of the left singular vectors of M^T M
+    bool solved = false;
+    {
+        double A[72], w12[12];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+        for (int p = 0; p < 12; p++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = PAIR[j][k];
-            const double s0 = g[e], s1 = g[10 + e], s2 = g[20 + e], s3 = g[30 + e];
-            const int o = (3 * j) * 12 + 3 * k;
-            mtm[o] = cam.fu * cam.fu * s0; mtm[o + 1] = 0;                     mtm[o + 2] = cam.fu * s1;
-            mtm[o + 12] = 0;               mtm[o + 13] = cam.fv * cam.fv * s0; mtm[o + 14] = cam.fv * s2;
-            mtm[o + 24] = cam.fu * s1;     mtm[o + 25] = cam.fv * s2;          mtm[o + 26] = s3;
-        }
-    double w12[12];
-    jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
-    const double* ut = mtm;
+            for (int e = 0; e < 6; e++) {
+                const double lo = mtm_entry(g, cam, p, e), hi = mtm_entry(g, cam, p, 6 + e);
+                A[p * 6 + e] = half ? hi : lo;
+            }
+        solved = jacobi12_pair(A, w12, half);
+        if (solved) gather_rows8(A, half, u8);
+    }
+    if (!solved) {          // a zero singular value: the single-lane routine has OpenCV's random fill-in
+        double mtm[144], w12[12];
+#pragma unroll
+        for (int p = 0; p < 12; p++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) mtm[p * 12 + k] = mtm_entry(g, cam, p, k);
+        jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
+#pragma unroll
+        for (int k = 0; k < 48; k++) u8[k] = mtm[96 + k];
+    }
+    const double* ut = u8;
     double l[60], rho[6];
     compute_L_6x10(ut, l);
     compute_rho(cws, rho);
@@ -1186,11 +1409,13 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
         }
         double R[3][3], t[3];
         orientation(abt, pc0, cws[0], R, t);
+        if (half == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < 3; i++) {
 #pragma unroll
-            for (int j = 0; j < 3; j++) fit.cand[12 * c + 3 * i + j] = R[i][j];
-            fit.cand[12 * c + 9 + i] = t[i];
+                for (int j = 0; j < 3; j++) fit.cand[12 * c + 3 * i + j] = R[i][j];
+                fit.cand[12 * c + 9 + i] = t[i];
+            }
         }
     }
 }
@@ -1269,7 +1494,7 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
     const int stops[3] = {pnp::HYP_ROUND0, pnp::HYP_ROUND1, pnp::MAX_ITERS};
     int h_begin = 0;
     for (int r = 0; r < 3; ++r) {
-        const int ppb = r == 0 ? 4 : 1;
+        const int ppb = r == 0 ? 2 : 1;
         hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(((n_problems + ppb - 1) / ppb + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
                            min_points, h_begin, stops[r], ppb, act, r);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1279,7 +1504,7 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
         h_begin = stops[r];
         if (iterations <= h_begin) break;
     }
-    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((3 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
+    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((6 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);
     return hipGetLastError();

@@ -32,4 +32,24 @@ for i in range(calls + 5):
     r = shim.est_pose(sc["images"][img_i], bbox)
     lat.append(time.perf_counter() - t1)
 lat = np.array(lat[5:]) * 1e3
+# where the host time goes: the C call alone (same arguments, marshalled once) against the whole shim call
+from pix2pose_amd import runtime, _lib
+import ctypes as C
+spec = shim._spec()
+img_i, _, bbox, K = sc["dets"][0]
+rgb = sc["images"][img_i]
+inj = dict(inject1=shim._inject[0], inject2=shim._inject[1], inject_slots=3)
+objs, imgs, dets, opts, extras, keep = runtime._marshal([spec], [rgb], [(0, 0, [int(b) for b in bbox], K)], inj["inject1"], inj["inject2"], 3, True, None, 0, 0.0, 0.0)
+poses = (_lib.Pose * 1)()
+tc = []
+for i in range(60):
+    t1 = time.perf_counter()
+    _lib.lib().p2p_est_pose_batch(ctx.handle, objs, 1, imgs, 1, dets, 1, poses, C.byref(opts))
+    tc.append(time.perf_counter() - t1)
+tm = []
+for i in range(60):
+    t1 = time.perf_counter()
+    runtime._marshal([spec], [rgb], [(0, 0, [int(b) for b in bbox], K)], inj["inject1"], inj["inject2"], 3, True, None, 0, 0.0, 0.0)
+    tm.append(time.perf_counter() - t1)
+print("C call alone: median %.3f ms; marshalling alone: %.3f ms" % (np.median(tc[10:]) * 1e3, np.median(tm[10:]) * 1e3))
 print("single est_pose: median %.3f ms  p10 %.3f  p90 %.3f  (%d calls)" % (np.median(lat), np.percentile(lat, 10), np.percentile(lat, 90), calls))
