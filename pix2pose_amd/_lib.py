@@ -139,8 +139,10 @@ def _stale_reason_of(L):
     if not hasattr(L, "p2p_build_id"):
         return "no build id"
     L.p2p_build_id.restype = C.c_char_p
-    if "P2P_LIB" not in os.environ:          # an explicitly named A/B build is taken as is
-        from . import build as _build
+    from . import build as _build
+    # (an explicitly named A/B build is taken as is; a deployment that ships the .so without its sources has nothing to compare
+    # with -- the ABI version and struct sizes below still guard the binding)
+    if "P2P_LIB" not in os.environ and _build.have_sources():
         want = _build.source_hash()
         got = (L.p2p_build_id() or b"").decode()
         if got != want:

@@ -1279,7 +1279,12 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         HIP_TRY(hipEventCreateWithFlags(&P.frames_ready, hipEventDisableTiming));
         for (Slot& s : P.slot) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
-    const int slot_idx = async ? (P.next_ticket % Pipeline::N_SLOTS) : 0;
+    int slot_idx = 0;
+    if (async) {          // any free slot (tickets may be collected out of order)
+        slot_idx = P.next_ticket % Pipeline::N_SLOTS;
+        for (int k = 0; k < Pipeline::N_SLOTS; ++k)
+            if (P.slot[(slot_idx + k) % Pipeline::N_SLOTS].ticket < 0) { slot_idx = (slot_idx + k) % Pipeline::N_SLOTS; break; }
+    }
     Slot& SL = P.slot[slot_idx];
     if (SL.ticket >= 0) {
         if (async) { set_error("%d batches are already in flight: collect ticket %d first", Pipeline::N_SLOTS, SL.ticket); return P2P_ERR_CAPACITY; }

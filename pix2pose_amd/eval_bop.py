@@ -201,7 +201,7 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
     specs = []
     for m, mid in enumerate(model_ids):                                       # one network per object (:206-225)
         wfn = dump["weights"][str(mid)]
-        if not wfn.startswith("synthetic:"):
+        if not wfn.startswith(("synthetic:", "trained-like:")):
             wfn = os.path.join(base_dir, wfn)
         gen = runtime.Generator(W.load_weights(wfn, backbone), backbone, ctx)
         specs.append(runtime.ObjectSpec(gen, model_params_to_obj_param(dump["norm_factor"][str(mid)]), th_o[m], th_i))

@@ -50,10 +50,26 @@ def poses_to_records(poses, base_id=0, ids=None) -> np.ndarray:
     return out
 
 
-def gather_poses(records: np.ndarray, device=None, pad_to: int | None = None) -> np.ndarray:
-    """All-gather the per-rank records.  Shards may differ in length by padding to the largest
-    (``pad_to`` or an all-reduce MAX); padded rows carry id = -1 and are dropped.  Returns the
-    concatenation over ranks, sorted by record id."""
+class PendingGather:
+    """An all-gather of pose records in flight (gather_poses_async).  result() waits for it."""
+
+    def __init__(self, work, out, keep):
+        self._work, self._out, self._keep = work, out, keep
+
+    def result(self) -> np.ndarray:
+        if self._work is not None:
+            self._work.wait()
+        res = self._out.cpu().numpy()
+        self._keep = None
+        res = res[res[:, 0] >= 0]
+        return res[np.argsort(res[:, 0], kind="stable")]
+
+
+def gather_poses_async(records: np.ndarray, device=None, pad_to: int | None = None) -> PendingGather:
+    """Start the all-gather of the per-rank records and return at once: the caller enqueues its next batch and picks the result up
+    one step later (PendingGather.result()), so that a rank that is late for step i does not hold the other ranks' step i + 1 back.
+    Shards may differ in length by padding to the largest (``pad_to``, or an all-reduce MAX -- which does block); padded rows carry
+    id = -1 and are dropped.  On the "nccl" backend (= RCCL over xGMI) the records travel from device memory."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
@@ -65,9 +81,34 @@ def gather_poses(records: np.ndarray, device=None, pad_to: int | None = None) ->
         pad_to = int(m.item())
     buf = torch.full((pad_to, REC), -1.0, dtype=torch.float64, device=dev)
     if n:
-        buf[:n] = torch.from_numpy(np.ascontiguousarray(records)).to(dev)
+        buf[:n] = torch.from_numpy(np.ascontiguousarray(records)).to(dev, non_blocking=True)
     out = torch.empty((world * pad_to, REC), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(out, buf)
-    res = out.cpu().numpy()
-    res = res[res[:, 0] >= 0]
-    return res[np.argsort(res[:, 0], kind="stable")]
+    work = dist.all_gather_into_tensor(out, buf, async_op=True)
+    return PendingGather(work, out, buf)
+
+
+def gather_poses(records: np.ndarray, device=None, pad_to: int | None = None) -> np.ndarray:
+    """All-gather the per-rank records (blocking).  Returns the concatenation over ranks, sorted by record id."""
+    return gather_poses_async(records, device, pad_to).result()
+
+
+def pin_rank_to_cpus(rank: int, world: int, usable: int | None = None):
+    """Give every rank of a node its own slice of the CPUs this container may use (affinity mask, capped by the cgroup quota ``usable``):
+    the GPU boxes show 256 CPUs but own a quota of 16, and eight Python ranks plus their HIP runtime threads otherwise migrate over
+    all of them and throttle each other.  -> the CPU list the rank now runs on (or None where affinity cannot be set)."""
+    import os
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if world <= 1 or not cpus:
+        return cpus
+    usable = min(len(cpus), usable or len(cpus))
+    per = max(1, usable // world)
+    stride = max(per, len(cpus) // world)              # spread the slices over the mask (distinct cores / CCDs where there are many)
+    mine = cpus[rank * stride:rank * stride + per] or cpus[rank % len(cpus):rank % len(cpus) + 1]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine

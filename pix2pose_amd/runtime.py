@@ -216,6 +216,12 @@ def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_m
         dms = max(int(np.asarray(m).size) for m in det_masks)
         dm = np.zeros((n, dms), np.uint8)
         for i, m in enumerate(det_masks):
+            im = images[detections[i][0]]
+            hw = (im[1], im[2]) if isinstance(im, tuple) else tuple(np.asarray(im).shape[:2])
+            if tuple(np.asarray(m).shape[:2]) != tuple(hw):
+                # the device reads the mask with the frame's row stride; the reference resizes such masks to the frame first
+                # (tools/5_evaluation_bop_basic.py:309-310) -- that resize is left to the caller; a mismatch is an error here, not a silent misread
+                raise ValueError("detector mask %d has shape %r, its frame %r" % (i, tuple(np.asarray(m).shape[:2]), tuple(hw)))
             mm = np.ascontiguousarray(np.asarray(m) != 0, dtype=np.uint8).reshape(-1)
             dm[i, :mm.size] = mm
         extras["mask_stats"] = np.zeros((n, 3), np.int64)

@@ -42,3 +42,31 @@ def test_bench_two_ranks_configs3_shape():
     assert out["n_gpus"] == 2 and out["gathered_records"] == 512
     assert out["config"]["objects"] == 30 and "configs[3]" in out["config"]["workload"]
     assert out["poses_ok"] >= 245
+
+
+def test_bench_two_ranks_host_time_and_pinning():
+    """The ranks of a node pin themselves to disjoint CPU slices and the host side of a step (marshalling + enqueueing one 256-detection
+    batch) stays far below the 34 ms the GPU needs for it -- what keeps eight ranks on a 16-CPU container from throttling each other."""
+    out = _bench()
+    assert out["collective"] == {"backend": "gloo", "device": "cpu", "async": True, "world": 2}
+    assert out["rank_cpus"] is None or out["rank_cpus"] >= 1
+    assert out["host_submit_ms_per_step"] is not None and out["host_submit_ms_per_step"] < 2.0, out["host_submit_ms_per_step"]
+
+
+def test_bench_rccl_path_with_one_rank():
+    """The RCCL branch on the single GPU a test box has: `--backend nccl --collective` under the launcher with WORLD_SIZE=1 goes through
+    init_process_group("nccl", device_id=...), the barrier, the device-side asynchronous all_gather_into_tensor of float64 pose records
+    and the all-reduce(MAX) of the step time -- everything the 8-GPU run does except talking to a second GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29747", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--collective",
+                        "--steps", "3", "--warmup", "1", "--no-legs"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["collective"] == {"backend": "nccl", "device": "cuda:0", "async": True, "world": 1}
+    assert out["n_gpus"] == 1 and out["gathered_records"] == 256 and out["poses_ok"] >= 250

@@ -137,7 +137,12 @@ for i in mine:                       # stand-in for the per-rank pipeline output
     for k in range(9): p.R[k] = i + k / 16.0
     for k in range(3): p.t[k] = -i - k / 3.0
     poses.append(p)
-rec = gather_poses(poses_to_records(poses, ids=mine))
+from pix2pose_amd.parallel import gather_poses_async
+h1 = gather_poses_async(poses_to_records(poses, ids=mine))       # two gathers in flight, collected in order
+h2 = gather_poses_async(poses_to_records(poses, ids=mine))
+rec = h1.result()
+assert (h2.result() == rec).all()
+assert (gather_poses(poses_to_records(poses, ids=mine)) == rec).all()
 assert rec.shape == (11, 20), rec.shape
 assert rec[:, 0].tolist() == list(range(11))
 for i in range(11):
