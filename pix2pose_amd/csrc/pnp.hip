@@ -42,7 +42,7 @@ constexpr double kDblMin = 2.2250738585072014e-308;
 // null space whose basis is decided by rounding -- so one differing ulp changes a hypothesis.
 // One exact-residual correction step (fma(-g, g, x) is exact for g within 1 ulp of the root)
 // makes the device agree bit for bit with a host libm.
-__device__ inline double sqrt_cr(double x)
+__device__ __noinline__ double sqrt_cr_slow(double x)      // zero, subnormal-range, infinite and NaN arguments
 {
     double g = __builtin_sqrt(x);
     if (!(x > 0.0) || !(g < 1.7976931348623157e308)) return g;
@@ -57,6 +57,48 @@ __device__ inline double sqrt_cr(double x)
         if (rp <= 0.0 || -r > rp) g = gp;
     }
     return g;
+}
+// The Jacobi sweeps spend most of their instructions here (three roots per rotation, each a dependent chain), and the lanes of a wave
+// solve different systems: a branchy root costs the wave every path.  So: the compiler's own sequence for arguments that need no
+// scaling (x >= 2^-767: the same operations it emits, minus the range handling), then the correction WITHOUT branches -- both
+// neighbours' residuals are computed and the root is selected.  The correctly rounded root is unique: same bits as before.
+__device__ __forceinline__ double sqrt_cr(double x)
+{
+    if (!(x >= 0x1p-767 && x < 1.7976931348623157e308)) return sqrt_cr_slow(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r0 = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r0, g);
+    h = __builtin_fma(h, r0, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    const double r = __builtin_fma(-g, g, x);
+    const double gn = __longlong_as_double(__double_as_longlong(g) + 1), gp = __longlong_as_double(__double_as_longlong(g) - 1);
+    const double rn = __builtin_fma(-gn, gn, x), rp = __builtin_fma(-gp, gp, x);
+    const bool up = (r > 0.0) & ((rn >= 0.0) | (r > -rn));
+    const bool dn = (r < 0.0) & ((rp <= 0.0) | (-r > rp));
+    return up ? gn : (dn ? gp : g);
+}
+
+// (c, s) of a one-sided Jacobi rotation from the dot product p and the squared norms a, b of two rows (OpenCV JacobiSVDImpl_).  OpenCV
+// branches on the sign of beta; the two branches are the same four operations on swapped roles, so they are written once on selected
+// operands: lanes with either sign walk the same instructions (a branch costs a wave both paths).  hypot() is written out: identical
+// bits on every libm (see oracle/pnp_oracle.c).
+__device__ __forceinline__ void jacobi_cs(double p, const double a, const double b, double& c, double& s)
+{
+    p *= 2;
+    const double beta = a - b, gamma = sqrt_cr(p * p + beta * beta);
+    const bool neg = beta < 0;
+    // beta < 0:  delta = (gamma - beta) * 0.5;  s = sqrt(delta / gamma);             c = p / (gamma * s * 2)
+    // else:                                     c = sqrt((gamma + beta) / (gamma * 2)); s = p / (gamma * c * 2)
+    const double num = neg ? (gamma - beta) * 0.5 : gamma + beta;
+    const double den = neg ? gamma : gamma * 2;
+    const double r1 = sqrt_cr(num / den);
+    const double r2 = p / (gamma * r1 * 2);
+    s = neg ? r1 : r2;
+    c = neg ? r2 : r1;
 }
 
 // ---------------------------------------------------------------- cv::RNG (multiply with carry)
@@ -107,18 +149,8 @@ __device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N]
 #pragma unroll
                 for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
                 if (fabs(p) <= eps * sqrt_cr(a * b)) continue;
-                p *= 2;
-                // hypot() written out: identical bits on every libm (see oracle/pnp_oracle.c)
-                const double beta = a - b, gamma = sqrt_cr(p * p + beta * beta);
                 double c, s;
-                if (beta < 0) {
-                    const double delta = (gamma - beta) * 0.5;
-                    s = sqrt_cr(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt_cr((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
+                jacobi_cs(p, a, b, c, s);
                 a = b = 0;
 #pragma unroll
                 for (int k = 0; k < M; k++) {
@@ -208,62 +240,65 @@ __device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N]
     }
 }
 
-// ---------------------------------------------------------------- 12x12 SVD on a LANE PAIR
-// The 12x12 Jacobi SVD of M^T M is most of an EPnP solve, and on one lane it is bound by instruction issue: the matrix alone is 288
-// registers -- more than the 256 architectural VGPRs, so every rotation shuffles rows through the accumulation registers -- and a
-// sweep is 66 pairs x ~600 instructions.  Here lanes (2h, 2h + 1) share one solve: lane `half` holds columns [6 half, 6 half + 6) of
-// every row (72 registers).  Products and rotations are per column (half the work per lane); the three sums of a pair -- the dot
-// product and the two squared norms -- are OpenCV's sequential sums over k = 0..11, so they stay ONE chain of additions in the
-// same order: lane 0 adds its six terms, hands the partial to lane 1 (DPP), which adds its six and hands the total back.  Same
-// operations on the same values in the same order => the same bits as jacobi_svd_t<12, 12, false>.
-__device__ __forceinline__ double xlane1(double v)          // the partner lane's value (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+// ---------------------------------------------------------------- 12x12 SVD on a LANE QUAD
+// The 12x12 Jacobi SVD of M^T M is most of an EPnP solve, and on one lane it is bound by instruction issue and by its registers: the
+// matrix alone is 288 of them -- more than the 256 architectural VGPRs, so every rotation shuffles rows through the accumulation
+// registers and scratch -- and a sweep is 66 pairs x ~600 instructions.  Here lanes (4h .. 4h + 3) share one solve: lane q holds
+// columns [3q, 3q + 3) of every row (36 doubles).  Products and rotations are per column; the three sums of a pair -- the dot
+// product and the two squared norms -- are OpenCV's sequential sums over k = 0..11, so they stay ONE chain of additions in the same
+// order: lane 0 adds its three terms and hands the partial to lane 1 (DPP), and so on; lane 3 broadcasts the total.  Same operations
+// on the same values in the same order => the same bits as jacobi_svd_t<12, 12, false>.
+template <int CTRL>
+__device__ __forceinline__ double quad_dpp(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+constexpr int QUAD_PREV = 0x90;      // every lane reads the lane before it in its quad (lane 0: itself): quad_perm [0, 0, 1, 2]
+template <int K> __device__ __forceinline__ double quad_bcast(double v) { return quad_dpp<K | (K << 2) | (K << 4) | (K << 6)>(v); }   // lane K -> all four
 
-// s = 0; for k = 0..11: s += x_k   with x_k on lane k / 6 (x[k % 6]); both lanes get the result
-__device__ __forceinline__ double chain12(const double (&x)[6], const int half)
+// s = 0; for k = 0..11: s += x_k   with x_k on lane k / 3 (x[k % 3]); all four lanes get the result
+__device__ __forceinline__ double chain12(const double (&x)[3])
 {
     double s = 0;
+    s += x[0]; s += x[1]; s += x[2];              // lane 0 holds the partial over k = 0..2
 #pragma unroll
-    for (int e = 0; e < 6; e++) s += x[e];          // meaningful on lane 0
-    double s2 = xlane1(s);                            // lane 1 continues from lane 0's partial
-#pragma unroll
-    for (int e = 0; e < 6; e++) s2 += x[e];         // meaningful on lane 1
-    const double t = xlane1(s2);
-    return half ? s2 : t;
+    for (int q = 1; q < 4; q++) {                  // after pass q, lane q holds the partial over k = 0 .. 3q + 2
+        s = quad_dpp<QUAD_PREV>(s);
+        s += x[0]; s += x[1]; s += x[2];
+    }
+    return quad_bcast<3>(s);
 }
 
 // two such chains at once (independent: the additions interleave)
-__device__ __forceinline__ void chain12x2(const double (&x)[6], const double (&y)[6], const int half, double& sx, double& sy)
+__device__ __forceinline__ void chain12x2(const double (&x)[3], const double (&y)[3], double& sx, double& sy)
 {
     double a = 0, b = 0;
+    a += x[0]; b += y[0]; a += x[1]; b += y[1]; a += x[2]; b += y[2];
 #pragma unroll
-    for (int e = 0; e < 6; e++) { a += x[e]; b += y[e]; }
-    double a2 = xlane1(a), b2 = xlane1(b);
-#pragma unroll
-    for (int e = 0; e < 6; e++) { a2 += x[e]; b2 += y[e]; }
-    const double ta = xlane1(a2), tb = xlane1(b2);
-    sx = half ? a2 : ta;
-    sy = half ? b2 : tb;
+    for (int q = 1; q < 4; q++) {
+        a = quad_dpp<QUAD_PREV>(a); b = quad_dpp<QUAD_PREV>(b);
+        a += x[0]; b += y[0]; a += x[1]; b += y[1]; a += x[2]; b += y[2];
+    }
+    sx = quad_bcast<3>(a);
+    sy = quad_bcast<3>(b);
 }
 
-// A[i * 6 + e] = element (i, 6 half + e) of the row image (a symmetric matrix: rows == columns).  On exit the rows are the left singular
+// A[i * 3 + e] = element (i, 3 q + e) of the row image (a symmetric matrix: rows == columns).  On exit the rows are the left singular
 // vectors (this lane's columns of them), W the singular values, descending.  Returns false when a singular value is (numerically) zero:
 // OpenCV then fills in pseudo-random directions -- the caller redoes the solve on the single-lane path, which implements that.
-__device__ __forceinline__ bool jacobi12_pair(double (&A)[72], double (&W)[12], const int half)
+__device__ __forceinline__ bool jacobi12_quad(double (&A)[36], double (&W)[12])
 {
     const double eps = kDblEps * 10;
     constexpr int max_iter = 30;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        double x[6];
+        double x[3];
 #pragma unroll
-        for (int e = 0; e < 6; e++) { const double t = A[i * 6 + e]; x[e] = t * t; }
-        W[i] = chain12(x, half);
+        for (int e = 0; e < 3; e++) { const double t = A[i * 3 + e]; x[e] = t * t; }
+        W[i] = chain12(x);
     }
 #pragma unroll 1
     for (int iter = 0; iter < max_iter; iter++) {
@@ -273,30 +308,21 @@ __device__ __forceinline__ bool jacobi12_pair(double (&A)[72], double (&W)[12], 
 #pragma unroll
             for (int j = i + 1; j < 12; j++) {
                 double a = W[i], b = W[j];
-                double x[6], y[6];
+                double x[3], y[3];
 #pragma unroll
-                for (int e = 0; e < 6; e++) x[e] = A[i * 6 + e] * A[j * 6 + e];
-                double p = chain12(x, half);
-                if (fabs(p) <= eps * sqrt_cr(a * b)) continue;           // the same decision on both lanes: p, a, b are the same values
-                p *= 2;
-                const double beta = a - b, gamma = sqrt_cr(p * p + beta * beta);
+                for (int e = 0; e < 3; e++) x[e] = A[i * 3 + e] * A[j * 3 + e];
+                double p = chain12(x);
+                if (fabs(p) <= eps * sqrt_cr(a * b)) continue;           // the same decision on all four lanes: p, a, b are the same values
                 double c, s;
-                if (beta < 0) {
-                    const double delta = (gamma - beta) * 0.5;
-                    s = sqrt_cr(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt_cr((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
+                jacobi_cs(p, a, b, c, s);
 #pragma unroll
-                for (int e = 0; e < 6; e++) {
-                    const double t0 = c * A[i * 6 + e] + s * A[j * 6 + e];
-                    const double t1 = -s * A[i * 6 + e] + c * A[j * 6 + e];
-                    A[i * 6 + e] = t0; A[j * 6 + e] = t1;
+                for (int e = 0; e < 3; e++) {
+                    const double t0 = c * A[i * 3 + e] + s * A[j * 3 + e];
+                    const double t1 = -s * A[i * 3 + e] + c * A[j * 3 + e];
+                    A[i * 3 + e] = t0; A[j * 3 + e] = t1;
                     x[e] = t0 * t0; y[e] = t1 * t1;
                 }
-                chain12x2(x, y, half, a, b);
+                chain12x2(x, y, a, b);
                 W[i] = a; W[j] = b;
                 changed = true;
             }
@@ -304,12 +330,12 @@ __device__ __forceinline__ bool jacobi12_pair(double (&A)[72], double (&W)[12], 
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        double x[6];
+        double x[3];
 #pragma unroll
-        for (int e = 0; e < 6; e++) { const double t = A[i * 6 + e]; x[e] = t * t; }
-        W[i] = sqrt_cr(chain12(x, half));
+        for (int e = 0; e < 3; e++) { const double t = A[i * 3 + e]; x[e] = t * t; }
+        W[i] = sqrt_cr(chain12(x));
     }
-    // selection sort, descending, as predicated swaps (see jacobi_svd_t); W is the same on both lanes, so are the swaps
+    // selection sort, descending, as predicated swaps (see jacobi_svd_t); W is the same on all four lanes, so are the swaps
 #pragma unroll
     for (int i = 0; i < 11; i++) {
         int j = i;
@@ -322,7 +348,7 @@ __device__ __forceinline__ bool jacobi12_pair(double (&A)[72], double (&W)[12], 
             if (j == k) {
                 double t = W[i]; W[i] = W[k]; W[k] = t;
 #pragma unroll
-                for (int e = 0; e < 6; e++) { t = A[i * 6 + e]; A[i * 6 + e] = A[k * 6 + e]; A[k * 6 + e] = t; }
+                for (int e = 0; e < 3; e++) { t = A[i * 3 + e]; A[i * 3 + e] = A[k * 3 + e]; A[k * 3 + e] = t; }
             }
     }
     bool ok = true;
@@ -332,21 +358,23 @@ __device__ __forceinline__ bool jacobi12_pair(double (&A)[72], double (&W)[12], 
         if (sd <= kDblMin) ok = false;
         const double s = sd > kDblMin ? 1 / sd : 0.;
 #pragma unroll
-        for (int e = 0; e < 6; e++) A[i * 6 + e] *= s;
+        for (int e = 0; e < 3; e++) A[i * 3 + e] *= s;
     }
     return ok;
 }
 
-// rows 8..11 of the left singular vectors with all twelve columns on both lanes: u8[r * 12 + k] = row 8 + r
-__device__ __forceinline__ void gather_rows8(const double (&A)[72], const int half, double (&u8)[48])
+// rows 8..11 of the left singular vectors with all twelve columns on all four lanes: u8[r * 12 + k] = row 8 + r
+__device__ __forceinline__ void gather_rows8(const double (&A)[36], double (&u8)[48])
 {
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int e = 0; e < 6; e++) {
-            const double mine = A[(8 + r) * 6 + e], other = xlane1(mine);
-            u8[r * 12 + e] = half ? other : mine;
-            u8[r * 12 + 6 + e] = half ? mine : other;
+        for (int e = 0; e < 3; e++) {
+            const double v = A[(8 + r) * 3 + e];
+            u8[r * 12 + e] = quad_bcast<0>(v);
+            u8[r * 12 + 3 + e] = quad_bcast<1>(v);
+            u8[r * 12 + 6 + e] = quad_bcast<2>(v);
+            u8[r * 12 + 9 + e] = quad_bcast<3>(v);
         }
 }
 
@@ -716,10 +744,10 @@ __device__ void orientation(const double* abt, const double* pc0, const double* 
 
 // ---------------------------------------------------------------- 5-point EPnP, one lane, sequential
 // pws[15] (object, mm), us[10] (pixels).  Sequential summation order = OpenCV's.
-// PAIR: lanes (2h, 2h + 1) run this together on the same inputs; the 12x12 SVD is shared between them (jacobi12_pair), everything
-// else is computed by both (same inputs, same bits).  half = lane & 1.
-template <bool PAIR>
-__device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout, const int half)
+// QUAD: lanes (4h .. 4h + 3) run this together on the same inputs; the 12x12 SVD is shared between them (jacobi12_quad), everything
+// else is computed by all four (same inputs, same bits).  q = lane & 3.
+template <bool QUAD>
+__device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout, const int q)
 {
     const int n = 5;
     double cws[4][3], c0[3] = {0, 0, 0}, ptp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -754,14 +782,14 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
 
     double u8[48];          // rows 8..11 of the left singular vectors of M^T M
     bool solved = false;
-    if (PAIR) {
-        double A[72];       // this lane's six columns of M^T M (symmetric: rows == columns, the row image of A^T is the matrix itself)
+    if (QUAD) {
+        double A[36];       // this lane's three columns of M^T M (symmetric: rows == columns, the row image of A^T is the matrix itself)
         #pragma unroll
-        for (int k = 0; k < 72; k++) A[k] = 0;
+        for (int k = 0; k < 36; k++) A[k] = 0;
         #pragma unroll
         for (int i = 0; i < n; i++) {
             const double* a = alphas + 4 * i;
-            double m1[12], m2[12], m1q[6], m2q[6];
+            double m1[12], m2[12], m1q[3], m2q[3];
             const double u = us[2 * i], v = us[2 * i + 1];
             #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -769,21 +797,24 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
                 m2[3 * j] = 0.0; m2[3 * j + 1] = a[j] * cam.fv; m2[3 * j + 2] = a[j] * (cam.vc - v);
             }
             #pragma unroll
-            for (int e = 0; e < 6; e++) { m1q[e] = half ? m1[6 + e] : m1[e]; m2q[e] = half ? m2[6 + e] : m2[e]; }
+            for (int e = 0; e < 3; e++) {
+                m1q[e] = q == 0 ? m1[e] : q == 1 ? m1[3 + e] : q == 2 ? m1[6 + e] : m1[9 + e];
+                m2q[e] = q == 0 ? m2[e] : q == 1 ? m2[3 + e] : q == 2 ? m2[6 + e] : m2[9 + e];
+            }
             #pragma unroll
             for (int p = 0; p < 12; p++)
                 #pragma unroll
-                for (int e = 0; e < 6; e++) A[p * 6 + e] += m1[p] * m1q[e];
+                for (int e = 0; e < 3; e++) A[p * 3 + e] += m1[p] * m1q[e];
             #pragma unroll
             for (int p = 0; p < 12; p++)
                 #pragma unroll
-                for (int e = 0; e < 6; e++) A[p * 6 + e] += m2[p] * m2q[e];
+                for (int e = 0; e < 3; e++) A[p * 3 + e] += m2[p] * m2q[e];
         }
         double w12[12];
-        solved = jacobi12_pair(A, w12, half);
-        if (solved) gather_rows8(A, half, u8);
+        solved = jacobi12_quad(A, w12);
+        if (solved) gather_rows8(A, u8);
     }
-    if (!solved) {          // single-lane solve (not PAIR, or a zero singular value: OpenCV's random fill-in lives in jacobi_svd_t)
+    if (!solved) {          // single-lane solve (not QUAD, or a zero singular value: OpenCV's random fill-in lives in jacobi_svd_t)
         double mtm[144];
         #pragma unroll
         for (int k = 0; k < 144; k++) mtm[k] = 0;
@@ -962,7 +993,7 @@ struct PnpFit {
 // ALL problems are solved in one resident round.
 constexpr int SCORE_CHUNK = 8;   // hypotheses whose inlier counts are taken in one pass over the points (pnp_score_kernel)
 // Hypotheses are solved lazily in three rounds: RANSAC's adaptive bound stops long before 100 on good data (mean ~12 here), so
-// [0, 16) are solved first -- TWO problems per wave, 32 lanes (16 lane pairs) each: the inlined fp64 solver takes the whole 512-entry register
+// [0, 16) are solved first -- ONE problem per wave, 16 lane quads: the inlined fp64 solver takes the whole 512-entry register
 // file, i.e. a resident wave blocks its SIMD for everything else, and a quarter of the waves blocks a quarter of the SIMD time --,
 // then [16, 64) and [64, iterations) only for the problems whose scoring ran past what it had (one problem per wave).
 constexpr int HYP_ROUND0 = 16, HYP_ROUND1 = 64;
@@ -977,7 +1008,7 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     __shared__ int s_idx_wg[4][MAX_ITERS][5];    // per wave; ppb == 4: rows 16 sub + it (it < 16); ppb == 1: row it
     int (*s_idx)[5] = s_idx_wg[threadIdx.x >> 6];
     const int tid = threadIdx.x & 63;
-    const int lanes = 64 / ppb;                  // lanes per problem: TWO per hypothesis (lane pairs share the 12x12 SVD, jacobi12_pair)
+    const int lanes = 64 / ppb;                  // lanes per problem: FOUR per hypothesis (lane quads share the 12x12 SVD, jacobi12_quad)
     const int sub = tid / lanes, lane_in = tid - sub * lanes;
     // Round 0 takes the problems in order (and clears the lists of the later rounds); rounds 1 and 2 take theirs from the list the
     // scoring pass of the round before appended to (act: [count1, count2, list1[n], list2[n]]), so that the few problems still
@@ -1023,10 +1054,10 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     }
     __syncthreads();
 
-    // ---- 2. hypotheses: one lane PAIR each; a wave's lane group walks its range in passes of lanes / 2
-    const int half = lane_in & 1;
-    for (int h0 = h_begin; h0 < h_end; h0 += lanes >> 1) {
-    const int hi = h0 + (lane_in >> 1);
+    // ---- 2. hypotheses: one lane QUAD each; a wave's lane group walks its range in passes of lanes / 4
+    const int q4 = lane_in & 3;
+    for (int h0 = h_begin; h0 < h_end; h0 += lanes >> 2) {
+    const int hi = h0 + (lane_in >> 2);
     if (active && hi < h_end) {
         const float* PX = pb.pts;
         const float* PY = pb.pts + (size_t)pb.cap;
@@ -1046,10 +1077,10 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
             us[2 * i + 1] = yn * pb.K[4] + pb.K[5];
         }
         double R[9], t[3], rvec[3];
-        epnp5<true>(cam, pws, us, R, t, half);
+        epnp5<true>(cam, pws, us, R, t, q4);
         rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
         rodrigues_v2r(rvec, R);
-        if (half == 0) {
+        if (q4 == 0) {
             double* h = hyp + ((size_t)prob * MAX_ITERS + hi) * 12;
             for (int k = 0; k < 9; k++) h[k] = R[k];
             for (int k = 0; k < 3; k++) h[9 + k] = t[k];
@@ -1341,8 +1372,8 @@ __device__ __forceinline__ double mtm_entry(const double (&g)[56], const Cam& ca
 __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
 {
     const int li = blockIdx.x * 256 + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
-    const int half = li & 1, q = li >> 1;               // a lane PAIR per (problem, beta case): the pair shares the 12x12 SVD
-    const int pi = q / 3, c = q - pi * 3;
+    const int q4 = li & 3, qi = li >> 2;                // a lane QUAD per (problem, beta case): the quad shares the 12x12 SVD
+    const int pi = qi / 3, c = qi - pi * 3;
     if (pi >= n_problems) return;
     PnpFit& fit = fits[pi];
     if (fit.state != 0) return;
@@ -1359,16 +1390,16 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
     double u8[48];          // rows 8..11 of the left singular vectors of M^T M
     bool solved = false;
     {
-        double A[72], w12[12];
+        double A[36], w12[12];
 #pragma unroll
         for (int p = 0; p < 12; p++)
 #pragma unroll
-            for (int e = 0; e < 6; e++) {
-                const double lo = mtm_entry(g, cam, p, e), hi = mtm_entry(g, cam, p, 6 + e);
-                A[p * 6 + e] = half ? hi : lo;
+            for (int e = 0; e < 3; e++) {
+                const double v0 = mtm_entry(g, cam, p, e), v1 = mtm_entry(g, cam, p, 3 + e), v2 = mtm_entry(g, cam, p, 6 + e), v3 = mtm_entry(g, cam, p, 9 + e);
+                A[p * 3 + e] = q4 == 0 ? v0 : q4 == 1 ? v1 : q4 == 2 ? v2 : v3;
             }
-        solved = jacobi12_pair(A, w12, half);
-        if (solved) gather_rows8(A, half, u8);
+        solved = jacobi12_quad(A, w12);
+        if (solved) gather_rows8(A, u8);
     }
     if (!solved) {          // a zero singular value: the single-lane routine has OpenCV's random fill-in
         double mtm[144], w12[12];
@@ -1409,7 +1440,7 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
         }
         double R[3][3], t[3];
         orientation(abt, pc0, cws[0], R, t);
-        if (half == 0) {
+        if (q4 == 0) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {
 #pragma unroll
@@ -1494,7 +1525,7 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
     const int stops[3] = {pnp::HYP_ROUND0, pnp::HYP_ROUND1, pnp::MAX_ITERS};
     int h_begin = 0;
     for (int r = 0; r < 3; ++r) {
-        const int ppb = r == 0 ? 2 : 1;
+        const int ppb = 1;          // a wave per problem: 16 hypotheses x 4 lanes
         hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(((n_problems + ppb - 1) / ppb + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
                            min_points, h_begin, stops[r], ppb, act, r);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1504,7 +1535,7 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
         h_begin = stops[r];
         if (iterations <= h_begin) break;
     }
-    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((6 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
+    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((12 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);
     return hipGetLastError();

@@ -1,2 +1,4 @@
-timeout 1700 python -m pytest tests/test_bench_multirank_gpu.py -x -q 2>&1 | tail -8
-python bench.py --steps 10 --warmup 3 > gpurun_out/bench_r3a.json 2> gpurun_out/bench_r3a.err; tail -c 600 gpurun_out/bench_r3a.err
+cd /tmp && export TMPDIR=/tmp
+G=$GRAFT_REPO_ROOT/gpurun_out
+rm -rf $G/prof_call
+rocprofv3 --kernel-trace -d $G/prof_call -o t -- python $GRAFT_REPO_ROOT/tools/single_det.py 10 > $G/call.log 2>&1
