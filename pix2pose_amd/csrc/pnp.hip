@@ -20,6 +20,7 @@
 // All arithmetic that decides an inlier uses OpenCV's types (float32 point storage, float32
 // projected points and squared distance) with FMA contraction disabled.
 #include "pipeline.h"
+#include <algorithm>
 
 // minimum waves per SIMD the two PnP kernels are compiled for (caps their register allocation)
 #ifndef P2P_PNP_HYP_WAVES
@@ -1003,7 +1004,7 @@ constexpr int HYP_ROUND0 = 16, HYP_ROUND1 = 64;
 // batch: the ResNet front running under it was 2.7x slower); packed four to a CU they take a quarter as many.
 __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
                                                             const PnpFit* __restrict__ fits, int n_problems, int iterations, int min_points,
-                                                            int h_begin, int h_stop, int ppb, int* __restrict__ act, int round)
+                                                            int h_begin, int h_stop, int ppb, int* __restrict__ act, int round, int wpp)
 {
     __shared__ int s_idx_wg[4][MAX_ITERS][5];    // per wave; ppb == 4: rows 16 sub + it (it < 16); ppb == 1: row it
     int (*s_idx)[5] = s_idx_wg[threadIdx.x >> 6];
@@ -1013,12 +1014,17 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     // Round 0 takes the problems in order (and clears the lists of the later rounds); rounds 1 and 2 take theirs from the list the
     // scoring pass of the round before appended to (act: [count1, count2, list1[n], list2[n]]), so that the few problems still
     // running are packed four to a workgroup: the waves of the other workgroups leave at once.
-    int prob = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ppb + sub;
+    // wpp waves share a problem's hypothesis range, 16 hypotheses each (the later rounds: 48 and 36 hypotheses -- walked by one wave
+    // they were three passes of 0.5 ms on the critical path of exactly the detections that are slow already)
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int prob = (wave_g / wpp) * ppb + sub;
+    h_begin += (wave_g % wpp) * (lanes >> 2);
+    h_stop = min(h_stop, h_begin + (wpp > 1 ? lanes >> 2 : MAX_ITERS));
     if (round == 0) {
         if (blockIdx.x == 0 && threadIdx.x < 2) act[threadIdx.x] = 0;
     } else
         prob = prob < act[round - 1] ? act[2 + (round - 1) * n_problems + prob] : n_problems;
-    bool active = prob < n_problems && (h_begin == 0 || fits[prob].state == 2);
+    bool active = prob < n_problems && (round == 0 || fits[prob].state == 2);
     PnpProblem pb;
     pb.n = 0; pb.cap = 0; pb.pts = nullptr; pb.mask = nullptr;
     if (active) pb = probs[prob];
@@ -1526,8 +1532,9 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
     int h_begin = 0;
     for (int r = 0; r < 3; ++r) {
         const int ppb = 1;          // a wave per problem: 16 hypotheses x 4 lanes
-        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3(((n_problems + ppb - 1) / ppb + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
-                           min_points, h_begin, stops[r], ppb, act, r);
+        const int wpp = (std::min(stops[r], iterations) - h_begin + pnp::HYP_ROUND0 - 1) / pnp::HYP_ROUND0;      // waves per problem: 16 hypotheses each
+        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems * wpp + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
+                           min_points, h_begin, stops[r], ppb, act, r, wpp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
                            reproj_err, confidence, min_points, stops[r], r == 0 ? 1 : 0, act, r, n_problems);
