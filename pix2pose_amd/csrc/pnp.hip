@@ -852,13 +852,8 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
     compute_L_6x10(ut, l);
     compute_rho(cws, rho);
 
-    double best_err = 0;
-    #pragma unroll 1
-    for (int c = 1; c <= 3; c++) {
-        double betas[4];
-        if (c == 1) betas_approx_1(l, rho, betas);
-        else if (c == 2) betas_approx_2(l, rho, betas);
-        else betas_approx_3(l, rho, betas);
+    // one beta case: Gauss-Newton from the case's starting point, camera-frame control points, absolute orientation, mean reprojection error
+    auto finish_case = [&](double* betas, double (&R)[3][3], double (&t)[3]) -> double {
         gauss_newton(l, rho, betas);
         double ccs[4][3], pcs[15];
         compute_ccs(betas, ut, ccs);
@@ -887,7 +882,6 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
                 abt[3 * j + 1] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + 1] - pw0[1]);
                 abt[3 * j + 2] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + 2] - pw0[2]);
             }
-        double R[3][3], t[3];
         orientation(abt, pc0, pw0, R, t);
         double sum2 = 0.0;
         #pragma unroll
@@ -899,17 +893,57 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
             const double u = us[2 * i], v = us[2 * i + 1];
             sum2 += sqrt_cr((u - ue) * (u - ue) + (v - ve) * (v - ve));
         }
+        return sum2 / n;
+    };
+    if (QUAD) {
+        // Lanes 0, 1, 2 of the quad take the beta cases 1, 2, 3 (lane 3 repeats case 3).  The starting points are three different routines
+        // -- the wave walks them one after the other, as a single lane did -- but everything after them is the same code for every case
+        // and now runs ONCE for the three: two of the three tails (a third of the solve) are gone.
+        const int c = q < 2 ? q + 1 : 3;
+        double betas[4], R[3][3], t[3];
+        if (c == 1) betas_approx_1(l, rho, betas);
+        else if (c == 2) betas_approx_2(l, rho, betas);
+        else betas_approx_3(l, rho, betas);
+        const double err = finish_case(betas, R, t);
 #ifdef P2P_PNP_TIMING
-        tk[nk++] = clock64();
+        tk[nk++] = clock64(); tk[nk++] = tk[nk - 1]; tk[nk++] = tk[nk - 1];
 #endif
-        const double err = sum2 / n;
-        if (c == 1 || err < best_err) {
-            best_err = err;
+        // OpenCV's rule, in its order: keep case 1; take case 2 if its error is smaller; then case 3 if smaller than the best so far
+        const double e1 = quad_bcast<0>(err), e2 = quad_bcast<1>(err), e3 = quad_bcast<2>(err);
+        int best = 0;
+        double be = e1;
+        if (e2 < be) { best = 1; be = e2; }
+        if (e3 < be) best = 2;
+        #pragma unroll
+        for (int i = 0; i < 3; i++) {
             #pragma unroll
-            for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) {
+                const double v0 = quad_bcast<0>(R[i][j]), v1 = quad_bcast<1>(R[i][j]), v2 = quad_bcast<2>(R[i][j]);
+                Rout[3 * i + j] = best == 0 ? v0 : best == 1 ? v1 : v2;
+            }
+            const double v0 = quad_bcast<0>(t[i]), v1 = quad_bcast<1>(t[i]), v2 = quad_bcast<2>(t[i]);
+            tout[i] = best == 0 ? v0 : best == 1 ? v1 : v2;
+        }
+    } else {
+        double best_err = 0;
+        #pragma unroll 1
+        for (int c = 1; c <= 3; c++) {
+            double betas[4], R[3][3], t[3];
+            if (c == 1) betas_approx_1(l, rho, betas);
+            else if (c == 2) betas_approx_2(l, rho, betas);
+            else betas_approx_3(l, rho, betas);
+            const double err = finish_case(betas, R, t);
+#ifdef P2P_PNP_TIMING
+            tk[nk++] = clock64();
+#endif
+            if (c == 1 || err < best_err) {
+                best_err = err;
                 #pragma unroll
-                for (int j = 0; j < 3; j++) Rout[3 * i + j] = R[i][j];
-                tout[i] = t[i];
+                for (int i = 0; i < 3; i++) {
+                    #pragma unroll
+                    for (int j = 0; j < 3; j++) Rout[3 * i + j] = R[i][j];
+                    tout[i] = t[i];
+                }
             }
         }
     }
