@@ -12,6 +12,7 @@
 #include "pipeline.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -71,7 +72,7 @@ void PinnedBuf::release()
 Pipeline::~Pipeline()
 {
     for (Slot& s : slot) {
-        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images,
+        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images, &s.crec, &s.cseg,
                           &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_kp, &s.aa_kp_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
         for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat, &s.h_frames}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
@@ -548,6 +549,128 @@ __global__ __launch_bounds__(1024) void cand_corr_kernel(const DetInfo* __restri
         pb.pts = pts; pb.cap = D.corr_cap;
         // n_non_gray < 10 -> the reference skips the candidate before PnP (:149-150)
         pb.n = (s_ng >= 10) ? total : 0;
+        for (int k = 0; k < 9; ++k) pb.K[k] = D.K[k];
+        pb.mask = nullptr;
+        probs[cand] = pb;
+    }
+}
+
+// The same work for a HANDFUL of candidates (one detection at a time: three), as two launches over CORR_SEG pixel segments per candidate:
+// one workgroup per candidate spent 75 us walking its 16 384 pixels (the per-pixel evaluation is ~300 fp64 instructions); eight
+// segments on eight CUs evaluate them at once and leave a 4-byte record per pixel, then the compaction -- which needs the counts of
+// the segments before it, hence the second launch -- writes the correspondences in the same row-major order.
+constexpr int CORR_SEG = 8;
+struct CorrSeg { int n_valid, n_ng; unsigned long long sv, su; };
+
+__global__ __launch_bounds__(256) void cand_eval_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1, const float* __restrict__ y2,
+                                                        int K, unsigned* __restrict__ rec, CorrSeg* __restrict__ segs,
+                                                        const CandRange* __restrict__ crange, AaPtrs aa)
+{
+    __shared__ int s_nv[4], s_ng[4];
+    __shared__ unsigned long long s_sv[4], s_su[4];
+    const int cand = blockIdx.y, seg = blockIdx.x;
+    const int d = cand / K, slot = cand - d * K;
+    const DetInfo& D = dets[d];
+    const Stage1& S = s1[d];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nv = 0, ng = 0;
+    unsigned long long sv = 0, su = 0;
+    if (slot < D.n_th && S.valid2[slot]) {
+        const Boxes& b = S.b2;
+        const int S2 = b.v2_ori - b.v1_ori, S2w = b.u2_ori - b.u1_ori;
+        const int h = b.v2 - b.v1, w = b.u2 - b.u1;
+        const int npx = h * w, per = (npx + CORR_SEG - 1) / CORR_SEG;
+        const float* y2c = y2 + (size_t)cand * 16384 * 4;
+        const double* bk = (aa.k3 && aa.k3[cand * 5].radius > 0) ? aa.k3[cand * 5].a : nullptr;
+        const CandRange R = crange[cand];
+        unsigned* r = rec + D.corr_off / 5 + (size_t)slot * D.corr_cap;
+        for (int p = seg * per + tid; p < min(npx, (seg + 1) * per); p += 256) {
+            const int rr = p / w, cc = p - rr * w;
+            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+            r[p] = (unsigned)cp.q[0] | ((unsigned)cp.q[1] << 8) | ((unsigned)cp.q[2] << 16) | (cp.valid ? 1u << 24 : 0u);
+            nv += cp.valid;
+            if (cp.non_gray) { ++ng; sv += (unsigned)(b.v1 + rr); su += (unsigned)(b.u1 + cc); }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nv += __shfl_down(nv, o, 64); ng += __shfl_down(ng, o, 64);
+        sv += __shfl_down(sv, o, 64); su += __shfl_down(su, o, 64);
+    }
+    if (lane == 0) { s_nv[wave] = nv; s_ng[wave] = ng; s_sv[wave] = sv; s_su[wave] = su; }
+    __syncthreads();
+    if (tid == 0) {
+        CorrSeg o;
+        o.n_valid = s_nv[0] + s_nv[1] + s_nv[2] + s_nv[3]; o.n_ng = s_ng[0] + s_ng[1] + s_ng[2] + s_ng[3];
+        o.sv = s_sv[0] + s_sv[1] + s_sv[2] + s_sv[3]; o.su = s_su[0] + s_su[1] + s_su[2] + s_su[3];
+        segs[cand * CORR_SEG + seg] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void cand_compact_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1, int K,
+                                                           const unsigned* __restrict__ rec, const CorrSeg* __restrict__ segs,
+                                                           float* __restrict__ corr, CandStat* __restrict__ cstat, PnpProblem* __restrict__ probs)
+{
+    __shared__ int s_wave[4];
+    const int cand = blockIdx.y, seg = blockIdx.x;
+    const int d = cand / K, slot = cand - d * K;
+    const DetInfo& D = dets[d];
+    const Stage1& S = s1[d];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* pts = corr + D.corr_off + (size_t)slot * 5 * D.corr_cap;
+    int before = 0, all = 0, ng = 0;
+    unsigned long long sv = 0, su = 0;
+    for (int k = 0; k < CORR_SEG; ++k) {
+        const CorrSeg c = segs[cand * CORR_SEG + k];
+        if (k < seg) before += c.n_valid;
+        all += c.n_valid; ng += c.n_ng; sv += c.sv; su += c.su;
+    }
+    if (slot < D.n_th && S.valid2[slot]) {
+        const Boxes& b = S.b2;
+        const int h = b.v2 - b.v1, w = b.u2 - b.u1;
+        const int npx = h * w, per = (npx + CORR_SEG - 1) / CORR_SEG;
+        const unsigned* r = rec + D.corr_off / 5 + (size_t)slot * D.corr_cap;
+        float* PX = pts; float* PY = pts + D.corr_cap; float* PZ = pts + 2 * (size_t)D.corr_cap;
+        float* PU = pts + 3 * (size_t)D.corr_cap; float* PV = pts + 4 * (size_t)D.corr_cap;
+        int total = before;
+        const int p_end = min(npx, (seg + 1) * per);
+        for (int base = seg * per; base < p_end; base += 256) {
+            const int p = base + tid;
+            const unsigned v = p < p_end ? r[p] : 0u;
+            const bool valid = (v >> 24) & 1u;
+            const unsigned long long bal = __ballot(valid);
+            const int rank = __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (lane == 0) s_wave[wave] = __popcll(bal);
+            __syncthreads();
+            int off = total, chunk = 0;
+            for (int k = 0; k < 4; ++k) {
+                if (k < wave) off += s_wave[k];
+                chunk += s_wave[k];
+            }
+            if (valid) {
+                const int o = off + rank;
+                const int rr = p / w, cc = p - rr * w;
+                for (int ch = 0; ch < 3; ++ch) {
+                    double x = (double)((v >> (8 * ch)) & 255u);
+                    x = x / 255;                                                   // :198
+                    x = x * 2 - 1;                                                 // :199
+                    x = x * D.obj_scale[ch] + D.obj_ct[ch];                        // :200-202
+                    (ch == 0 ? PX : ch == 1 ? PY : PZ)[o] = (float)x;             // solvePnPRansac stores float32
+                }
+                PU[o] = (float)(b.u1 + cc);                                        // :207-209 (u, v) + (u1, v1)
+                PV[o] = (float)(b.v1 + rr);
+            }
+            total += chunk;
+            __syncthreads();
+        }
+    }
+    if (seg == 0 && tid == 0) {
+        const bool on = slot < D.n_th && S.valid2[slot];
+        CandStat cs;
+        cs.n_non_gray = on ? ng : 0; cs.n_corr = on ? all : 0; cs.sum_v = on ? (long long)sv : 0; cs.sum_u = on ? (long long)su : 0;
+        cstat[cand] = cs;
+        PnpProblem pb;
+        pb.pts = pts; pb.cap = D.corr_cap;
+        pb.n = (on && ng >= 10) ? all : 0;                                         // n_non_gray < 10 -> skipped before PnP (:149-150)
         for (int k = 0; k < 9; ++k) pb.K[k] = D.K[k];
         pb.mask = nullptr;
         probs[cand] = pb;
@@ -1099,6 +1222,8 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
     if ((rc = SL.y2.reserve(sizeof(float) * 16384 * 4 * ((size_t)n * K + SL.tail_cap)))) return rc;
     if ((rc = SL.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
     if ((rc = SL.crange.reserve(sizeof(CandRange) * (size_t)n * K))) return rc;
+    if (n * K <= 16 && ((rc = SL.crec.reserve(sizeof(unsigned) * (size_t)std::max<long long>(corr_total / 5, 1))) ||
+                        (rc = SL.cseg.reserve(sizeof(CorrSeg) * CORR_SEG * (size_t)n * K)))) return rc;
     SL.aa = {nullptr, nullptr, nullptr, nullptr};
     AaBufs aab = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     AaTable aat;
@@ -1207,8 +1332,14 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
     }
 
     // -- correspondences, PnP-RANSAC, selection
-    hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(glue_nt), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
-                       SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>(), d_cr, aa);
+    static const bool corr_split = getenv("P2P_CORR_SPLIT") == nullptr || atoi(getenv("P2P_CORR_SPLIT")) != 0;      // development switch (A/B)
+    if (n * K <= 16 && corr_split) {        // a handful of candidates: evaluate on CORR_SEG CUs each, then compact (see cand_eval_kernel)
+        hipLaunchKernelGGL(cand_eval_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(), d_cr, aa);
+        hipLaunchKernelGGL(cand_compact_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(),
+                           SL.corr.as<float>(), SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>());
+    } else
+        hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(glue_nt), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
+                           SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>(), d_cr, aa);
     HIP_TRY(hipGetLastError());
     const int iters = opt.ransac_iterations > 0 ? opt.ransac_iterations : 100;
     const double rerr = opt.reprojection_error > 0 ? opt.reprojection_error : 5.0;

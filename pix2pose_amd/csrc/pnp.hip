@@ -83,6 +83,18 @@ __device__ __forceinline__ double sqrt_cr(double x)
     return up ? gn : (dn ? gp : g);
 }
 
+// OpenCV's "is this pair already orthogonal" test, fabs(p) <= eps * sqrt(a * b), without the square root where the answer cannot depend
+// on it: p^2 against eps^2 a b with a relative margin a million times wider than any rounding in either form decides all but a sliver of
+// cases; inside the sliver (and wherever a product could leave the normal range) the original expression is evaluated.  Same decisions.
+__device__ __forceinline__ bool jacobi_skip(const double p, const double a, const double b, const double eps)
+{
+    const double ab = a * b, pp = p * p, lim = (eps * eps) * ab;
+    const bool in_range = (pp > 1e-280) & (pp < 1e280) & (ab > 1e-250) & (ab < 1e280);
+    if (in_range & (pp > lim * 1.000001)) return false;
+    if (in_range & (pp < lim * 0.999999)) return true;
+    return fabs(p) <= eps * sqrt_cr(ab);
+}
+
 // (c, s) of a one-sided Jacobi rotation from the dot product p and the squared norms a, b of two rows (OpenCV JacobiSVDImpl_).  OpenCV
 // branches on the sign of beta; the two branches are the same four operations on swapped roles, so they are written once on selected
 // operands: lanes with either sign walk the same instructions (a branch costs a wave both paths).  hypot() is written out: identical
@@ -149,7 +161,7 @@ __device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N]
                 double a = W[i], p = 0, b = W[j];
 #pragma unroll
                 for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
-                if (fabs(p) <= eps * sqrt_cr(a * b)) continue;
+                if (jacobi_skip(p, a, b, eps)) continue;
                 double c, s;
                 jacobi_cs(p, a, b, c, s);
                 a = b = 0;
@@ -313,7 +325,7 @@ __device__ __forceinline__ bool jacobi12_quad(double (&A)[36], double (&W)[12])
 #pragma unroll
                 for (int e = 0; e < 3; e++) x[e] = A[i * 3 + e] * A[j * 3 + e];
                 double p = chain12(x);
-                if (fabs(p) <= eps * sqrt_cr(a * b)) continue;           // the same decision on all four lanes: p, a, b are the same values
+                if (jacobi_skip(p, a, b, eps)) continue;                 // the same decision on all four lanes: p, a, b are the same values
                 double c, s;
                 jacobi_cs(p, a, b, c, s);
 #pragma unroll
