@@ -149,6 +149,8 @@ struct Slot {
     DevBuf det, s1, cand, probs, results, poses, corr, hyp;
     DevBuf x1, y1, x2, y2, images;      // network inputs / outputs of both stages, uploaded frames
     DevBuf crange;                      // CandRange per candidate
+    DevBuf sacc;                        // few detections: global accumulators of the segmented stage-1 reductions (self-clearing)
+    int sacc_n = 0;
     DevBuf crec, cseg;                  // few candidates: per-pixel records and per-segment counts of the two-launch correspondence build
     DevBuf aa_items, aa_cv, aa_cv_tmp, aa_kp, aa_kp_tmp, aa_bk, aa_bk_tmp;   // anti-aliased resizes: descriptors, canvases, 128x128 planes
     DevBuf mask, pred, dmask, mstat;    // optional outputs of the batch (valid_mask_full, img_pred_f, detector masks, IoU sums)

@@ -72,7 +72,7 @@ void PinnedBuf::release()
 Pipeline::~Pipeline()
 {
     for (Slot& s : slot) {
-        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images, &s.crec, &s.cseg,
+        for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images, &s.crec, &s.cseg, &s.sacc,
                           &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_kp, &s.aa_kp_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
         for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat, &s.h_frames}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
@@ -226,6 +226,38 @@ __global__ __launch_bounds__(256) void stage1_input_kernel(const DetInfo* __rest
     }
 }
 
+// stage-2 geometry from the reductions of one detection (recognition.py:96-110)
+__device__ inline void stage1_finalize(const DetInfo& D, int s_n, int s_minv, int s_minu, int s_maxv, int s_maxu, long long s_sv, long long s_su,
+                                       const int* s_keep, Stage1* out)
+{
+    Stage1 o;
+    memset(&o, 0, sizeof(o));
+    o.n_init_mask = s_n;
+    o.bb[0] = s_minv; o.bb[1] = s_minu; o.bb[2] = s_maxv; o.bb[3] = s_maxu;
+    o.sum_v = s_sv; o.sum_u = s_su;
+    o.b2 = D.b1;
+    bool any = false;
+    if (D.ok1 && s_n > 0) {
+        const Boxes& b = D.b1;
+        const double sy = (double)(b.v2_ori - b.v1_ori) / 128, sx = (double)(b.u2_ori - b.u1_ori) / 128;
+        const double bb[4] = {s_minv * sy, s_minu * sx, s_maxv * sy, s_maxu * sx};          // :101-102
+        const double mean_u = (double)s_su / (double)s_n, mean_v = (double)s_sv / (double)s_n;
+        const int cx_m = (int)((mean_u - (127.0 / 2)) + D.cx_o);                            // :108
+        const int cy_m = (int)((mean_v - (127.0 / 2)) + D.cy_o);                            // :109
+        const Boxes b2 = get_boxes(bb, D.H, D.W, D.box_size, true, cy_m, cx_m, (double)(b.v2_ori - b.v1_ori));   // :110
+        const bool geo_ok = boxes_ok(b2, D.H, D.W);
+        for (int k = 0; k < D.n_th; ++k) {
+            o.keep_cnt[k] = s_keep[k];
+            o.kmin[k] = s_keep[k] == 16384 ? 1.0 : 0.0;      // range of the bool mask as float (clip=True of the :103 resize)
+            o.kmax[k] = s_keep[k] > 0 ? 1.0 : 0.0;
+            o.valid2[k] = (s_keep[k] >= 10 && geo_ok) ? 1 : 0;                             // :96-97, :117-119
+            if (o.valid2[k]) { any = true; ++o.n_cand; }
+        }
+        if (any) o.b2 = b2;
+    }
+    *out = o;
+}
+
 // ------------------------------------------------------------------------------------------
 // K3: stage-1 reductions + stage-2 geometry  (recognition.py:89-110)
 // ------------------------------------------------------------------------------------------
@@ -264,32 +296,77 @@ __global__ __launch_bounds__(1024) void stage1_stats_kernel(const DetInfo* __res
         if (keep[k]) atomicAdd(&s_keep[k], keep[k]);
     __syncthreads();
     if (tid != 0) return;
-    Stage1 o;
-    memset(&o, 0, sizeof(o));
-    o.n_init_mask = s_n;
-    o.bb[0] = s_minv; o.bb[1] = s_minu; o.bb[2] = s_maxv; o.bb[3] = s_maxu;
-    o.sum_v = s_sv; o.sum_u = s_su;
-    o.b2 = D.b1;
-    bool any = false;
-    if (D.ok1 && s_n > 0) {
-        const Boxes& b = D.b1;
-        const double sy = (double)(b.v2_ori - b.v1_ori) / 128, sx = (double)(b.u2_ori - b.u1_ori) / 128;
-        const double bb[4] = {s_minv * sy, s_minu * sx, s_maxv * sy, s_maxu * sx};          // :101-102
-        const double mean_u = (double)s_su / (double)s_n, mean_v = (double)s_sv / (double)s_n;
-        const int cx_m = (int)((mean_u - (127.0 / 2)) + D.cx_o);                            // :108
-        const int cy_m = (int)((mean_v - (127.0 / 2)) + D.cy_o);                            // :109
-        const Boxes b2 = get_boxes(bb, D.H, D.W, D.box_size, true, cy_m, cx_m, (double)(b.v2_ori - b.v1_ori));   // :110
-        const bool geo_ok = boxes_ok(b2, D.H, D.W);
-        for (int k = 0; k < D.n_th; ++k) {
-            o.keep_cnt[k] = s_keep[k];
-            o.kmin[k] = s_keep[k] == 16384 ? 1.0 : 0.0;      // range of the bool mask as float (clip=True of the :103 resize)
-            o.kmax[k] = s_keep[k] > 0 ? 1.0 : 0.0;
-            o.valid2[k] = (s_keep[k] >= 10 && geo_ok) ? 1 : 0;                             // :96-97, :117-119
-            if (o.valid2[k]) { any = true; ++o.n_cand; }
-        }
-        if (any) o.b2 = b2;
+    stage1_finalize(D, s_n, s_minv, s_minu, s_maxv, s_maxu, s_sv, s_su, s_keep, &s1[d]);
+}
+
+// The same reductions for a HANDFUL of detections (one at a time: the reference's caller), spread over STATS_SEG workgroups per detection: each
+// adds its share to per-detection accumulators in global memory, and whichever finishes last turns them into the Stage1 record and
+// leaves them cleared for the next call (integer sums and extrema: the order of the additions is immaterial).
+constexpr int STATS_SEG = 8;
+struct StatsAcc { int n, minv, minu, maxv, maxu, sv, su, keep[MAX_TH], done; };
+
+__global__ void stats_acc_init_kernel(StatsAcc* acc, int n)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    StatsAcc a;
+    memset(&a, 0, sizeof(a));
+    a.minv = a.minu = 1 << 30; a.maxv = a.maxu = -1;
+    acc[d] = a;
+}
+
+__global__ __launch_bounds__(256) void stage1_stats_seg_kernel(const DetInfo* __restrict__ dets, const float* __restrict__ y1,
+                                                               Stage1* __restrict__ s1, StatsAcc* __restrict__ acc)
+{
+    __shared__ int s_last;
+    const int d = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    const DetInfo& D = dets[d];
+    int n = 0, minv = 1 << 30, minu = 1 << 30, maxv = -1, maxu = -1, sv = 0, su = 0;
+    int keep[MAX_TH];
+#pragma unroll
+    for (int k = 0; k < MAX_TH; ++k) keep[k] = 0;
+    const float* y = y1 + (size_t)d * 16384 * 4;
+    constexpr int PER = 16384 / STATS_SEG;
+    for (int p = seg * PER + tid; p < (seg + 1) * PER; p += 256) {
+        const float4 q = reinterpret_cast<const float4*>(y)[p];
+        const float v4[4] = {q.x, q.y, q.z, q.w};
+        if (!non_gray_at(v4)) continue;
+        const int v = p >> 7, u = p & 127;
+        ++n; sv += v; su += u;
+        minv = min(minv, v); maxv = max(maxv, v); minu = min(minu, u); maxu = max(maxu, u);
+#pragma unroll
+        for (int k = 0; k < MAX_TH; ++k)
+            if (k < D.n_th && q.w < D.th_o[k]) ++keep[k];
     }
-    s1[d] = o;
+    for (int o = 32; o > 0; o >>= 1) {
+        n += __shfl_down(n, o, 64); sv += __shfl_down(sv, o, 64); su += __shfl_down(su, o, 64);
+        minv = min(minv, __shfl_down(minv, o, 64)); minu = min(minu, __shfl_down(minu, o, 64));
+        maxv = max(maxv, __shfl_down(maxv, o, 64)); maxu = max(maxu, __shfl_down(maxu, o, 64));
+#pragma unroll
+        for (int k = 0; k < MAX_TH; ++k) keep[k] += __shfl_down(keep[k], o, 64);
+    }
+    StatsAcc& A = acc[d];
+    if ((tid & 63) == 0 && n > 0) {
+        atomicAdd(&A.n, n); atomicAdd(&A.sv, sv); atomicAdd(&A.su, su);
+        atomicMin(&A.minv, minv); atomicMin(&A.minu, minu); atomicMax(&A.maxv, maxv); atomicMax(&A.maxu, maxu);
+#pragma unroll
+        for (int k = 0; k < MAX_TH; ++k)
+            if (keep[k]) atomicAdd(&A.keep[k], keep[k]);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&A.done, 1) == STATS_SEG - 1;
+    __syncthreads();
+    if (!s_last || tid != 0) return;
+    __threadfence();
+    int kp[MAX_TH];
+    for (int k = 0; k < MAX_TH; ++k) kp[k] = atomicAdd(&A.keep[k], 0);
+    stage1_finalize(D, atomicAdd(&A.n, 0), atomicAdd(&A.minv, 0), atomicAdd(&A.minu, 0), atomicAdd(&A.maxv, 0), atomicAdd(&A.maxu, 0),
+                    atomicAdd(&A.sv, 0), atomicAdd(&A.su, 0), kp, &s1[d]);
+    StatsAcc z;
+    memset(&z, 0, sizeof(z));
+    z.minv = z.minu = 1 << 30; z.maxv = z.maxu = -1;
+    A = z;                                           // cleared for the next batch that uses this slot
 }
 
 // resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square.  kp: the anti-aliased keep
@@ -1285,7 +1362,15 @@ static int enqueue_mid(Ctx& X, Slot& SL, hipStream_t st, float* y1)
     const DetInfo* d_det = SL.det.as<DetInfo>();
     Stage1* d_s1 = SL.s1.as<Stage1>();
     if (SL.opt.inject1 && (rc = inject_maps(SL, st, SL.opt.inject1, y1, 16384 * 4))) return rc;
-    hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(n <= 64 ? 1024 : 256), 0, st, d_det, y1, d_s1);
+    if (n <= 16) {            // a handful of detections: STATS_SEG workgroups each (see stage1_stats_seg_kernel)
+        if (SL.sacc_n < n) {  // accumulators: initialised when (re)allocated, self-clearing afterwards
+            if ((rc = SL.sacc.reserve(sizeof(StatsAcc) * 16))) return rc;
+            hipLaunchKernelGGL(stats_acc_init_kernel, dim3(1), dim3(64), 0, st, SL.sacc.as<StatsAcc>(), 16);
+            SL.sacc_n = 16;
+        }
+        hipLaunchKernelGGL(stage1_stats_seg_kernel, dim3(STATS_SEG, n), dim3(256), 0, st, d_det, y1, d_s1, SL.sacc.as<StatsAcc>());
+    } else
+        hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(n <= 64 ? 1024 : 256), 0, st, d_det, y1, d_s1);
     HIP_TRY(hipGetLastError());
     if (SL.use_aa) {      // anti-aliased keep masks (stage-1 sides < 128) and stage-2 canvases (sides > 128)
         AaTable aat;
