@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--latency", type=int, default=100, help="calls of the single-detection latency leg (N=1; 0 = skip)")
     ap.add_argument("--merge", action="store_true", help="stream mode: merge step i's stage-2 generator pass with step i+1's stage-1 pass (p2p_est_pose_opts.merge_stream_passes)")
     ap.add_argument("--anti-aliasing", action="store_true", help="scikit-image 0.15 - 0.18 resize semantics (Gaussian pre-filter whenever a resize shrinks)")
+    ap.add_argument("--bbox-side", default="86,86", help="range of detection box sides in px (default 86 = 128-px crops, the headline workload; "
+                    "e.g. 40,300 for general crop sizes -- profiling runs)")
     ap.add_argument("--no-legs", action="store_true", help="skip the f32 / host-frame / latency / CPU legs (profiling runs)")
     args = ap.parse_args()
     if args.no_legs:
@@ -232,7 +234,8 @@ def main():
                [ObjectSpec(Generator(W.synthetic_weights(args.backbone, 1 + k), args.backbone, ctx, precision=precision), synthetic.OBJ_PARAM, TH_O, TH_I)
                 for k in range(1, args.objects)]
     specs = make_specs(args.precision)
-    sc = synthetic.make_scene(args.batch, seed=1000 + rank)
+    bb_lo, bb_hi = [int(v) for v in args.bbox_side.split(",")]
+    sc = synthetic.make_scene(args.batch, seed=1000 + rank, bbox_side=(bb_lo, bb_hi))
     if args.objects > 1:
         sc["dets"] = [(d[0], i % args.objects, d[2], d[3]) for i, d in enumerate(sc["dets"])]
     frames = torch.from_numpy(sc["images"]).cuda()

@@ -969,12 +969,12 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
 template <int NV>
 __device__ void block_reduce(double (&v)[NV], double* red /* LDS: >= 4*NV doubles */)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // waves past the fourth (pnp_score_kernel runs eight) only keep the barriers
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         double x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) red[wave * NV + k] = x;
+        if (lane == 0 && wave < 4) red[wave * NV + k] = x;
     }
     __syncthreads();
 #pragma unroll
@@ -1144,7 +1144,11 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
 // Kernel 2 of 4 -- scoring in OpenCV's order with the adaptive bound, then the two reduction passes
 // of the EPnP refit over the inliers of the winning hypothesis (centroid/covariance -> control
 // points; Gram sums).  One workgroup (256 threads) per problem.
-__global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
+// SCORE_NT threads: all of them count inliers (integers: any partition gives the same counts -- with detections of 200 - 450 px a candidate
+// carries up to 200 000 correspondences and this loop was a quarter of a step's kernel time); the refit's floating-point sums keep their
+// 256-thread partition (threads past 256 only keep the barriers), so a pose has the bits it always had.
+constexpr int SCORE_NT = 512;
+__global__ __launch_bounds__(SCORE_NT, 1) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
                                                               PnpResult* __restrict__ results, PnpFit* __restrict__ fits, int iterations,
                                                               double reproj_err, double confidence, int min_points, int n_solved, int first,
                                                               int* __restrict__ act, int round, int n_problems)
@@ -1181,7 +1185,7 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     }
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
     const int n_avail = min(n_hyp, n_solved);                           // hypotheses solved so far
-    for (int i = tid; i < n_avail * 12; i += 256) {
+    for (int i = tid; i < n_avail * 12; i += SCORE_NT) {
         const int h = i / 12, k = i - h * 12;
         const double v = hyp[((size_t)blockIdx.x * MAX_ITERS + h) * 12 + k];
         if (k < 9) s_R[h][k] = v; else s_t[h][k - 9] = v;
@@ -1214,16 +1218,16 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
 #pragma unroll
             for (int h = 0; h < SCORE_CHUNK; ++h) cnt[h] = 0;
             if (tid < SCORE_CHUNK) s_cnt[tid] = 0;
-            for (int i0 = tid; i0 < n; i0 += 4 * 256) {          // four points per trip: their 20 loads are in flight together
+            for (int i0 = tid; i0 < n; i0 += 4 * SCORE_NT) {     // four points per trip: their 20 loads are in flight together
                 float px[4], py[4], pz[4], pu[4], pv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int i = min(i0 + 256 * u, n - 1);
+                    const int i = min(i0 + SCORE_NT * u, n - 1);
                     px[u] = PX[i]; py[u] = PY[i]; pz[u] = PZ[i]; pu[u] = PU[i]; pv[u] = PV[i];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (i0 + 256 * u >= n) break;
+                    if (i0 + SCORE_NT * u >= n) break;
 #pragma unroll
                     for (int h = 0; h < SCORE_CHUNK; ++h)
                         if (h < hc) cnt[h] += is_inlier(s_R[it0 + h], s_t[it0 + h], cam, px[u], py[u], pz[u], pu[u], pv[u], thr2) ? 1 : 0;
@@ -1271,7 +1275,7 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
             out.n_inliers = 5; out.iters = 0; out.best_iter = 0; out.ok = 1;
             fit.state = 1;
         }
-        if (pb.mask) for (int i = tid; i < n; i += 256) pb.mask[i] = 1;
+        if (pb.mask) for (int i = tid; i < n; i += SCORE_NT) pb.mask[i] = 1;
         return;
     }
 
@@ -1290,7 +1294,7 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     // pass A: centroid and covariance of the inlier object points
     {
         double v[3] = {0, 0, 0};
-        for (int i0 = tid, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
+        for (int i0 = tid < 256 ? tid : n, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
             float px[4], py[4], pz[4], pu[4], pv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1309,7 +1313,7 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
         block_reduce<3>(v, s_red);
         double c0[3] = {v[0] / m, v[1] / m, v[2] / m};
         double q[6] = {0, 0, 0, 0, 0, 0};
-        for (int i0 = tid, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
+        for (int i0 = tid < 256 ? tid : n, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
             float px[4], py[4], pz[4], pu[4], pv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1351,7 +1355,7 @@ __global__ __launch_bounds__(256, P2P_PNP_FIT_WAVES) void pnp_score_kernel(const
     double g[56];
 #pragma unroll
     for (int k = 0; k < 56; k++) g[k] = 0;
-    for (int i0 = tid, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
+    for (int i0 = tid < 256 ? tid : n, k0 = 0; i0 < n; i0 += 4 * 256, k0 += 4) {
         float px[4], py[4], pz[4], pu[4], pv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1582,7 +1586,7 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
         hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems * wpp + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
                            min_points, h_begin, stops[r], ppb, act, r, wpp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, results, fits, iterations,
+        hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(pnp::SCORE_NT), 0, s, probs, workspace, results, fits, iterations,
                            reproj_err, confidence, min_points, stops[r], r == 0 ? 1 : 0, act, r, n_problems);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         h_begin = stops[r];
