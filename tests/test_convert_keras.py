@@ -140,3 +140,38 @@ def test_read_hdf5_on_keras_file_layouts(monkeypatch, tmp_path):
     assert CK.main(["convert_keras", "weights.hdf5", "paper", out_fn]) == 0
     w2 = W.load_weights(out_fn, "paper")
     assert np.array_equal(w2["deconv2.kernel"], W.synthetic_weights("paper", 6)["deconv2.kernel"])
+
+
+def test_read_hdf5_on_real_files(tmp_path):
+    """The same two layouts written as REAL HDF5 files with plain h5py (no Keras needed): layer groups with Keras' `weight_names`
+    attributes, a `layer_names` attribute at the root, the nested `model_1` front, and -- for the model.save layout -- the
+    `model_weights` / `optimizer_weights` groups and a `model_config` attribute.  Skipped where h5py is not installed (this image);
+    the dict-backed stand-in above imitates h5py by construction, this one does not."""
+    h5py = pytest.importorskip("h5py")
+
+    def write(path, keras, full_model):
+        with h5py.File(path, "w") as f:
+            root = f.create_group("model_weights") if full_model else f
+            layers = sorted({k.split("/")[0] for k in keras})
+            root.attrs["layer_names"] = [n.encode() for n in layers]
+            root.attrs["backend"] = b"tensorflow"
+            root.attrs["keras_version"] = b"2.2.1"
+            for key, arr in keras.items():
+                root.create_dataset(key, data=np.asarray(arr))
+            for layer in layers:
+                root[layer].attrs["weight_names"] = [k[len(layer) + 1:].encode() for k in keras if k.startswith(layer + "/")]
+            if full_model:
+                f.attrs["model_config"] = b'{"class_name": "Model"}'
+                opt = f.create_group("optimizer_weights")
+                opt.create_dataset("Adam/iterations:0", data=np.zeros(1))
+
+    for backbone, offset in (("paper", 1), ("resnet50", 22)):
+        w = W.synthetic_weights(backbone, 6)
+        keras = _fake_keras(backbone, w, offset)
+        for fn, full in (("weights.hdf5", False), ("model.hdf5", True)):
+            path = str(tmp_path / ("%s_%s" % (backbone, fn)))
+            write(path, keras, full)
+            flat = CK.read_hdf5(path)
+            assert not any("optimizer" in k or "Adam" in k for k in flat)
+            out = CK.convert_named(flat, backbone)
+            assert set(out) == set(w) and all(np.array_equal(out[k], w[k]) for k in w), (backbone, fn)

@@ -1,1 +1,4 @@
-python bench.py --steps 10 --warmup 2 --f32-steps 0 --host-frames 0 --latency 0 --cpu-sample 0 --general 10 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('value', d['value'], d.get('general_crops'))"
+cd /tmp && export TMPDIR=/tmp
+G=$GRAFT_REPO_ROOT/gpurun_out
+rm -rf $G/prof_blk
+rocprofv3 --kernel-trace --stats -d $G/prof_blk -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --blocking --no-legs > $G/blk.log 2>&1

@@ -6,7 +6,7 @@
 #      --sys-trace / HIP trace domain) -- and the bench lines (default, 30 objects, strict fp32, 2 ranks on one device)
 #   2. here: summarise the rocpd databases into profiles/
 set -e
-R=${1:-r02}
+R=${1:-r03}
 PROF="--steps 3 --warmup 1 --blocking --no-legs"
 PMC="--steps 1 --warmup 1 --blocking --no-legs"
 /usr/local/graft/bin/gpurun --timeout 2400 -- '
@@ -14,7 +14,10 @@ python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/gpu_tests.log
 cd /tmp && export TMPDIR=/tmp
 G=$GRAFT_REPO_ROOT/gpurun_out
 B=$GRAFT_REPO_ROOT/bench.py
-rm -rf $G/prof_final $G/pmc_fetch2 $G/pmc_write2 $G/pmc_sq1 $G/pmc_sq2 $G/pmc_sq3
+rm -rf $G/prof_final $G/pmc_fetch2 $G/pmc_write2 $G/pmc_sq1 $G/pmc_sq2 $G/pmc_sq3 $G/prof_call $G/prof_small1 $G/prof_small3
+rocprofv3 --kernel-trace -d $G/prof_call -o t -- python $GRAFT_REPO_ROOT/tools/single_det.py 10 > $G/call.log 2>&1
+rocprofv3 --kernel-trace -d $G/prof_small1 -o t -- python $GRAFT_REPO_ROOT/tools/time_small.py resnet50 3 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $G/prof_small3 -o t -- python $GRAFT_REPO_ROOT/tools/time_small.py resnet50 3 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $G/prof_final -o bench -- python $B '"$PROF"' > $G/bench_final_prof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $G/pmc_fetch2 -o x -- python $B '"$PMC"' > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $G/pmc_write2 -o x -- python $B '"$PMC"' > /dev/null 2>&1
@@ -23,7 +26,10 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS -d $G/pmc_sq3 -o x -- python $B '"$PMC"' > $G/pmc_sq3.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/'"$R"'_traffic.json > /dev/null   # bench.py reads it
-python bench.py --steps 5 --warmup 2 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+python tools/single_det.py 200 > gpurun_out/single_det.log 2>&1
+python tools/time_small.py resnet50 50 > gpurun_out/small_passes.log 2>&1
+P2P_STREAM_WGS=0 python tools/time_small.py resnet50 50 1,3,8 >> gpurun_out/small_passes.log 2>&1
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --objects 30 --no-legs > gpurun_out/bench_objects30.json 2>> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --precision f32 --no-legs > gpurun_out/bench_f32.json 2>> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --masks --no-legs > gpurun_out/bench_masks.json 2>> gpurun_out/bench_final.err
@@ -36,6 +42,11 @@ python tools/rocprof_summary.py gpurun_out/prof_final/bench_results.db > profile
 python tools/layer_times.py gpurun_out/prof_final/bench_results.db > profiles/${R}_layer_times.txt
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/${R}_traffic.json | head -4
 python tools/pmc_sq.py gpurun_out/pmc_sq1/x_results.db gpurun_out/pmc_sq2/x_results.db gpurun_out/pmc_sq3/x_results.db > profiles/${R}_sq_counters.txt
+python tools/trace_call.py gpurun_out/prof_call/t_results.db > profiles/${R}_single_det_trace.txt
+python tools/trace_small.py gpurun_out/prof_small1/t_results.db > profiles/${R}_small_pass_n1.txt
+python tools/trace_small.py gpurun_out/prof_small3/t_results.db > profiles/${R}_small_pass_n3.txt
+grep -h "single est_pose\|C call" gpurun_out/single_det.log > profiles/${R}_single_det.txt
+grep -h resnet50 gpurun_out/small_passes.log > profiles/${R}_small_passes.txt
 for f in bench_final:bench_line bench_objects30:bench_line_objects30 bench_f32:bench_line_f32mode bench_masks:bench_line_masks bench_2ranks_same_device:bench_line_2ranks_same_device bench_k20:bench_line_k20 bench_paper:bench_line_paper_backbone; do
     grep '^{' gpurun_out/${f%%:*}.json | tail -1 > profiles/${R}_${f##*:}.json
 done
