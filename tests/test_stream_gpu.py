@@ -65,3 +65,33 @@ def test_crop_alone_equals_crop_inside_a_large_batch(backbone):
     d3, p3 = g.predict(x[20:23])            # the stage-2 pass of one detection: K = 3 inputs
     np.testing.assert_array_equal(dec[20:23], d3)
     np.testing.assert_array_equal(prob[20:23], p3)
+
+
+@pytest.mark.parametrize("inject", [True, False])
+def test_est_pose_alone_equals_est_pose_inside_a_batch(inject):
+    """The whole call, not only the generator: a detection handed over alone (the reference's loop: small-launch generator kernels, segmented
+    glue kernels, two-launch correspondence build) returns the very same record -- R, t, counts, box, selected candidate -- as inside a batch
+    of 40 (batched kernels throughout).  With injected decoder maps (a pose worth comparing) and with the random-weight generator's own
+    output driving the masks (whatever it yields must not depend on the batch)."""
+    import torch
+    from pix2pose_amd import synthetic as S
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
+    ctx = Context(0, max_batch=160)
+    gen = Generator(W.synthetic_weights("resnet50", 11), "resnet50", ctx)
+    spec = ObjectSpec(gen, S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2)
+    sc = S.make_scene(40, seed=77, bbox_side=(60, 140))
+    j1 = torch.from_numpy(sc["inject1"]).cuda()
+    j2 = torch.from_numpy(sc["inject2"]).cuda()
+    torch.cuda.synchronize()
+
+    def key(p):
+        return (p.status, p.n_inliers, p.n_init_mask, p.best_slot, p.n_candidates, p.ransac_iters, tuple(p.bbox_t), tuple(p.R), tuple(p.t), p.frac_inlier)
+
+    kw = dict(inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3) if inject else {}
+    batch, _ = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], **kw)
+    if inject:
+        assert sum(p.status == 0 for p in batch) >= 36
+    for i in (0, 7, 23, 39):
+        kw1 = dict(inject1=j1[i:i + 1].data_ptr(), inject2=j2[i:i + 1].data_ptr(), inject_slots=3) if inject else {}
+        one, _ = est_pose_batch(ctx, [spec], list(sc["images"]), [sc["dets"][i]], **kw1)
+        assert key(one[0]) == key(batch[i]), i
