@@ -120,9 +120,6 @@ struct StreamMulti {
 bool igemm_stream_supported(const IgemmParams& p);
 void stream_phase_of(const IgemmParams& p, const StreamOrder& o, StreamPhase* ph);
 hipError_t launch_igemm_stream(const IgemmParams& p, const StreamMulti& mp, hipStream_t s);
-// The same contract with the work of a tile split over a workgroup (igemm_coop.hip): two loader waves (row-major loads, split, LDS),
-// one or two MFMA waves; what runs by default.  launch_igemm_stream is kept as the one-wave form it was measured against.
-hipError_t launch_igemm_coop(const IgemmParams& p, const StreamMulti& mp, hipStream_t s);
 
 // Halo-tiled kernel for the merged output heads (heads.hip); takes the same parameter block as the
 // generic kernel when heads_halo_supported() says so (PREC_F16X3, 64-wide grid, 128 input channels).

@@ -666,10 +666,7 @@ static int launch_prepared(Ctx& X, const PreparedConv* pc, int n)
         for (int i = 0; i < n; ++i) stream_phase_of(pc[i].p, pc[i].so, &mp.ph[i]);
     } else if (n != 1) { set_error("launch_prepared: only streaming launches merge"); return P2P_ERR_INVALID_ARG; }
     const IgemmParams& p = c0.p;
-    // development switch (A/B): P2P_SMALL_KERNEL=coop runs the workgroup-cooperative form of the small-launch kernel (igemm_coop.hip) -- same
-    // bits, and measured the same speed: both sit at what ONE CU can stream (~35 GB/s: 8 KB of operands per K-step = 235 ns, tools/load_pattern2.hip)
-    static const bool coop = getenv("P2P_SMALL_KERNEL") && !strcmp(getenv("P2P_SMALL_KERNEL"), "coop");
-    auto launch = [&]() { return c0.stream ? (coop ? launch_igemm_coop(p, mp, st) : launch_igemm_stream(p, mp, st)) : c0.halo ? launch_heads_halo(p, st) : c0.halo_conv ? launch_igemm_halo(p, st) :
+    auto launch = [&]() { return c0.stream ? launch_igemm_stream(p, mp, st) : c0.halo ? launch_heads_halo(p, st) : c0.halo_conv ? launch_igemm_halo(p, st) :
                                  c0.halo8 ? launch_igemm_halo8(p, st) : c0.halo_s2 ? launch_igemm_halo_s2(p, st) : launch_igemm(p, c0.cfg, st); };
     if (X.profiling) {
         double fl = 0;

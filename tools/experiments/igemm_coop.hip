@@ -1,3 +1,7 @@
+// EXPERIMENT, not part of the library (measured in round 3, same bits and the same 237 ns per K-step as pix2pose_amd/csrc/igemm_stream.hip:
+// both are bound by what one CU can stream, DESIGN.md section 3 "Small launches").  To try it again: copy next to igemm_stream.hip, add it to
+// pix2pose_amd/build.py SOURCES, declare launch_igemm_coop in kernels.h and call it instead of launch_igemm_stream in model.hip:launch_prepared.
+//
 // Small-launch implicit GEMM, cooperative form (gfx950, PREC_F16X3): one workgroup per 32x32 (or 64x32) output tile; four LOADER waves
 // stream the operands global -> registers (8 K-steps in flight) -> LDS, one or two MFMA waves walk the tile's chain out of LDS.
 //
@@ -16,7 +20,7 @@
 //   * one s_barrier per K-step with an LDS-only wait (a __syncthreads() would also wait for the loaders' global loads in flight).
 // Stage protocol (buffer = step mod 3): at barrier B_s steps <= s + 1 are in LDS and the MFMA waves have finished reading step s;
 // after it the loaders overwrite buffer (s + 2) mod 3, whose step s - 1 was last read before B_{s-1}.
-#include "kernels.h"
+#include "../../pix2pose_amd/csrc/kernels.h"
 #include <cstdlib>
 
 namespace p2p {
