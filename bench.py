@@ -25,7 +25,7 @@ Extra legs (N=1, after the timed region; none of them changes `value`):
                     reference's own loop shape -- est_pose once per roi (tools/5_evaluation_bop_basic.py:289-304)
   contract          host frames in AND the full return tuple out (valid_mask, img_pred) at the headline's K steps
   general_crops     the same 256-detection step with bbox sides ~U(40, 300) px (non-identity resizes, n = side^2 correspondences), with and
-                    without the anti-aliasing filter of scikit-image 0.15 - 0.18
+                    without the anti-aliasing filter of scikit-image 0.17 - 0.18
   pose_delta_vs_oracle  the CPU-baseline sample's detections also run on the GPU: max |dt| (mm), max rotation delta (deg), exact integer matches
   cpu_baseline      the CPU restatement on the host cores (tuned torch/oneDNN fp32 network + numpy/C glue and PnP)
 """
@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--general", type=int, default=-1, help="steps of the general-crop-size legs (N=1; -1 = as many as --steps, 0 = skip)")
     ap.add_argument("--latency", type=int, default=100, help="calls of the single-detection latency leg (N=1; 0 = skip)")
     ap.add_argument("--merge", action="store_true", help="stream mode: merge step i's stage-2 generator pass with step i+1's stage-1 pass (p2p_est_pose_opts.merge_stream_passes)")
-    ap.add_argument("--anti-aliasing", action="store_true", help="scikit-image 0.15 - 0.18 resize semantics (Gaussian pre-filter whenever a resize shrinks)")
+    ap.add_argument("--anti-aliasing", action="store_true", help="scikit-image 0.17 - 0.18 resize semantics (Gaussian pre-filter whenever a resize shrinks)")
     ap.add_argument("--bbox-side", default="86,86", help="range of detection box sides in px (default 86 = 128-px crops, the headline workload; "
                     "e.g. 40,300 for general crop sizes -- profiling runs)")
     ap.add_argument("--no-legs", action="store_true", help="skip the f32 / host-frame / latency / CPU legs (profiling runs)")
@@ -451,7 +451,7 @@ def main():
         out["host_frames_value"] = out["host_frames"]["value"]
         del pool
     # -- general crop sizes: the same step with bbox sides ~U(40, 300) px: every resize is a real resampling (recognition.py:82,103,121,134-146)
-    #    and a candidate carries side^2 correspondences instead of 16 384; with and without the anti-aliasing filter (scikit-image 0.15 - 0.18)
+    #    and a candidate carries side^2 correspondences instead of 16 384; with and without the anti-aliasing filter (scikit-image 0.17 - 0.18)
     if solo and args.general > 0:
         scg = synthetic.make_scene(args.batch, seed=2000, bbox_side=(40, 300))
         gj1 = torch.from_numpy(scg["inject1"]).cuda()

@@ -204,9 +204,12 @@ typedef struct {
     /* skimage.transform.resize version switch.  The reference calls resize(order=1) six times per detection
      * (recognition.py:82,103,121,134,144,146) and does not pin scikit-image (requirements.txt does not list it):
      *   0 (default): scikit-image <= 0.14 -- plain bilinear warp;
-     *   1: scikit-image 0.15 - 0.18, where anti_aliasing=True became the default -- every DOWN-scaling resize is preceded
+     *   1: scikit-image 0.17 - 0.18: anti_aliasing is on by default for float images -- every DOWN-scaling resize of one is preceded
      *      by scipy.ndimage.gaussian_filter(sigma = (in/out - 1)/2, truncate 4, border 'mirror' / 'constant'+cval, result
-     *      kept in the array's dtype), restated in csrc/resize_aa.hip.
+     *      kept in the array's dtype), restated in csrc/resize_aa.hip -- and off for BOOL images (the keep mask of
+     *      recognition.py:103: "Gaussian convolution is not defined with bool data type").  0.15 / 0.16, where the default first became
+     *      True, ran the filter on that bool array as well, whose bool result is an erosion to the pixels whose weighted sum is
+     *      exactly 1.0; that generation is NOT modelled.
      * (scikit-image >= 0.19 rejects the bool array of recognition.py:103, so the reference does not run there.)
      * clip=True of resize (output clamped to the input's range, cval preserved) is common to all versions and always on. */
     int resize_anti_aliasing;

@@ -8,7 +8,7 @@ quirks listed in SURVEY.md section 8a-Q.  Third-party pieces are replaced by res
     centres, per-tap border handling 'reflect' / 'constant'+cval, ``clip=True`` output clipping to the input's
     range with cval preservation).  The scikit-image version is unpinned in the reference (requirements.txt does
     not list it): ``anti_aliasing=False`` (default here) is scikit-image <= 0.14, ``anti_aliasing=True`` is the
-    0.15 - 0.18 default: ``scipy.ndimage.gaussian_filter`` with sigma = (in/out - 1)/2 per down-scaled axis --
+    0.17 - 0.18 default: ``scipy.ndimage.gaussian_filter`` with sigma = (in/out - 1)/2 per down-scaled axis --
     the REAL scipy routine skimage calls, not a restatement -- before the warp.  (>= 0.19 refuses the bool
     array recognition.py:103 passes, so the reference cannot run there at all.)
   * ``cv2.solvePnPRansac`` / ``cv2.Rodrigues`` -> oracle/pnp_oracle.c
@@ -45,12 +45,18 @@ def resize_bilinear(img, out_shape, mode, cval=0.0, anti_aliasing=False, clip=Tr
     """img [H,W] or [H,W,C] (bool/float) -> float64 [oh,ow(,C)].
     src = dst*scale + (0.5*scale - 0.5), scale = in/out; taps floor/ceil; out-of-range taps are
     reflected ('reflect') or replaced by cval ('constant').
-    anti_aliasing (skimage 0.15-0.18 default): Gaussian pre-filter, sigma = max(0, (in/out - 1)/2) per axis, truncated at
+    anti_aliasing (skimage 0.17-0.18 semantics: on by default for float images, off for bool ones): Gaussian pre-filter, sigma = max(0, (in/out - 1)/2) per axis, truncated at
     4 sigma, border mode 'mirror' (for 'reflect') or 'constant' with cval; the filter keeps the input's dtype (a float32
     map is rounded to float32 after each axis pass, exactly what scipy does for skimage).
     clip (skimage default): the output is clipped to [min, max] of the (filtered) input; in 'constant' mode with cval
     outside that range, pixels exactly equal to cval are kept (skimage._shared / transform._warps._clip_warp_output)."""
     a0 = np.asarray(img)
+    if a0.dtype == bool:
+        # scikit-image 0.17 / 0.18: `anti_aliasing` defaults to "not a bool image" ("Gaussian convolution is not defined with bool data
+        # type": a FutureWarning there, a ValueError from 0.19 on) -- the one bool input of the path is the keep mask of recognition.py:103.
+        # (0.15 / 0.16 ran scipy's filter on the bool array, whose bool OUTPUT keeps only pixels whose weighted sum is exactly 1.0: an
+        # erosion down to a few percent of the mask.  That generation is not modelled.)
+        anti_aliasing = False
     if a0.dtype == bool or a0.dtype.kind not in "f":
         a0 = a0.astype(np.float64)                  # img_as_float(bool / ints used here) -> float64
     h, w = a0.shape[:2]

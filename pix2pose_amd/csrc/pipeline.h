@@ -31,7 +31,7 @@ struct DetInfo {
     int ok1;                // 0 => recognition.py:78-79 early return
     long long corr_off;     // float offset of this detection's correspondence storage
     int corr_cap;           // points per candidate (stage-1 side squared)
-    int aa;                 // anti-aliased resizes (scikit-image 0.15 - 0.18 default), p2p_est_pose_opts.resize_anti_aliasing
+    int aa;                 // anti-aliased resizes (scikit-image 0.17 - 0.18 default), p2p_est_pose_opts.resize_anti_aliasing
     long long cv_off;       // double offset of this detection's (1 + K) canvases of corr_cap * 3 doubles each (aa, side > 128)
     int src_index;          // index of this detection in the caller's array (detections are processed sorted by object)
 };
@@ -132,12 +132,10 @@ struct PinnedBuf {
 struct AaPtrs {
     AaItem* k0;   // [n]        stage-1 canvases           (side > 128)
     AaItem* k1;   // [n*K]      stage-2 canvases           (side > 128)
-    AaItem* k2;   // [n*K]      keep masks, 128x128        (stage-1 side < 128)
     AaItem* k3;   // [n*K*5]    prob, pred r/g/b, non_gray (stage-2 side < 128)
 };
 struct AaBufs {
     double *cv, *cv_tmp;      // canvases: per detection (1 + K) x corr_cap x 3 doubles at DetInfo::cv_off
-    double *kp, *kp_tmp;      // keep masks: [n*K][128*128]
     double *bk, *bk_tmp;      // back-resize planes: [n*K][5][128*128]
 };
 struct BatchGroup { int obj, begin, end; };   // detections [begin, end) of the sorted batch belong to object `obj`
@@ -152,7 +150,7 @@ struct Slot {
     DevBuf sacc;                        // few detections: global accumulators of the segmented stage-1 reductions (self-clearing)
     int sacc_n = 0;
     DevBuf crec, cseg;                  // few candidates: per-pixel records and per-segment counts of the two-launch correspondence build
-    DevBuf aa_items, aa_cv, aa_cv_tmp, aa_kp, aa_kp_tmp, aa_bk, aa_bk_tmp;   // anti-aliased resizes: descriptors, canvases, 128x128 planes
+    DevBuf aa_items, aa_cv, aa_cv_tmp, aa_bk, aa_bk_tmp;   // anti-aliased resizes: descriptors, canvases, 128x128 planes
     DevBuf mask, pred, dmask, mstat;    // optional outputs of the batch (valid_mask_full, img_pred_f, detector masks, IoU sums)
     p2p_pose* host_poses = nullptr;     // pinned
     size_t host_cap = 0;
@@ -169,7 +167,7 @@ struct Slot {
     bool stage2_pending = false;        // stage-2 inputs are built, the stage-2 generator pass and the tail are not enqueued yet
     int tail_cap = 0;                   // network inputs of a following batch that fit behind this batch's stage-2 inputs
     int max_side = 0;
-    AaPtrs aa = {nullptr, nullptr, nullptr, nullptr};
+    AaPtrs aa = {nullptr, nullptr, nullptr};
     std::vector<int> img_hw, img_w;     // H*W and W of each detection's frame (sorted order)
     long long cmask_stride = 0, cpred_stride = 0;   // bytes per detection of the compact mask / image landing buffers
     p2p_est_pose_opts opt;              // the caller's output pointers (host), filled at collect time

@@ -73,7 +73,7 @@ Pipeline::~Pipeline()
 {
     for (Slot& s : slot) {
         for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images, &s.crec, &s.cseg, &s.sacc,
-                          &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_kp, &s.aa_kp_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
+                          &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
         for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat, &s.h_frames}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
         if (s.done) (void)hipEventDestroy(s.done);
@@ -369,9 +369,9 @@ __global__ __launch_bounds__(256) void stage1_stats_seg_kernel(const DetInfo* __
     A = z;                                           // cleared for the next batch that uses this slot
 }
 
-// resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square.  kp: the anti-aliased keep
-// image (null: the raw mask from the network output); [kmin, kmax]: range of the warp input (clip=True).
-__device__ inline bool keep_ori_at(const float* y1d, const double* kp, float th, double kmin, double kmax, int r, int c, int S, int Sw)
+// resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square.  The keep mask is a BOOL image: no scikit-image
+// generation this library models filters it (see aa_plan_kernel); [kmin, kmax]: range of the warp input (clip=True).
+__device__ inline bool keep_ori_at(const float* y1d, float th, double kmin, double kmax, int r, int c, int S, int Sw)
 {
     const Tap tr = axis_tap(r, 128, S), tc = axis_tap(c, 128, Sw);
     double v[2][2];
@@ -380,11 +380,8 @@ __device__ inline bool keep_ori_at(const float* y1d, const double* kp, float th,
         for (int e = 0; e < 2; ++e) {
             double k = 0.0;
             if (P2P_TAP_LIVE(a, e, tr, tc) && ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
-                if (kp) k = kp[ri[a] * 128 + cj[e]];
-                else {
-                    const float* q = y1d + ((size_t)ri[a] * 128 + cj[e]) * 4;
-                    k = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
-                }
+                const float* q = y1d + ((size_t)ri[a] * 128 + cj[e]) * 4;
+                k = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
             }
             v[a][e] = k;
         }
@@ -393,7 +390,7 @@ __device__ inline bool keep_ori_at(const float* y1d, const double* kp, float th,
 
 // value of the stage-2 canvas (recognition.py:113-120) at canvas position (r, c), channel ch: the frame pixel where the
 // kept mask says foreground, zero elsewhere
-__device__ inline bool stage2_fg(const DetInfo& D, const Stage1& S, const float* y1d, const double* kp, int slot, int r, int c, int* fy, int* fx)
+__device__ inline bool stage2_fg(const DetInfo& D, const Stage1& S, const float* y1d, int slot, int r, int c, int* fy, int* fx)
 {
     const Boxes& b1 = D.b1;
     const Boxes& b = S.b2;
@@ -403,7 +400,7 @@ __device__ inline bool stage2_fg(const DetInfo& D, const Stage1& S, const float*
     *fy = y; *fx = x;
     // bg_full: True outside the stage-1 clipped crop, ~keep_ori inside   (:105-106)
     if (y >= b1.v1 && y < b1.v2 && x >= b1.u1 && x < b1.u2)
-        return keep_ori_at(y1d, kp, D.th_o[slot], S.kmin[slot], S.kmax[slot], y - b1.v1_ori, x - b1.u1_ori, b1.v2_ori - b1.v1_ori, b1.u2_ori - b1.u1_ori);
+        return keep_ori_at(y1d, D.th_o[slot], S.kmin[slot], S.kmax[slot], y - b1.v1_ori, x - b1.u1_ori, b1.v2_ori - b1.v1_ori, b1.u2_ori - b1.u1_ori);
     return false;
 }
 
@@ -437,13 +434,12 @@ __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __rest
         return;
     }
     const float* y1d = y1 + (size_t)d * 16384 * 4;
-    const double* kp = (aa.k2 && aa.k2[cand].radius > 0) ? aa.k2[cand].a : nullptr;
     bool fg[2][2];
     int fy[2][2], fx[2][2];
     for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 2; ++e) {
             fy[a][e] = fx[a][e] = 0;
-            fg[a][e] = P2P_TAP_LIVE(a, e, tr, tc) && stage2_fg(D, S, y1d, kp, slot, r[a], c[e], &fy[a][e], &fx[a][e]);
+            fg[a][e] = P2P_TAP_LIVE(a, e, tr, tc) && stage2_fg(D, S, y1d, slot, r[a], c[e], &fy[a][e], &fx[a][e]);
         }
     for (int ch = 0; ch < 3; ++ch) {
         double v[2][2];
@@ -913,7 +909,7 @@ __global__ void aa_plan_kernel(const DetInfo* __restrict__ dets, const Stage1* _
     const int S1 = D.b1.v2_ori - D.b1.v1_ori;
     const size_t cap3 = (size_t)D.corr_cap * 3;
     if (phase == 0) {
-        aa_item_off(aa.k1[t]); aa_item_off(aa.k2[t]);
+        aa_item_off(aa.k1[t]);
         for (int j = 0; j < 5; ++j) aa_item_off(aa.k3[t * 5 + j]);
         if (slot == 0) {
             AaItem I;
@@ -929,12 +925,8 @@ __global__ void aa_plan_kernel(const DetInfo* __restrict__ dets, const Stage1* _
     }
     const Stage1& S = s1[d];
     if (!D.aa || !D.ok1 || slot >= D.n_th) return;
-    if (S1 < 128 && S.keep_cnt[slot] >= 10 && tab.rad[S1] > 0) {        // :103 shrinks the 128x128 keep mask to the stage-1 square
-        AaItem& I = aa.k2[t];
-        I.a = B.kp + (size_t)t * 16384; I.tmp = B.kp_tmp + (size_t)t * 16384;
-        I.H = I.W = 128; I.C = 1; I.radius = tab.rad[S1]; I.w = tab.w + tab.off[S1];
-        I.mode = 1; I.cval = 0.0; I.round32 = 0;                          // bool -> float64
-    }
+    // :103 shrinks the 128x128 keep mask to the stage-1 square -- a BOOL image: scikit-image 0.17 / 0.18 do not filter those
+    // (anti_aliasing defaults to "not bool"; 0.15 / 0.16 ran the filter into a bool array, an erosion that is not modelled): nothing to plan for it.
     if (!S.valid2[slot]) return;
     const int S2 = S.b2.v2_ori - S.b2.v1_ori;
     if (S2 > 128 && S2 <= tab.max_side && tab.rad[S2] > 0) {              // :121 shrinks the stage-2 canvas to 128
@@ -968,33 +960,6 @@ __global__ __launch_bounds__(256) void aa_canvas1_kernel(const DetInfo* __restri
     }
 }
 
-// keep masks as float (recognition.py:94-95,103).  grid (64, n*K)
-__global__ __launch_bounds__(256) void aa_keep_fill_kernel(const DetInfo* __restrict__ dets, const float* __restrict__ y1, int K, AaPtrs aa)
-{
-    const int t = blockIdx.y;
-    const AaItem& I = aa.k2[t];
-    if (I.radius <= 0) return;
-    const int d = t / K, slot = t - d * K;
-    const float th = dets[d].th_o[slot];
-    const float* y1d = y1 + (size_t)d * 16384 * 4;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < 16384; p += gridDim.x * 256) {
-        const float* q = y1d + (size_t)p * 4;
-        I.a[p] = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
-    }
-}
-
-// filtered keep-mask range -> Stage1 (clip=True of the :103 resize).  one thread per (detection, slot)
-__global__ void aa_keep_range_kernel(Stage1* __restrict__ s1, int n, int K, AaPtrs aa)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * K) return;
-    const AaItem& I = aa.k2[t];
-    if (I.radius <= 0) return;
-    const int d = t / K, slot = t - d * K;
-    s1[d].kmin[slot] = I.vmin;
-    s1[d].kmax[slot] = I.vmax;
-}
-
 // stage-2 canvases (recognition.py:113-120).  grid (64, n*K)
 __global__ __launch_bounds__(256) void aa_canvas2_kernel(const DetInfo* __restrict__ dets, const Stage1* __restrict__ s1,
                                                          const float* __restrict__ y1, int K, AaPtrs aa)
@@ -1006,12 +971,11 @@ __global__ __launch_bounds__(256) void aa_canvas2_kernel(const DetInfo* __restri
     const DetInfo& D = dets[d];
     const Stage1& S = s1[d];
     const float* y1d = y1 + (size_t)d * 16384 * 4;
-    const double* kp = aa.k2[t].radius > 0 ? aa.k2[t].a : nullptr;     // (never both: stage-2 side > 128 implies stage-1 side > 128)
     const int npx = I.H * I.W;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
         const int r = p / I.W, c = p - r * I.W;
         int fy = 0, fx = 0;
-        const bool fg = stage2_fg(D, S, y1d, kp, slot, r, c, &fy, &fx);
+        const bool fg = stage2_fg(D, S, y1d, slot, r, c, &fy, &fx);
         for (int ch = 0; ch < 3; ++ch) I.a[(size_t)p * 3 + ch] = fg ? frame_px(D, fy, fx, ch) : 0.0;
     }
 }
@@ -1301,17 +1265,17 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
     if ((rc = SL.crange.reserve(sizeof(CandRange) * (size_t)n * K))) return rc;
     if (n * K <= 16 && ((rc = SL.crec.reserve(sizeof(unsigned) * (size_t)std::max<long long>(corr_total / 5, 1))) ||
                         (rc = SL.cseg.reserve(sizeof(CorrSeg) * CORR_SEG * (size_t)n * K)))) return rc;
-    SL.aa = {nullptr, nullptr, nullptr, nullptr};
-    AaBufs aab = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SL.aa = {nullptr, nullptr, nullptr};
+    AaBufs aab = {nullptr, nullptr, nullptr, nullptr};
     AaTable aat;
     if (use_aa) {
         if ((rc = aa_table_get(X.device, &aat))) return rc;
         const size_t cvb = sizeof(double) * (size_t)std::max<long long>(cv_total, 1), plane = sizeof(double) * 16384 * (size_t)n * K;
-        if ((rc = SL.aa_items.reserve(sizeof(AaItem) * (size_t)(n + 7 * n * K))) || (rc = SL.aa_cv.reserve(cvb)) || (rc = SL.aa_cv_tmp.reserve(cvb)) ||
-            (rc = SL.aa_kp.reserve(plane)) || (rc = SL.aa_kp_tmp.reserve(plane)) || (rc = SL.aa_bk.reserve(plane * 5)) || (rc = SL.aa_bk_tmp.reserve(plane * 5))) return rc;
+        if ((rc = SL.aa_items.reserve(sizeof(AaItem) * (size_t)(n + 6 * n * K))) || (rc = SL.aa_cv.reserve(cvb)) || (rc = SL.aa_cv_tmp.reserve(cvb)) ||
+            (rc = SL.aa_bk.reserve(plane * 5)) || (rc = SL.aa_bk_tmp.reserve(plane * 5))) return rc;
         AaItem* it = SL.aa_items.as<AaItem>();
-        SL.aa = {it, it + n, it + n + n * K, it + n + 2 * n * K};
-        aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_kp.as<double>(), SL.aa_kp_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
+        SL.aa = {it, it + n, it + n + n * K};
+        aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
     }
     // -- optional outputs: argument checks, landing buffers and the detector-mask upload (read during submit)
     const bool want_mask = opt.valid_mask != nullptr, want_pred = opt.img_pred != nullptr, want_iou = opt.det_mask != nullptr;
@@ -1372,15 +1336,11 @@ static int enqueue_mid(Ctx& X, Slot& SL, hipStream_t st, float* y1)
     } else
         hipLaunchKernelGGL(stage1_stats_kernel, dim3(n), dim3(n <= 64 ? 1024 : 256), 0, st, d_det, y1, d_s1);
     HIP_TRY(hipGetLastError());
-    if (SL.use_aa) {      // anti-aliased keep masks (stage-1 sides < 128) and stage-2 canvases (sides > 128)
+    if (SL.use_aa) {      // anti-aliased stage-2 canvases (sides > 128; the bool keep masks of sides < 128 are not filtered, see aa_plan_kernel)
         AaTable aat;
         if ((rc = aa_table_get(X.device, &aat))) return rc;
-        AaBufs aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_kp.as<double>(), SL.aa_kp_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
+        AaBufs aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
         hipLaunchKernelGGL(aa_plan_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_det, d_s1, n, K, 1, aat, aab, SL.aa);
-        hipLaunchKernelGGL(aa_keep_fill_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, y1, K, SL.aa);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(launch_aa_filter(SL.aa.k2, n * K, 16384, st));
-        hipLaunchKernelGGL(aa_keep_range_kernel, dim3((n * K + 63) / 64), dim3(64), 0, st, d_s1, n, K, SL.aa);
         hipLaunchKernelGGL(aa_canvas2_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, d_s1, y1, K, SL.aa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(launch_aa_filter(SL.aa.k1, n * K, SL.max_side * SL.max_side * 3, st));

@@ -1,4 +1,4 @@
-// Anti-aliased resizes: the Gaussian pre-filter scikit-image 0.15 - 0.18 applies by default before down-scaling
+// Anti-aliased resizes: the Gaussian pre-filter scikit-image 0.17 - 0.18 applies by default before down-scaling
 // (skimage.transform.resize(anti_aliasing=True) -> scipy.ndimage.gaussian_filter(image, sigma, mode, cval) -> warp), for all
 // six resize call sites of est_pose (reference recognition.py:82,103,121,134,144,146).  The reference does not pin its
 // scikit-image version (requirements.txt does not list it): p2p_est_pose_opts.resize_anti_aliasing selects this behaviour,

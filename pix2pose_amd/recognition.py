@@ -64,7 +64,7 @@ class pix2pose():
         ctx = kwargs.get("ctx") or runtime.default_context(kwargs.get("device", 0))
         weights = weight_fn if isinstance(weight_fn, dict) else W.load_weights(weight_fn, backbone)
         self.ctx = ctx
-        # skimage.transform.resize semantics: False = scikit-image <= 0.14 (no anti-aliasing), True = 0.15 - 0.18 (Gaussian
+        # skimage.transform.resize semantics: False = scikit-image <= 0.14 (no anti-aliasing), True = 0.17 - 0.18 (Gaussian
         # pre-filter when down-scaling); the reference does not pin the version
         self.anti_aliasing = bool(kwargs.get("anti_aliasing", False))
         self.generator_train = runtime.Generator(weights, backbone, ctx)

@@ -235,7 +235,7 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
                    want_masks=False, debug=False, ransac_iterations=0, reprojection_error=0.0, confidence=0.0,
                    det_masks=None, anti_aliasing=False):
     """detections: list of (image_idx, object_idx, bbox[v1,u1,v2,u2], camK 3x3).
-    anti_aliasing: scikit-image 0.15-0.18 resize semantics (Gaussian pre-filter when down-scaling); default = <= 0.14.
+    anti_aliasing: scikit-image 0.17-0.18 resize semantics (Gaussian pre-filter when down-scaling); default = <= 0.14.
     Returns (poses: list[_lib.Pose], extras: dict)."""
     n = len(detections)
     objs, imgs, dets, opts, extras, keep = _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks,

@@ -107,7 +107,7 @@ def test_injected_scenes_general_crop_sizes(rig):
 
 
 def test_anti_aliased_resizes_small_crops(rig):
-    """p2p_est_pose_opts.resize_anti_aliasing (scikit-image 0.15 - 0.18): crop sides 60..126 px -- the keep mask and the
+    """p2p_est_pose_opts.resize_anti_aliasing (scikit-image 0.17 - 0.18): crop sides 60..126 px -- the keep mask and the
     prob / img_pred / non_gray maps are Gaussian-filtered (scipy.ndimage.gaussian_filter in the oracle, csrc/resize_aa.hip on
     the device; float32 maps rounded per axis pass) before they shrink to the crop; network inputs are up-scaled (no filter).
     Same exactness as without the filter: masks, u8 images, counts, boxes bit for bit."""

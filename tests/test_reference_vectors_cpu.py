@@ -39,7 +39,7 @@ def test_shim_get_boxes_matches_reference():
 @pytest.mark.parametrize("key", ["scenes", "scenes_aa"])
 def test_est_pose_matches_reference(key):
     """"scenes": resize stand-in without anti-aliasing (scikit-image <= 0.14); "scenes_aa": with the Gaussian pre-filter of
-    scikit-image 0.15 - 0.18 (scipy.ndimage.gaussian_filter itself)."""
+    scikit-image 0.17 - 0.18 (scipy.ndimage.gaussian_filter itself)."""
     n = 0
     aa = key == "scenes_aa"
     for s in G[key]:

@@ -23,7 +23,7 @@ def _crc(a):
 @pytest.mark.parametrize("key", ["scenes", "scenes_aa"])
 def test_est_pose_pipeline_matches_reference_vectors(key):
     """"scenes_aa": p2p_est_pose_opts.resize_anti_aliasing = 1 against the reference run with an anti-aliasing resize
-    (scikit-image 0.15 - 0.18 semantics; the Gaussian filter there was scipy.ndimage's own)."""
+    (scikit-image 0.17 - 0.18 semantics; the Gaussian filter there was scipy.ndimage's own)."""
     import torch
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
     ctx = Context(0, max_batch=16)
