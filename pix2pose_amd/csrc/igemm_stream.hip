@@ -259,8 +259,6 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
 
 }  // namespace
 
-static int stream_depth() { static const int v = getenv("P2P_STREAM_D") ? atoi(getenv("P2P_STREAM_D")) : 0; return v; }
-
 bool igemm_stream_supported(const IgemmParams& p)
 {
     if (p.prec != PREC_F16X3 || p.mode != EPI_NORMAL || p.n_groups > 1) return false;
@@ -288,13 +286,10 @@ void stream_phase_of(const IgemmParams& p, const StreamOrder& o, StreamPhase* ph
 hipError_t launch_igemm_stream(const IgemmParams& p, const StreamMulti& mp, hipStream_t s)
 {
     const int ny = mp.n > 1 ? mp.n : (p.ksplit > 1 ? p.ksplit : 1);
-    // 64 x 32 tiles once the 32 x 32 ones would put more than ~3 waves on every CU (the weight fragments are then shared by two row blocks)
+    // 64 x 32 tiles once the 32 x 32 ones would put more than ~3 waves on every CU (the weight fragments are then shared by two row blocks;
+    // 64 x 64 tiles per wave were measured slower at every size: 3 K-steps in flight and twice the instruction stream per wave)
     if (igemm_stream_waves(p, 1) * ny > 768) {
         hipLaunchKernelGGL((igemm_stream_kernel<2, 1, 4>), dim3(igemm_stream_waves(p, 2), ny), dim3(64), 0, s, p, mp);
-    } else if (stream_depth() == 8) {
-        hipLaunchKernelGGL((igemm_stream_kernel<1, 1, 8>), dim3(igemm_stream_waves(p, 1), ny), dim3(64), 0, s, p, mp);
-    } else if (stream_depth() == 12) {
-        hipLaunchKernelGGL((igemm_stream_kernel<1, 1, 12>), dim3(igemm_stream_waves(p, 1), ny), dim3(64), 0, s, p, mp);
     } else {
         hipLaunchKernelGGL((igemm_stream_kernel<1, 1, 6>), dim3(igemm_stream_waves(p, 1), ny), dim3(64), 0, s, p, mp);
     }
