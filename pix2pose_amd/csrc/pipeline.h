@@ -107,7 +107,8 @@ struct PnpResult {
 // workspace: pnp_workspace_bytes(n_problems) bytes of device memory (hypothesis models)
 size_t pnp_workspace_bytes(int n_problems);
 hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_problems, int iterations,
-                             double reproj_err, double confidence, int min_points, double* workspace, hipStream_t s);
+                             double reproj_err, double confidence, int min_points, int max_points, double* workspace, hipStream_t s);
+// max_points: upper bound of PnpProblem::n over the problems (shapes the counting launch; results do not depend on it)
 
 // growable device buffer
 struct DevBuf {

@@ -1263,7 +1263,10 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
     if ((rc = SL.y2.reserve(sizeof(float) * 16384 * 4 * ((size_t)n * K + SL.tail_cap)))) return rc;
     if ((rc = SL.corr.reserve(sizeof(float) * (size_t)std::max<long long>(corr_total, 1)))) return rc;
     if ((rc = SL.crange.reserve(sizeof(CandRange) * (size_t)n * K))) return rc;
-    if (n * K <= 16 && ((rc = SL.crec.reserve(sizeof(unsigned) * (size_t)std::max<long long>(corr_total / 5, 1))) ||
+    // two-launch correspondence build (cand_eval_kernel): a handful of candidates, or crops large enough that one workgroup per candidate
+    // leaves the launch waiting for its largest member
+    const bool corr_seg = n * K <= 16 || max_side > 192;
+    if (corr_seg && ((rc = SL.crec.reserve(sizeof(unsigned) * (size_t)std::max<long long>(corr_total / 5, 1))) ||
                         (rc = SL.cseg.reserve(sizeof(CorrSeg) * CORR_SEG * (size_t)n * K)))) return rc;
     SL.aa = {nullptr, nullptr, nullptr};
     AaBufs aab = {nullptr, nullptr, nullptr, nullptr};
@@ -1378,7 +1381,7 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
 
     // -- correspondences, PnP-RANSAC, selection
     static const bool corr_split = getenv("P2P_CORR_SPLIT") == nullptr || atoi(getenv("P2P_CORR_SPLIT")) != 0;      // development switch (A/B)
-    if (n * K <= 16 && corr_split) {        // a handful of candidates: evaluate on CORR_SEG CUs each, then compact (see cand_eval_kernel)
+    if ((n * K <= 16 || SL.max_side > 192) && corr_split) {        // evaluate on CORR_SEG CUs per candidate, then compact (see cand_eval_kernel)
         hipLaunchKernelGGL(cand_eval_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(), d_cr, aa);
         hipLaunchKernelGGL(cand_compact_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(),
                            SL.corr.as<float>(), SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>());
@@ -1395,7 +1398,8 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
         HIP_TRY(hipEventRecord(P.corr_ready, st));
         HIP_TRY(hipStreamWaitEvent(ts, P.corr_ready, 0));
     }
-    HIP_TRY(launch_pnp_ransac(SL.probs.as<PnpProblem>(), SL.results.as<PnpResult>(), n * K, iters, rerr, conf, 6, SL.hyp.as<double>(), ts));
+    HIP_TRY(launch_pnp_ransac(SL.probs.as<PnpProblem>(), SL.results.as<PnpResult>(), n * K, iters, rerr, conf, 6, std::max(1, SL.max_side * SL.max_side),
+                              SL.hyp.as<double>(), ts));
     hipLaunchKernelGGL(select_kernel, dim3((n + 63) / 64), dim3(64), 0, ts, d_det, d_s1, SL.cand.as<CandStat>(),
                        SL.results.as<PnpResult>(), K, n, SL.poses.as<p2p_pose>());
     HIP_TRY(hipGetLastError());
@@ -1652,8 +1656,10 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
         dpts.release(); dprob.release(); dres.release(); dmask.release(); dhyp.release();
         return rc;
     }
+    int max_n = 1;
     for (int p = 0; p < n_problems; ++p) {
         const int o = offsets[p], n = offsets[p + 1] - o;
+        max_n = std::max(max_n, n);
         float* base = pts.data() + (size_t)o * 5;
         for (int i = 0; i < n; ++i) {
             base[i] = (float)obj_pts[3 * (size_t)(o + i)];
@@ -1674,7 +1680,7 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
         (e = hipMemcpyAsync(dprob.p, pb.data(), sizeof(PnpProblem) * n_problems, hipMemcpyHostToDevice, st)) != hipSuccess ||
         (e = hipMemsetAsync(dmask.p, 0, (size_t)std::max(N, 1), st)) != hipSuccess ||
         (e = launch_pnp_ransac(dprob.as<PnpProblem>(), dres.as<PnpResult>(), n_problems, iterations > 0 ? iterations : 100,
-                               reprojection_error > 0 ? reprojection_error : 5.0, confidence > 0 ? confidence : 0.99, 5, dhyp.as<double>(), st)) != hipSuccess ||
+                               reprojection_error > 0 ? reprojection_error : 5.0, confidence > 0 ? confidence : 0.99, 5, max_n, dhyp.as<double>(), st)) != hipSuccess ||
         (e = hipMemcpyAsync(res.data(), dres.p, sizeof(PnpResult) * n_problems, hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (inlier_mask && (e = hipMemcpyAsync(inlier_mask, dmask.p, (size_t)N, hipMemcpyDeviceToHost, st)) != hipSuccess) ||
         (e = hipStreamSynchronize(st)) != hipSuccess) {

@@ -1030,7 +1030,8 @@ struct PnpFit {
     double g[56];        // Gram sums (see pass B)
     double a_first[4];   // barycentric coordinates of the first inlier (sign disambiguation)
     double cand[36];     // three (R, t) candidates from the refit solve
-    int best, max_good, iters, state;   // state: 0 = refit pending, 1 = result already final, 2 = needs the lazy second hypothesis batch
+    int best, max_good, iters, state;   // state: 0 = refit pending, 1 = result already final, 2 = needs the next hypothesis round
+    int niters, pad_[3];                // state 2: RANSAC's iteration bound so far (best / max_good / iters hold the rest of the rule's state)
 };
 
 // Kernel 1 of 4 -- hypotheses.  A 16-lane group (round 0: four problems per wave) or a whole wave per problem: its first lane replays the sampler,
@@ -1068,6 +1069,10 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     h_stop = min(h_stop, h_begin + (wpp > 1 ? lanes >> 2 : MAX_ITERS));
     if (round == 0) {
         if (blockIdx.x == 0 && threadIdx.x < 2) act[threadIdx.x] = 0;
+        if (prob < n_problems) {                 // round 0 is one wave per problem: it clears the problem's inlier counters (pnp_count_kernel adds to them)
+            int* cnt = act + 2 + 2 * n_problems + (size_t)prob * MAX_ITERS;
+            for (int i = tid; i < MAX_ITERS; i += 64) cnt[i] = 0;
+        }
     } else
         prob = prob < act[round - 1] ? act[2 + (round - 1) * n_problems + prob] : n_problems;
     bool active = prob < n_problems && (round == 0 || fits[prob].state == 2);
@@ -1141,25 +1146,101 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     }
 }
 
-// Kernel 2 of 4 -- scoring in OpenCV's order with the adaptive bound, then the two reduction passes
-// of the EPnP refit over the inliers of the winning hypothesis (centroid/covariance -> control
-// points; Gram sums).  One workgroup (256 threads) per problem.
-// SCORE_NT threads: all of them count inliers (integers: any partition gives the same counts -- with detections of 200 - 450 px a candidate
-// carries up to 200 000 correspondences and this loop was a quarter of a step's kernel time); the refit's floating-point sums keep their
-// 256-thread partition (threads past 256 only keep the barriers), so a pose has the bits it always had.
-constexpr int SCORE_NT = 512;
-__global__ __launch_bounds__(SCORE_NT, 1) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
-                                                              PnpResult* __restrict__ results, PnpFit* __restrict__ fits, int iterations,
-                                                              double reproj_err, double confidence, int min_points, int n_solved, int first,
-                                                              int* __restrict__ act, int round, int n_problems)
+// Kernel 2a -- inlier counts.  Only the COUNT of a hypothesis enters OpenCV's sequential rule (keep the best, shrink the iteration
+// bound), and a count is an integer: any partition of the points and any order of the hypotheses gives the same numbers.  So the
+// counts of a round's hypotheses are taken by independent workgroups -- work item = (problem, chunk of SCORE_CHUNK hypotheses, slice of the
+// points): a point is loaded once and tested against the chunk's models out of LDS, four points in flight per thread -- and added to
+// the problem's counters; pnp_score_kernel then replays the rule over them.  With detections of 200 - 450 px a candidate carries up
+// to 200 000 correspondences: one workgroup per problem walking chunk after chunk (and starting over after every hypothesis round)
+// took 9 ms of kernel time per 256-detection step at bbox sides of 40 - 300 px, most of it in a few workgroups on an idle chip.
+// Later rounds: the problems on the round's work list, and only chunks below the bound the rule has reached so far.
+constexpr int COUNT_NT = 512;
+__global__ __launch_bounds__(COUNT_NT) void pnp_count_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
+                                                             const PnpFit* __restrict__ fits, int* __restrict__ act, int iterations,
+                                                             double reproj_err, int min_points, int h_begin, int n_solved, int nchunks,
+                                                             int slices, int round, int n_problems)
+{
+    __shared__ double s_R[SCORE_CHUNK][9];
+    __shared__ double s_t[SCORE_CHUNK][3];
+    __shared__ int s_cnt[SCORE_CHUNK];
+    int* counts = act + 2 + 2 * n_problems;
+    const int tid = threadIdx.x;
+    const int per_prob = nchunks * slices;
+    const int n_items = (round == 0 ? n_problems : act[round - 1]) * per_prob;
+    if (iterations > MAX_ITERS) iterations = MAX_ITERS;
+    const float thr2 = (float)(reproj_err * reproj_err);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int slot = item / per_prob, rem = item - slot * per_prob;
+        const int c = rem / slices, sl = rem - c * slices;
+        const int prob = round == 0 ? slot : act[2 + (round - 1) * n_problems + slot];
+        const PnpProblem& pb = probs[prob];
+        const int n = pb.n;
+        if (n < min_points || n <= 5) continue;                          // n == 5: the direct solution, nothing to count
+        if (sl * 4 * COUNT_NT >= n) continue;
+        const int n_hyp = iterations > 1 ? iterations : 1;
+        const int n_avail = min(n_hyp, n_solved);
+        const int it0 = h_begin + c * SCORE_CHUNK;
+        const int hc = min(SCORE_CHUNK, min(n_avail, round == 0 ? n_avail : fits[prob].niters) - it0);
+        if (hc <= 0) continue;
+        __syncthreads();                                                 // the previous item's models are no longer read
+        for (int i = tid; i < hc * 12; i += COUNT_NT) {
+            const int h = i / 12, k = i - h * 12;
+            const double v = hyp[((size_t)prob * MAX_ITERS + it0 + h) * 12 + k];
+            if (k < 9) s_R[h][k] = v; else s_t[h][k - 9] = v;
+        }
+        if (tid < SCORE_CHUNK) s_cnt[tid] = 0;
+        __syncthreads();
+        const float* PX = pb.pts;
+        const float* PY = pb.pts + (size_t)pb.cap;
+        const float* PZ = pb.pts + 2 * (size_t)pb.cap;
+        const float* PU = pb.pts + 3 * (size_t)pb.cap;
+        const float* PV = pb.pts + 4 * (size_t)pb.cap;
+        const Cam cam{pb.K[0], pb.K[4], pb.K[2], pb.K[5]};
+        int cnt[SCORE_CHUNK];
+#pragma unroll
+        for (int h = 0; h < SCORE_CHUNK; ++h) cnt[h] = 0;
+        for (int i0 = sl * 4 * COUNT_NT + tid; i0 < n; i0 += slices * 4 * COUNT_NT) {     // four points per trip: their 20 loads are in flight together
+            float px[4], py[4], pz[4], pu[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + COUNT_NT * u, n - 1);
+                px[u] = PX[i]; py[u] = PY[i]; pz[u] = PZ[i]; pu[u] = PU[i]; pv[u] = PV[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + COUNT_NT * u >= n) break;
+#pragma unroll
+                for (int h = 0; h < SCORE_CHUNK; ++h)
+                    if (h < hc) cnt[h] += is_inlier(s_R[h], s_t[h], cam, px[u], py[u], pz[u], pu[u], pv[u], thr2) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < SCORE_CHUNK; ++h) {
+            int x = cnt[h];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((tid & 63) == 0 && x) atomicAdd(&s_cnt[h], x);
+        }
+        __syncthreads();
+        if (tid < hc && s_cnt[tid]) atomicAdd(&counts[(size_t)prob * MAX_ITERS + it0 + tid], s_cnt[tid]);
+    }
+}
+
+// Kernel 2b -- OpenCV's sequential rule over the counts (keep the best, shrink the bound: same decisions, same iteration count as a
+// hypothesis-by-hypothesis walk), then the reduction passes of the EPnP refit over the inliers of the winning hypothesis
+// (centroid / covariance -> control points; Gram sums).  One workgroup (256 threads) per problem; the floating-point sums keep the
+// partition they always had (point i belongs to thread i mod 256), so a pose has the bits it always had.
+// A problem whose bound asks for hypotheses that are not solved yet parks the rule's state in its PnpFit (state 2), puts itself on the
+// next round's work list and resumes there.
+constexpr int SCORE_NT = 256;
+__global__ __launch_bounds__(SCORE_NT) void pnp_score_kernel(const PnpProblem* __restrict__ probs, const double* __restrict__ hyp,
+                                                             PnpResult* __restrict__ results, PnpFit* __restrict__ fits, int iterations,
+                                                             double reproj_err, double confidence, int min_points, int h_begin, int n_solved,
+                                                             int first, int* __restrict__ act, int round, int n_problems)
 {
     PnpFit& fit = fits[blockIdx.x];
     if (!first && fit.state != 2) return;        // later passes: only problems whose scoring ran out of hypotheses
-    __shared__ double s_R[MAX_ITERS][9];
-    __shared__ double s_t[MAX_ITERS][3];
     __shared__ double s_red[4 * 56];
-    __shared__ int s_ctl[4];         // niters, best, max_good, iter
-    __shared__ int s_cnt[SCORE_CHUNK];
+    __shared__ int s_ctl[5];         // niters, best, max_good, iter, 1 = needs the next hypothesis round
     __shared__ double s_fit[24];     // control points + inverse, thread 0 -> all
 
     const PnpProblem pb = probs[blockIdx.x];
@@ -1185,79 +1266,34 @@ __global__ __launch_bounds__(SCORE_NT, 1) void pnp_score_kernel(const PnpProblem
     }
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
     const int n_avail = min(n_hyp, n_solved);                           // hypotheses solved so far
-    for (int i = tid; i < n_avail * 12; i += SCORE_NT) {
-        const int h = i / 12, k = i - h * 12;
-        const double v = hyp[((size_t)blockIdx.x * MAX_ITERS + h) * 12 + k];
-        if (k < 9) s_R[h][k] = v; else s_t[h][k - 9] = v;
-    }
-    if (tid == 0) { s_ctl[0] = n_hyp; s_ctl[1] = -1; s_ctl[2] = 0; s_ctl[3] = 0; }
-    __syncthreads();
-
-    // ---- 3. score in OpenCV's order with the adaptive bound
     const float thr2 = (float)(reproj_err * reproj_err);
-    if (n == 5) {
-        if (tid == 0) { s_ctl[1] = 0; s_ctl[2] = 5; s_ctl[3] = 0; }
-        __syncthreads();
-    } else {
-        // OpenCV walks the hypotheses one by one: count inliers, keep the best, shrink the iteration bound.  Only the COUNT of a
-        // hypothesis enters that rule, so the counts of SCORE_CHUNK consecutive hypotheses are taken in one pass over the points
-        // (a point is loaded once and tested against the chunk's models out of LDS) and one reduction, and thread 0 then replays
-        // the sequential rule over them -- same decisions, same iteration count, a fraction of the passes and barriers (the
-        // kernel is bound by the latency of its point loops, not by arithmetic).  Counts past the stopping point are discarded.
-        for (int it0 = 0;; it0 += SCORE_CHUNK) {
-            if (it0 >= s_ctl[0]) break;          // uniform: s_ctl[0] is read after the barrier below
-            if (it0 >= n_avail) {                // (n_avail < n_hyp only) the bound still asks for more: solve the next round, score again from 0
-                if (tid == 0) {
-                    fit.state = 2;
-                    if (round < 2) act[2 + round * n_problems + atomicAdd(&act[round], 1)] = blockIdx.x;      // work list of the next hypothesis round
-                }
-                return;
-            }
-            const int hc = min(SCORE_CHUNK, n_avail - it0);
-            int cnt[SCORE_CHUNK];
-#pragma unroll
-            for (int h = 0; h < SCORE_CHUNK; ++h) cnt[h] = 0;
-            if (tid < SCORE_CHUNK) s_cnt[tid] = 0;
-            for (int i0 = tid; i0 < n; i0 += 4 * SCORE_NT) {     // four points per trip: their 20 loads are in flight together
-                float px[4], py[4], pz[4], pu[4], pv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = min(i0 + SCORE_NT * u, n - 1);
-                    px[u] = PX[i]; py[u] = PY[i]; pz[u] = PZ[i]; pu[u] = PU[i]; pv[u] = PV[i];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (i0 + SCORE_NT * u >= n) break;
-#pragma unroll
-                    for (int h = 0; h < SCORE_CHUNK; ++h)
-                        if (h < hc) cnt[h] += is_inlier(s_R[it0 + h], s_t[it0 + h], cam, px[u], py[u], pz[u], pu[u], pv[u], thr2) ? 1 : 0;
+
+    // ---- 3. OpenCV's rule over the counts of hypotheses [h_begin, n_avail)
+    if (tid == 0) {
+        if (n == 5) { s_ctl[0] = 1; s_ctl[1] = 0; s_ctl[2] = 5; s_ctl[3] = 0; s_ctl[4] = 0; }
+        else {
+            int niters = n_hyp, best = -1, max_good = 0, it = 0, more = 0;
+            if (!first) { niters = fit.niters; best = fit.best; max_good = fit.max_good; it = fit.iters; }
+            const int* cnt = act + 2 + 2 * n_problems + (size_t)blockIdx.x * MAX_ITERS;
+            for (it = h_begin; it < niters; ++it) {
+                if (it >= n_avail) { more = 1; break; }      // (n_avail < n_hyp only) the bound still asks for more: solve the next round
+                const int good = cnt[it];
+                if (good > (max_good > 4 ? max_good : 4)) {
+                    max_good = good;
+                    best = it;
+                    niters = ransac_update_num_iters(confidence, (double)(n - good) / n, 5, niters);
                 }
             }
-            __syncthreads();                     // s_cnt zeroed
-#pragma unroll
-            for (int h = 0; h < SCORE_CHUNK; ++h) {
-                int x = cnt[h];
-                for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-                if ((tid & 63) == 0 && x) atomicAdd(&s_cnt[h], x);
+            // `it` = hypotheses OpenCV would have walked: the loop leaves at it == niters (bound reached) or at n_avail
+            s_ctl[0] = niters; s_ctl[1] = best; s_ctl[2] = max_good; s_ctl[3] = it; s_ctl[4] = more;
+            if (more) {
+                fit.niters = niters; fit.best = best; fit.max_good = max_good; fit.iters = it; fit.state = 2;
+                if (round < 2) act[2 + round * n_problems + atomicAdd(&act[round], 1)] = blockIdx.x;      // work list of the next hypothesis round
             }
-            __syncthreads();
-            if (tid == 0) {
-                for (int h = 0; h < hc; ++h) {
-                    const int it = it0 + h;
-                    if (it >= s_ctl[0]) break;   // the bound was reached inside the chunk
-                    const int good = s_cnt[h];
-                    const int mg = s_ctl[2];
-                    if (good > (mg > 4 ? mg : 4)) {
-                        s_ctl[2] = good;
-                        s_ctl[1] = it;
-                        s_ctl[0] = ransac_update_num_iters(confidence, (double)(n - good) / n, 5, s_ctl[0]);
-                    }
-                    s_ctl[3] = it + 1;
-                }
-            }
-            __syncthreads();
         }
     }
+    __syncthreads();
+    if (s_ctl[4]) return;
     const int best = s_ctl[1], max_good = s_ctl[2], iters_run = s_ctl[3];
     if (best < 0 || max_good <= 0) {
         if (tid == 0) {
@@ -1268,10 +1304,11 @@ __global__ __launch_bounds__(SCORE_NT, 1) void pnp_score_kernel(const PnpProblem
         }
         return;
     }
+    const double* hb = hyp + ((size_t)blockIdx.x * MAX_ITERS + best) * 12;
     if (n == 5) {   // solvePnPRansac returns the direct solution when npoints == model_points
         if (tid == 0) {
-            for (int k = 0; k < 9; k++) out.R[k] = s_R[0][k];
-            for (int k = 0; k < 3; k++) out.t[k] = s_t[0][k];
+            for (int k = 0; k < 9; k++) out.R[k] = hb[k];
+            for (int k = 0; k < 3; k++) out.t[k] = hb[9 + k];
             out.n_inliers = 5; out.iters = 0; out.best_iter = 0; out.ok = 1;
             fit.state = 1;
         }
@@ -1281,8 +1318,8 @@ __global__ __launch_bounds__(SCORE_NT, 1) void pnp_score_kernel(const PnpProblem
 
     // ---- 4. re-fit EPnP on the inliers of the best hypothesis
     double Rb[9], tb[3];
-    for (int k = 0; k < 9; k++) Rb[k] = s_R[best][k];
-    for (int k = 0; k < 3; k++) tb[k] = s_t[best][k];
+    for (int k = 0; k < 9; k++) Rb[k] = hb[k];
+    for (int k = 0; k < 3; k++) tb[k] = hb[9 + k];
     const int m = max_good;
 
     // The three refit passes below walk the points in the same per-thread order as before (i = tid, tid + 256, ...: the partial sums
@@ -1566,11 +1603,13 @@ __global__ __launch_bounds__(256) void pnp_fit_select_kernel(const PnpProblem* _
 
 size_t pnp_workspace_bytes(int n_problems)
 {
-    return (size_t)n_problems * (pnp::MAX_ITERS * 12 * sizeof(double) + sizeof(pnp::PnpFit)) + (2 + 2 * (size_t)n_problems) * sizeof(int) + 16;
+    // hypothesis models, refit records, [count1, count2, list1[n], list2[n]] work lists, inlier counters [n][MAX_ITERS]
+    return (size_t)n_problems * (pnp::MAX_ITERS * 12 * sizeof(double) + sizeof(pnp::PnpFit)) +
+           (2 + 2 * (size_t)n_problems + (size_t)n_problems * pnp::MAX_ITERS) * sizeof(int) + 16;
 }
 
 hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_problems, int iterations,
-                             double reproj_err, double confidence, int min_points, double* workspace, hipStream_t s)
+                             double reproj_err, double confidence, int min_points, int max_points, double* workspace, hipStream_t s)
 {
     if (n_problems <= 0) return hipSuccess;
     pnp::PnpFit* fits = reinterpret_cast<pnp::PnpFit*>(workspace + (size_t)n_problems * pnp::MAX_ITERS * 12);
@@ -1586,8 +1625,19 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
         hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems * wpp + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
                            min_points, h_begin, stops[r], ppb, act, r, wpp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        // counts of the round's hypotheses: work items (problem, chunk of 8 hypotheses, slice of the points) walked by a bounded grid.
+        // Slices: 16 384 points each (the 128-px crop), more of them when the launch would not fill the chip otherwise
+        const int h_end = std::min(stops[r], std::min(iterations, pnp::MAX_ITERS));
+        const int nchunks = std::max(1, (h_end - h_begin + pnp::SCORE_CHUNK - 1) / pnp::SCORE_CHUNK);
+        const int per_trip = 4 * pnp::COUNT_NT;
+        int slices = std::max((max_points + 8 * per_trip - 1) / (8 * per_trip), 512 / std::max(1, n_problems * nchunks));
+        slices = std::max(1, std::min(slices, (max_points + per_trip - 1) / per_trip));
+        const long long items = (long long)n_problems * nchunks * slices;
+        hipLaunchKernelGGL(pnp::pnp_count_kernel, dim3((unsigned)std::min<long long>(items, 8192)), dim3(pnp::COUNT_NT), 0, s, probs, workspace, fits, act,
+                           iterations, reproj_err, min_points, h_begin, stops[r], nchunks, slices, r, n_problems);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(pnp::SCORE_NT), 0, s, probs, workspace, results, fits, iterations,
-                           reproj_err, confidence, min_points, stops[r], r == 0 ? 1 : 0, act, r, n_problems);
+                           reproj_err, confidence, min_points, h_begin, stops[r], r == 0 ? 1 : 0, act, r, n_problems);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         h_begin = stops[r];
         if (iterations <= h_begin) break;
