@@ -47,6 +47,7 @@ struct AaItem {
     int round32;            // the image is a float32 array in the reference: round to float32 after each axis pass
     double cval;
     double vmin, vmax;      // range of the filtered image (skimage clips the warp output to it)
+    unsigned long long kmin, kmax;   // the same as order-preserving keys while the filter's workgroups are still reducing into them
 };
 
 // Ranges skimage's clip=True needs for the 'constant'-mode back-resizes of one candidate (recognition.py:134,144,146):

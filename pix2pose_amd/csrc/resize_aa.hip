@@ -122,13 +122,29 @@ __device__ inline int mirror_idx(int i, int n)   // scipy 'mirror' == numpy-pad 
     return i >= n ? p - i : i;
 }
 
-// one axis pass of every item: thread per output element
-template <int AXIS>
-__global__ __launch_bounds__(256) void aa_filter_kernel(const AaItem* __restrict__ items)
+// order-preserving map double -> uint64 (atomicMin / atomicMax on the keys = min / max of the values)
+__device__ inline unsigned long long range_key(double v)
 {
-    const AaItem& I = items[blockIdx.y];
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : b | 0x8000000000000000ull;
+}
+__device__ inline double range_val(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? k & 0x7FFFFFFFFFFFFFFFull : ~k));
+}
+
+// one axis pass of every item: thread per output element.  The second pass also takes the [min, max] of what it writes -- the
+// range skimage's clip=True clips the warp output to (a separate pass, one workgroup per image, was 2 ms per 256-detection
+// step at 40 - 300-px boxes): the first pass resets the item's keys, aa_range_finish_kernel turns them into vmin / vmax.
+template <int AXIS>
+__global__ __launch_bounds__(256) void aa_filter_kernel(AaItem* __restrict__ items)
+{
+    __shared__ double s_lo[4], s_hi[4];
+    AaItem& I = items[blockIdx.y];
     const int r = I.radius;
     if (r <= 0) return;
+    if (AXIS == 0 && blockIdx.x == 0 && threadIdx.x == 0) { I.kmin = ~0ull; I.kmax = 0ull; }
+    double lo = 1e300, hi = -1e300;
     const double* src = AXIS == 0 ? I.a : I.tmp;
     double* dst = AXIS == 0 ? I.tmp : I.a;
     const int H = I.H, W = I.W, C = I.C;
@@ -154,34 +170,35 @@ __global__ __launch_bounds__(256) void aa_filter_kernel(const AaItem* __restrict
             }
             t += (a + b) * w[d];
         }
-        dst[e] = I.round32 ? (double)(float)t : t;
+        const double v = I.round32 ? (double)(float)t : t;
+        dst[e] = v;
+        if (AXIS == 1) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    }
+    if (AXIS == 1) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; }
+            if (lo <= hi) { atomicMin(&I.kmin, range_key(lo)); atomicMax(&I.kmax, range_key(hi)); }
+        }
     }
 }
 
-// [min, max] of every (filtered) image: what skimage's clip=True clips the warp output to.  One block per item.
-__global__ __launch_bounds__(256) void aa_range_kernel(AaItem* __restrict__ items)
+// keys -> [vmin, vmax] of every filtered image
+__global__ void aa_range_finish_kernel(AaItem* __restrict__ items, int n_items)
 {
-    __shared__ double s_lo[4], s_hi[4];
-    AaItem& I = items[blockIdx.x];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    AaItem& I = items[i];
     if (I.radius <= 0) return;
-    const long long total = (long long)I.H * I.W * I.C;
-    double lo = 1e300, hi = -1e300;
-    for (long long e = threadIdx.x; e < total; e += 256) {
-        const double v = I.a[e];
-        lo = v < lo ? v : lo;
-        hi = v > hi ? v : hi;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; }
-        I.vmin = lo; I.vmax = hi;
-    }
+    const bool any = I.kmin <= I.kmax;
+    I.vmin = any ? range_val(I.kmin) : 1e300;
+    I.vmax = any ? range_val(I.kmax) : -1e300;
 }
 
 }  // namespace
@@ -195,7 +212,7 @@ hipError_t launch_aa_filter(AaItem* items, int n_items, int max_elems, hipStream
         hipLaunchKernelGGL((aa_filter_kernel<0>), dim3(bx, ni), dim3(256), 0, s, items + i0);
         hipLaunchKernelGGL((aa_filter_kernel<1>), dim3(bx, ni), dim3(256), 0, s, items + i0);
     }
-    hipLaunchKernelGGL(aa_range_kernel, dim3(n_items), dim3(256), 0, s, items);
+    hipLaunchKernelGGL(aa_range_finish_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, items, n_items);
     return hipGetLastError();
 }
 
