@@ -13,6 +13,7 @@
 // GEMM orientation: rows = 16 output channels, columns = 16 consecutive output pixels, so a lane ends
 // up with 4 consecutive channels of one pixel (float4 store).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace p2p {
 
@@ -33,9 +34,23 @@ constexpr int C1_ROW_PX = C1_HIN + 6;                            // 134 staged p
 constexpr int C1_ROW_BYTES = C1_ROW_PX * 8;                      // 4 halves per pixel; 1072 B, 16-B aligned
 constexpr int C1_TILES_PER_WG = 8;                               // 16 output rows per workgroup (large batches; small ones: one tile, 32 workgroups per image)
 
-template <int C1_KH, int C1_PAD, int NCO>
+// POOL (resnet50 front, large batches): the 3x3 / 2 'same' max-pool that follows the layer (resnet50_mod.py:204) is taken from the
+// accumulators and only the 32 channels the decoder's skip connection reads (ae_model.py:186) are stored at full resolution -- the
+// layer wrote 268 MB per 256 inputs for the pooling kernel to fetch again (402 MB with its halo re-reads) and 67 MB to come out.
+// A wave then owns BOTH rows of a tile for 16 pixels: the vertical maximum is per lane, the row shared with the next tile
+// is carried in registers (the same lane owns the same pixel and channels there), the horizontal one is two DPP row shifts
+// (a pixel tile is one DPP row) plus one pixel per wave exchanged through LDS.  A workgroup computes one more tile than it stores
+// (the row below its last pooled row).  Values are the same ones the two kernels produce: max is exact.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(const float v)       // lane i of a 16-lane row <- lane i + n (row_shl:n); out of the row: own value
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+template <int C1_KH, int C1_PAD, int NCO, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __restrict__ x, int N, const Conv1Groups G,
-                                                             int act, float alpha, float* __restrict__ out, int tiles_per_wg)
+                                                             int act, float alpha, float* __restrict__ out, int tiles_per_wg,
+                                                             float* __restrict__ pool_out)
 {
     constexpr int C1_ROWS_IN = (C1_ROWS_OUT - 1) * 2 + C1_KH;        // 9 / 7 input rows
     constexpr int C1_PLANE = C1_ROWS_IN * C1_ROW_BYTES;              // hi plane, then lo plane
@@ -43,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
     constexpr int C1_PASSES = (C1_ROWS_IN * C1_HIN + 255) / 256;     // pixel loads per thread per tile (5 / 4)
     const int co0 = blockIdx.y * C1_COUT;                            // this workgroup's output channels
     __shared__ __attribute__((aligned(16))) char smem[C1_W_BYTES + 2 * C1_PLANE];
+    __shared__ float s_ex[POOL ? 4 * 64 : 1];                        // POOL: first pixel of every wave's strip, 64 channels
     char* ws = smem;
     char* xs = smem + C1_W_BYTES;
 
@@ -97,18 +113,44 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
 
     // wave -> output row (wave >> 1) of the tile, pixels 32 (wave & 1) .. +31 (two 16-pixel column tiles)
     const int li = lane & 15, lg = lane >> 4;
-    const int orow = wave >> 1, ox0 = (wave & 1) * 32;
+    // POOL: wave -> both rows of the tile (m = row), pixels 16 wave .. +15
+    const int orow = POOL ? 0 : wave >> 1, ox0 = POOL ? wave * 16 : (wave & 1) * 32;
+    constexpr int M_STEP = POOL ? 2 * C1_ROW_BYTES : 256;            // second pixel tile: the next output row / the next 16 pixels
     // pixel operand: the run of output pixel ox starts at staged pixel 2 ox (= input pixel 2 ox - 3): byte 16 ox
     const char* xb = xs + (2 * orow) * C1_ROW_BYTES + (ox0 + li) * 16 + lg * 16;
     const char* wb = ws + lg * (C1_COUT * 16) + li * 16;
 
+    // POOL: pooled row r = max over output rows 2r .. 2r + 2: one tile past the stored ones, unless that is the padding row
+    const int tiles_run = tiles_per_wg + ((POOL && oy_base + C1_ROWS_OUT * tiles_per_wg < C1_HOUT) ? 1 : 0);
+    f32x4 carry[4];                          // POOL: max of the previous tile's two rows at this lane's pixel
+    auto emit = [&](const f32x4 (&wv)[4], int prow) {      // horizontal 3-max at the even pixels of row-maximum wv -> pooled row prow
+        if (li == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&s_ex[wave * 64 + q * 16 + lg * 4]) = wv[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = fmaxf(wv[q][e], fmaxf(dpp_row<0x101>(wv[q][e]), dpp_row<0x102>(wv[q][e])));
+            if (li == 14 && wave < 3) {      // pixel x + 2 is the next wave's first one (past the last wave: the padding column)
+                const f32x4 o = *reinterpret_cast<const f32x4*>(&s_ex[(wave + 1) * 64 + q * 16 + lg * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = fmaxf(h[e], o[e]);
+            }
+            if (!(li & 1))
+                *reinterpret_cast<f32x4*>(pool_out + (((size_t)n * (C1_HOUT / 2) + prow) * (C1_HOUT / 2) + ((ox0 + li) >> 1)) * C1_COUT + q * 16 + lg * 4) = h;
+        }
+    };
+
     gload(oy_base);
-    for (int t = 0; t < tiles_per_wg; ++t) {
+    for (int t = 0; t < tiles_run; ++t) {
         const int oy0 = oy_base + t * C1_ROWS_OUT;
         __syncthreads();                     // previous tile's reads (and the initial fills) are done
         lstore();
         __syncthreads();
-        if (t + 1 < tiles_per_wg) gload(oy0 + C1_ROWS_OUT);
+        if (t + 1 < tiles_run) gload(oy0 + C1_ROWS_OUT);
 
         f32x4 acc[2][4];
 #pragma unroll
@@ -120,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
             f16x8 xh[2], xl[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                xh[m] = *reinterpret_cast<const f16x8*>(xb + kh * C1_ROW_BYTES + m * 256);
-                xl[m] = *reinterpret_cast<const f16x8*>(xb + kh * C1_ROW_BYTES + m * 256 + C1_PLANE);
+                xh[m] = *reinterpret_cast<const f16x8*>(xb + kh * C1_ROW_BYTES + m * M_STEP);
+                xl[m] = *reinterpret_cast<const f16x8*>(xb + kh * C1_ROW_BYTES + m * M_STEP + C1_PLANE);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -134,6 +176,45 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
                     acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][q], 0, 0, 0);
                 }
             }
+        }
+        if (POOL) {
+            // lane: channels 16 q + 4 lg .. +3 of output pixels (oy0 + m, ox0 + li)
+            f32x4 v[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 16 + lg * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 16 + lg * 4);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = fmaf(acc[m][q][e], sc[e], sh[e]);
+                        if (act == ACT_RELU) u = fmaxf(u, 0.f);
+                        else if (act == ACT_LEAKY) u = u > 0.f ? u : u * alpha;
+                        v[m][q][e] = u;
+                    }
+            }
+            if (t < tiles_per_wg) {          // the skip connection's channels 0 .. 31 of both rows
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float* op = out + (((size_t)n * C1_HOUT + oy0 + m) * C1_HOUT + ox0 + li) * NCO + co0 + lg * 4;
+                    *reinterpret_cast<f32x4*>(op) = v[m][0];
+                    *reinterpret_cast<f32x4*>(op + 16) = v[m][1];
+                }
+            }
+            if (t > 0) {                     // the row this tile shares with the pooled row of the tile before
+                f32x4 wv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wv[q][e] = fmaxf(carry[q][e], v[0][q][e]);
+                emit(wv, (oy0 >> 1) - 1);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) carry[q][e] = fmaxf(v[0][q][e], v[1][q][e]);
+            continue;
         }
         // lane: channels 16 q + 4 lg .. +3 of output pixel (oy0 + orow, ox0 + 16 m + li)
 #pragma unroll
@@ -155,6 +236,10 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
             }
         }
     }
+    if (POOL && tiles_run == tiles_per_wg) {      // last pooled row of the image: the row below is padding
+        __syncthreads();                           // the last emit's exchange reads are done
+        emit(carry, (C1_HOUT >> 1) - 1);
+    }
 }
 
 }  // namespace
@@ -171,7 +256,10 @@ size_t conv1_f16x3_panel_index(int KH, int kh, int plane, int kw, int c, int cou
 bool conv1_f16x3_supported(int KH, int Cout) { return (KH == 7 && Cout == 64) || (KH == 5 && Cout == 128); }
 
 // KH = 7: ZeroPadding2D(3) + 7x7/2 'valid', 3 -> 64 (resnet50 front); KH = 5: 5x5/2 'SAME' (one pixel before), 3 -> 128 (paper encoder)
-hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s)
+// pool_out (KH = 7 only): also produce MaxPooling2D(3, 2, 'same') of the layer, [N][32][32][64]; `out` is then only guaranteed to hold
+// channels 0 .. 31 (the decoder's skip connection)
+hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, float* pool_out,
+                              hipStream_t s)
 {
     if (N <= 0) return hipSuccess;
     if (!conv1_f16x3_supported(KH, Cout) || G.n_groups < 1 || G.n_groups > IGEMM_MAX_GROUPS) return hipErrorInvalidValue;
@@ -180,9 +268,16 @@ hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Con
     // (an output pixel is computed the same way whichever workgroup owns its row)
     const int tpw = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG)) >= 64 ? C1_TILES_PER_WG : (N >= 4 ? 2 : 1);
     const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * tpw));
-    if (KH == 7) hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw);
-    else hipLaunchKernelGGL((conv1_f16x3_kernel<5, 1, 128>), dim3(wgs, 2), dim3(256), 0, s, x, N, G, act, alpha, out, tpw);
-    return hipGetLastError();
+    static const bool no_fuse = getenv("P2P_NO_POOL_FUSE") != nullptr;      // development switch (A/B)
+    if (KH == 7 && pool_out && tpw == C1_TILES_PER_WG && !no_fuse) {
+        hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, true>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, pool_out);
+        return hipGetLastError();
+    }
+    if (KH == 7) hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, false>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, nullptr);
+    else hipLaunchKernelGGL((conv1_f16x3_kernel<5, 1, 128, false>), dim3(wgs, 2), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && KH == 7 && pool_out) e = launch_maxpool3s2(out, N, C1_HOUT, C1_HOUT, Cout, pool_out, s);
+    return e;
 }
 
 }  // namespace p2p

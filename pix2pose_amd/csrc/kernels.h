@@ -154,7 +154,8 @@ struct Conv1Groups {
     const float* scale[IGEMM_MAX_GROUPS];
     const float* shift[IGEMM_MAX_GROUPS];
 };
-hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, hipStream_t s);
+hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, float* pool_out,
+                              hipStream_t s);
 
 // MaxPooling2D 3x3 stride 2, TF 'SAME' (pad 0 before / 1 after), NHWC, C % 4 == 0.
 hipError_t launch_maxpool3s2(const float* x, int N, int H, int W, int C, float* out, hipStream_t s);

@@ -794,14 +794,15 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
                 G.start[g] = g0(g); G.w[g] = c1.w; G.scale[g] = c1.scale; G.shift[g] = c1.shift;
             }
             G.start[n_grp] = n;
-            HIP_TRY(launch_conv1_f16x3(x, n, 7, 64, G, ACT_RELU, LEAKY, A["f1"], st));
-        } else
+            HIP_TRY(launch_conv1_f16x3(x, n, 7, 64, G, ACT_RELU, LEAKY, A["f1"], A["p1"], st));      // + the max-pool (f1: skip channels)
+        } else {
         for (int g = 0; g < n_grp; ++g) {      // VALU first layer: one launch per object (tiny)
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
             HIP_TRY(launch_conv_first(x + (size_t)g0(g) * 49152, g0(g + 1) - g0(g), 128, 128, c1.w, 7, 2, 3, 64, c1.scale, c1.shift,
                                       ACT_RELU, LEAKY, A["f1"] + (size_t)g0(g) * 64 * 64 * 64, 64, 64, st));
         }
         HIP_TRY(launch_maxpool3s2(A["f1"], n, 64, 64, 64, A["p1"], st));
+        }
         if ((rc = res_block(M, X, "res2a", A["p1"], n, 32, 64, 64, 1, true, A["o_a"]))) return rc;
         if ((rc = res_block(M, X, "res2b", A["o_a"], n, 32, 256, 64, 1, false, A["o_b"]))) return rc;
         if ((rc = res_block(M, X, "res2c", A["o_b"], n, 32, 256, 64, 1, false, A["f2"]))) return rc;
@@ -827,7 +828,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
                 G.start[g] = g0(g); G.w[g] = c1.w; G.scale[g] = c1.scale; G.shift[g] = c1.shift;
             }
             G.start[n_grp] = n;
-            HIP_TRY(launch_conv1_f16x3(x, n, 5, 128, G, ACT_LEAKY, LEAKY, A["f1"], st));
+            HIP_TRY(launch_conv1_f16x3(x, n, 5, 128, G, ACT_LEAKY, LEAKY, A["f1"], nullptr, st));
         } else
         for (int g = 0; g < n_grp; ++g) {
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
