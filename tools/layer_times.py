@@ -32,9 +32,14 @@ def main(path, batch=256):
     db = sqlite3.connect(path)
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if "stage1_input" in r[0]][-1]
-    ks = [r for r in rows[idx + 1:] if "copyBuffer" not in r[0]][:len(LAYERS)]
+    ks = [r for r in rows[idx + 1:] if "copyBuffer" not in r[0]]
+    layers = list(LAYERS)
+    if "maxpool" not in ks[1][0]:              # first layer and max-pool in one kernel (conv1.hip, large batches)
+        layers = [("conv1+pool", LAYERS[0][1])] + LAYERS[2:]
+        KF["conv1+pool"] = 49 + 131 + 66       # input, the skip's 32 channels, the pooled tensor
+    ks = ks[:len(layers)]
     tot = 0
-    for (nm, mmac), r in zip(LAYERS, ks):
+    for (nm, mmac), r in zip(layers, ks):
         us = (r[2] - r[1]) / 1e3
         tot += us
         gf = 2 * mmac * batch / 1e3

@@ -14,11 +14,13 @@ python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/gpu_tests.log
 cd /tmp && export TMPDIR=/tmp
 G=$GRAFT_REPO_ROOT/gpurun_out
 B=$GRAFT_REPO_ROOT/bench.py
-rm -rf $G/prof_final $G/pmc_fetch2 $G/pmc_write2 $G/pmc_sq1 $G/pmc_sq2 $G/pmc_sq3 $G/prof_call $G/prof_small1 $G/prof_small3
+rm -rf $G/prof_final $G/prof_general $G/prof_general_aa $G/pmc_fetch2 $G/pmc_write2 $G/pmc_sq1 $G/pmc_sq2 $G/pmc_sq3 $G/prof_call $G/prof_small1 $G/prof_small3
 rocprofv3 --kernel-trace -d $G/prof_call -o t -- python $GRAFT_REPO_ROOT/tools/single_det.py 10 > $G/call.log 2>&1
 rocprofv3 --kernel-trace -d $G/prof_small1 -o t -- python $GRAFT_REPO_ROOT/tools/time_small.py resnet50 3 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace -d $G/prof_small3 -o t -- python $GRAFT_REPO_ROOT/tools/time_small.py resnet50 3 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $G/prof_final -o bench -- python $B '"$PROF"' > $G/bench_final_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $G/prof_general -o bench -- python $B '"$PROF"' --bbox-side 40,300 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $G/prof_general_aa -o bench -- python $B '"$PROF"' --bbox-side 40,300 --anti-aliasing > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $G/pmc_fetch2 -o x -- python $B '"$PMC"' > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $G/pmc_write2 -o x -- python $B '"$PMC"' > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $G/pmc_sq1 -o x -- python $B '"$PMC"' > $G/pmc_sq1.log 2>&1
@@ -40,6 +42,8 @@ cat gpurun_out/gpu_tests.log; tail -c 300 gpurun_out/bench_final.json
 ' 2>&1 | tail -8
 python tools/rocprof_summary.py gpurun_out/prof_final/bench_results.db > profiles/${R}_bench_kernel_stats.txt
 python tools/layer_times.py gpurun_out/prof_final/bench_results.db > profiles/${R}_layer_times.txt
+python tools/rocprof_summary.py gpurun_out/prof_general/bench_results.db > profiles/${R}_general_crops_kernel_stats.txt
+python tools/rocprof_summary.py gpurun_out/prof_general_aa/bench_results.db > profiles/${R}_general_crops_aa_kernel_stats.txt
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/${R}_traffic.json | head -4
 python tools/pmc_sq.py gpurun_out/pmc_sq1/x_results.db gpurun_out/pmc_sq2/x_results.db gpurun_out/pmc_sq3/x_results.db > profiles/${R}_sq_counters.txt
 python tools/trace_call.py gpurun_out/prof_call/t_results.db > profiles/${R}_single_det_trace.txt
