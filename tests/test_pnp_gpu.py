@@ -158,3 +158,31 @@ def test_pnp_full_size_problems_match_oracle():
         assert dt < 1.0 and dr < 0.1, (dt, dr)
         assert info[p, 0] >= 0.79 * 16384
         assert info[p, 1] < 100          # adaptive stop
+
+
+def test_pnp_large_crops_with_heavy_outliers_match_oracle():
+    """Candidates of 200 - 450-px crops (40 000 - 130 000 correspondences) at outlier ratios that push RANSAC's bound past the first
+    and the second hypothesis round: the inlier counts are taken by independent workgroups over slices of the points
+    (pnp_count_kernel) and OpenCV's rule resumes from its parked state after every round (pnp_score_kernel) -- iteration counts,
+    winners and inlier sets must still be the oracle's, also when small problems share the batch."""
+    from oracle import pnp_oracle as O
+    from pix2pose_amd.runtime import default_context, pnp_ransac_batch
+    big = _scenes(5, seed0=77, n_pts=(40000, 130000), outliers=(0.35, 0.65))
+    small = _scenes(3, seed0=78, n_pts=(50, 400), outliers=(0.3, 0.6))
+    Ks, objs, imgs = big[0] + small[0], big[1] + small[1], big[2] + small[2]
+    order = [5, 0, 1, 6, 2, 3, 7, 4]
+    Ks, objs, imgs = [Ks[i] for i in order], [objs[i] for i in order], [imgs[i] for i in order]
+    ok, R, t, info, masks = pnp_ransac_batch(default_context(), Ks, objs, imgs, want_mask=True)
+    rounds = set()
+    for p in range(len(objs)):
+        ok0, R0, t0, inl0, meta = O.solve_pnp_ransac(objs[p], imgs[p], Ks[p])
+        assert bool(ok[p]) == ok0, p
+        if not ok0:
+            continue
+        assert [int(v) for v in info[p]] == [meta["n_inliers"], meta["iterations"], meta["best_iter"]], p
+        np.testing.assert_array_equal(np.nonzero(masks[p])[0], inl0)
+        dt, dr = synth.pose_error(R0, t0, R[p], t[p])
+        assert dt < 1e-6 and dr < 1e-4, (p, dt, dr)
+        if len(objs[p]) > 1000:
+            rounds.add(0 if meta["iterations"] <= 16 else 1 if meta["iterations"] <= 64 else 2)
+    assert len(rounds) >= 2, rounds          # the large problems really end in different hypothesis rounds
