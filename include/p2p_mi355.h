@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define P2P_ABI_VERSION 5
+#define P2P_ABI_VERSION 6
 
 typedef enum {
     P2P_OK = 0,
@@ -218,6 +218,10 @@ typedef struct {
      * passes -- pays for small batches; at 256 detections per batch the chip is full either way (measured equal), so the
      * default is off.  Results are identical. */
     int merge_stream_passes;
+    /* The valid_mask buffers are zero-filled already (freshly calloc'ed pages, numpy.zeros): the library then writes only the rows of
+     * each detection's crop instead of clearing H x W bytes per detection first (256 detections of 640 x 480 frames: 79 MB of page
+     * touching per batch on the calling thread).  0 = the library clears them (valid_mask_full = zeros, recognition.py:175). */
+    int mask_prezeroed;
 } p2p_est_pose_opts;
 
 /* Blocking.  poses[i] corresponds to dets[i]. */
@@ -257,11 +261,10 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
  *   5  heads_halo_kernel (merged output heads)     6  igemm_halo8_kernel (layers on the 8x8 grid: conv4, first transposed conv)
  *   7  igemm_halo_s2_kernel (5x5 stride-2 convolutions on larger grids: the paper encoder's conv2 / conv3)
  *   8  igemm_stream_kernel (small launches: one wave per 32x32 tile, same K order and bits as the batched kernels)
- *   9  igemm_pair_kernel (two transposed-conv phases on one 128-wide tile)
  * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md
  * section 8a-L), not padded work and not the 3 MFMA products per MAC of the split-f16 arithmetic.
  * ---------------------------------------------------------------------------------------- */
-#define P2P_PROFILE_SLOTS 10
+#define P2P_PROFILE_SLOTS 9
 typedef struct {
     int64_t launches;
     double total_ms;

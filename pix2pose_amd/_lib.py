@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P2P_LIB", os.path.join(_HERE, "libp2p_mi355.so"))     # P2P_LIB: development override
 
 P2P_OK = 0
-ABI_VERSION = 5            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
+ABI_VERSION = 6            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
 MAX_RANSAC_ITERATIONS = 128
 BACKBONE = {"paper": 0, "resnet50": 1}
 PRECISION = {"f32": 0, "f16x3": 1}
@@ -65,10 +65,10 @@ class EstPoseOpts(C.Structure):
                 ("pred_stride", C.c_int64), ("dbg_x1", C.c_void_p), ("dbg_x2", C.c_void_p),
                 ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p),
                 ("det_mask", C.c_void_p), ("det_mask_stride", C.c_int64), ("mask_stats", C.c_void_p),
-                ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int)]
+                ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int), ("mask_prezeroed", C.c_int)]
 
 
-PROFILE_SLOTS = 10     # P2P_PROFILE_SLOTS
+PROFILE_SLOTS = 9     # P2P_PROFILE_SLOTS
 # kernel family of each slot: (label, substring of the rocprofv3 kernel name; %d = precision template argument)
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
                    ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
@@ -78,8 +78,7 @@ PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"
                    ("heads_halo_kernel (merged output heads)", "heads_halo_kernel"),
                    ("igemm_halo8_kernel 128x128 tiles (8x8-grid layers: conv4 through parity planes, first transposed conv)", "igemm_halo8_kernel"),
                    ("igemm_halo_s2_kernel (5x5 stride-2 convolutions on 16x16 and larger grids: the paper encoder)", "igemm_halo_s2_kernel"),
-                   ("igemm_stream_kernel (small launches: one wave per 32x32 output tile, operands streamed to registers)", "igemm_stream_kernel"),
-                   ("igemm_pair_kernel (two transposed-conv phases sharing one staged halo on a 128-wide tile)", "igemm_pair_kernel")]
+                   ("igemm_stream_kernel (small launches: one wave per 32x32 output tile, operands streamed to registers)", "igemm_stream_kernel")]
 
 
 class KernelStats(C.Structure):

@@ -1038,7 +1038,7 @@ static void finish_batch(const Slot& s, p2p_pose* poses)
         poses[o] = s.host_poses[i];
         if (opt.valid_mask) {       // valid_mask_full = zeros((H, W)); [v1:v2, u1:u2] = valid_mask   (recognition.py:175-176)
             unsigned char* dst = opt.valid_mask + (size_t)o * opt.mask_stride;
-            memset(dst, 0, (size_t)opt.mask_stride);
+            if (!opt.mask_prezeroed) memset(dst, 0, (size_t)opt.mask_stride);
             const p2p_pose& P = s.host_poses[i];
             if (P.status == P2P_POSE_OK) {
                 const int v1 = P.bbox_t[0], v2 = P.bbox_t[1], u1 = P.bbox_t[2], u2 = P.bbox_t[3], w = u2 - u1, W = s.img_w[i];

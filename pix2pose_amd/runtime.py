@@ -210,6 +210,7 @@ def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_m
         extras["valid_mask"] = np.zeros((n, mstride), np.uint8)
         extras["img_pred"] = np.zeros((n, pstride), np.uint8)
         opts.valid_mask, opts.mask_stride = extras["valid_mask"].ctypes.data, mstride
+        opts.mask_prezeroed = 1          # np.zeros above: fresh zero pages, the library writes the crop rows only
         opts.img_pred, opts.pred_stride = extras["img_pred"].ctypes.data, pstride
     if det_masks is not None and n:
         # score_type 2: IoU of each detector mask with valid_mask_full, computed on the device
