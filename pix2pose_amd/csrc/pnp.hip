@@ -1,4 +1,4 @@
-// Batched EPnP + RANSAC on gfx950: one workgroup per PnP problem (= one stage-2 candidate).
+// Batched EPnP + RANSAC on gfx950 (one problem = one stage-2 candidate).
 //
 // Replaces, per candidate, the call
 //     cv2.solvePnPRansac(obj, img, camK, None, flags=SOLVEPNP_EPNP, reprojectionError=5,
@@ -7,16 +7,16 @@
 //
 // OpenCV's RANSAC is sequential but its sampling is not data dependent: the RNG is re-seeded with
 // (uint64)-1 on every call and each iteration draws five distinct indices, so all minimal sets are
-// known up front.  The kernel therefore
-//   1. replays the multiply-with-carry generator once (lane 0) into LDS,
-//   2. solves the 5-point EPnP hypotheses in parallel, one lane each, in fp64,
-//   3. scores hypotheses in OpenCV's order with every lane striding over the correspondences and
-//      an LDS reduction of the inlier count, applying the same "best so far" rule and the same
-//      adaptive iteration bound (so it stops where OpenCV stops and picks the hypothesis OpenCV
-//      picks),
-//   4. re-fits EPnP on the inlier set with workgroup-wide reductions (the 2n x 12 system is
-//      never formed: M^T M has only four distinct weighted Gram sums of the barycentric
-//      coordinates), then the same beta / Gauss-Newton / absolute-orientation steps.
+// known up front.  The work is five kernels (launch_pnp_ransac):
+//   1. pnp_hypotheses_kernel: a lane replays the multiply-with-carry generator, lane quads solve the 5-point EPnP
+//      hypotheses in fp64 -- lazily, in rounds [0, 16), [16, 64), [64, 100): RANSAC's adaptive bound rarely asks for more,
+//   2. pnp_count_kernel: inlier counts of the round's hypotheses (integers: independent workgroups over slices of the points),
+//   3. pnp_score_kernel: OpenCV's "best so far" rule and adaptive iteration bound replayed over the counts in OpenCV's order
+//      (it stops where OpenCV stops and picks the hypothesis OpenCV picks; a problem that needs the next round parks its
+//      state), then the refit's reductions over the inlier set (the 2n x 12 system is never formed: M^T M has only four
+//      distinct weighted Gram sums of the barycentric coordinates),
+//   4. pnp_fit_solve_kernel: the 12x12 SVD and the same beta / Gauss-Newton / absolute-orientation steps,
+//   5. pnp_fit_select_kernel: the candidate with the smallest mean reprojection error, Rodrigues round trip.
 // All arithmetic that decides an inlier uses OpenCV's types (float32 point storage, float32
 // projected points and squared distance) with FMA contraction disabled.
 #include "pipeline.h"
@@ -969,7 +969,7 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
 template <int NV>
 __device__ void block_reduce(double (&v)[NV], double* red /* LDS: >= 4*NV doubles */)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // waves past the fourth (pnp_score_kernel runs eight) only keep the barriers
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // callers run four waves; any further ones only keep the barriers
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         double x = v[k];
