@@ -471,6 +471,10 @@ def main():
             dg = time.perf_counter() - t1
             out["general_crops"][key] = args.batch * args.general / dg
             out["general_crops"]["poses_ok" + ("_anti_aliasing" if aa else "")] = sum(1 for q in gp if q.status == 0)
+            if not aa:      # how far RANSAC ran on the selected candidates: hypotheses are solved in rounds [0,16), [16,64), [64,100)
+                it = np.array([q.ransac_iters for q in gp if q.status == 0])
+                out["general_crops"]["ransac_iters_selected_le16_le32_le64_le100"] = [int((it <= 16).sum()), int(((it > 16) & (it <= 32)).sum()),
+                                                                                       int(((it > 32) & (it <= 64)).sum()), int((it > 64).sum())]
         del gj1, gj2, gfr
     # -- latency leg: ONE detection through the drop-in shim, masks and image returned like the reference's est_pose
     if solo and args.latency > 0:

@@ -1083,7 +1083,8 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
     active = active && n >= min_points && n >= 5;
     if (iterations > MAX_ITERS) iterations = MAX_ITERS;
     const int n_hyp = n == 5 ? 1 : (iterations > 1 ? iterations : 1);
-    const int h_end = min(n_hyp, h_stop);
+    // later rounds: nothing past the bound the rule has reached so far is ever read (pnp_count_kernel and pnp_score_kernel stop there)
+    const int h_end = min(min(n_hyp, h_stop), round > 0 && active ? fits[prob].niters : MAX_ITERS);
     active = active && h_begin < h_end;
     const int row0 = ppb > 1 ? sub * HYP_ROUND0 : 0;
 
