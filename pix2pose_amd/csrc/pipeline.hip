@@ -1398,6 +1398,8 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
         HIP_TRY(hipEventRecord(P.corr_ready, st));
         HIP_TRY(hipStreamWaitEvent(ts, P.corr_ready, 0));
     }
+    static const bool skip_pnp = getenv("P2P_SKIP_PNP") != nullptr;      // timing experiment: what the PnP tail costs a stream of batches (poses are garbage)
+    if (!skip_pnp)
     HIP_TRY(launch_pnp_ransac(SL.probs.as<PnpProblem>(), SL.results.as<PnpResult>(), n * K, iters, rerr, conf, 6, std::max(1, SL.max_side * SL.max_side),
                               SL.hyp.as<double>(), ts));
     hipLaunchKernelGGL(select_kernel, dim3((n + 63) / 64), dim3(64), 0, ts, d_det, d_s1, SL.cand.as<CandStat>(),
