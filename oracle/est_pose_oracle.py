@@ -41,8 +41,53 @@ def _map_reflect(i, n):
     return np.where(i >= n, p - i, i)
 
 
-def resize_bilinear(img, out_shape, mode, cval=0.0, anti_aliasing=False, clip=True):
-    """img [H,W] or [H,W,C] (bool/float) -> float64 [oh,ow(,C)].
+def _warp_bilinear_f32(a, out_shape, mode, cval):
+    """scikit-image 0.17 / 0.18 ``_warp_fast[float32]`` + ``bilinear_interpolation[float32]`` for a float32 image, operation for
+    operation as compiled in the 0.18.3 wheel (checked bit for bit against the real library: tests/golden/external_vectors.json,
+    tools/make_external_vectors.py).  ``warp`` casts the 3x3 matrix to the image dtype; ``_transform_metric`` evaluates
+    c = M00 * col + M02 in float32 (two roundings); taps floorf / ceilf; d = c - floor in float32; then, per pixel,
+        top    = (1.0 - (double)dc) * (double)tl + (double)(dc * tr)        [dc * tr is a FLOAT32 product]
+        bottom = (1.0 - (double)dc) * (double)bl + (double)(dc * br)
+        out    = (float)((1.0 - (double)dr) * top + (double)dr * bottom)
+    (Cython types the literal in ``1 - dc`` as a C double; ``dc * pixel`` stays float * float)."""
+    f32, f64 = np.float32, np.float64
+    h, w = a.shape[:2]
+    oh, ow = out_shape
+
+    def axis(n_in, n_out):
+        s = n_in / n_out                                  # factors[i], float64
+        m_s, m_t = f32(s), f32(s * 0.5 - 0.5)             # the affine's scale / translation, cast to the image dtype
+        src = (m_s * np.arange(n_out, dtype=f32)).astype(f32) + m_t
+        lo = np.floor(src)
+        return lo.astype(np.int64), np.ceil(src).astype(np.int64), (src - lo).astype(f32)
+
+    r0, r1, dr = axis(h, oh)
+    c0, c1, dc = axis(w, ow)
+
+    def tap(ri, ci):
+        if mode == "reflect":
+            return a[_map_reflect(ri, h)][:, _map_reflect(ci, w)]
+        ok = ((ri >= 0) & (ri < h))[:, None] & ((ci >= 0) & (ci < w))[None, :]
+        v = a[np.clip(ri, 0, h - 1)][:, np.clip(ci, 0, w - 1)]
+        if a.ndim == 3:
+            ok = ok[..., None]
+        return np.where(ok, v, f32(cval)).astype(f32)
+
+    if a.ndim == 3:
+        dcb, drb = dc[None, :, None], dr[:, None, None]
+    else:
+        dcb, drb = dc[None, :], dr[:, None]
+    dcd, drd = dcb.astype(f64), drb.astype(f64)
+    top = (1.0 - dcd) * tap(r0, c0).astype(f64) + (dcb * tap(r0, c1)).astype(f32).astype(f64)
+    bot = (1.0 - dcd) * tap(r1, c0).astype(f64) + (dcb * tap(r1, c1)).astype(f32).astype(f64)
+    return ((1.0 - drd) * top + drd * bot).astype(f32)
+
+
+def resize_bilinear(img, out_shape, mode, cval=0.0, anti_aliasing=False, clip=True, keep_float32=None):
+    """img [H,W] or [H,W,C] (bool/float) -> float64 [oh,ow(,C)]  (float32 for a float32 image when ``keep_float32``).
+    keep_float32 (default: = anti_aliasing, i.e. the two switches select a scikit-image GENERATION -- <= 0.14: no filter, everything
+    in double; 0.17 / 0.18: filter on, and ``warp`` keeps a float32 image float32: matrix, coordinates and result in float32, see
+    :func:`_warp_bilinear_f32`; the float32 images of the path are the prob map of recognition.py:134 and img_pred of :144).
     src = dst*scale + (0.5*scale - 0.5), scale = in/out; taps floor/ceil; out-of-range taps are
     reflected ('reflect') or replaced by cval ('constant').
     anti_aliasing (skimage 0.17-0.18 semantics: on by default for float images, off for bool ones): Gaussian pre-filter, sigma = max(0, (in/out - 1)/2) per axis, truncated at
@@ -67,6 +112,17 @@ def resize_bilinear(img, out_shape, mode, cval=0.0, anti_aliasing=False, clip=Tr
         if max(sig) > 0:
             a0 = ndi.gaussian_filter(a0, sig, cval=cval, mode="mirror" if mode == "reflect" else "constant")
     lo_v, hi_v = (float(a0.min()), float(a0.max())) if a0.size else (0.0, 0.0)
+    if keep_float32 is None:
+        keep_float32 = bool(anti_aliasing)
+    if keep_float32 and a0.dtype == np.float32:
+        out = _warp_bilinear_f32(a0, (oh, ow), mode, cval)
+        if clip:                                                    # _clip_warp_output on the float32 arrays
+            preserve = mode == "constant" and not (lo_v <= cval <= hi_v)
+            keep = (out == np.float32(cval)) if preserve else None
+            out = np.clip(out, np.float32(lo_v), np.float32(hi_v))
+            if preserve:
+                out[keep] = cval
+        return out
     a = a0.astype(np.float64)
 
     def axis(n_in, n_out):
@@ -169,7 +225,7 @@ def correspondences(rgb_aug, img_prob_ori, non_zero, v1, v2, u1, u2, obj_scale, 
     xyz = xyz * 2 - 1
     for k in range(3):
         xyz[:, :, k] = xyz[:, :, k] * obj_scale[k] + obj_ct[k]
-    valid = np.logical_and(non_zero, img_prob_ori < th_i)
+    valid = np.logical_and(non_zero, img_prob_ori < float(th_i))     # a float32 img_prob_ori (scikit-image >= 0.17) is compared in float32
     vs, us = np.where(valid == 1)                     # row-major order
     obj_pts = xyz[vs, us]
     img_pts = np.stack((us + u1, vs + v1), axis=1).astype(np.float64)

@@ -13,7 +13,14 @@ cv2, scikit-image; no network), so exactly these calls are served by the oracle'
                                                                      Gaussian pre-filter is scipy.ndimage.gaussian_filter itself)
     cv2.solvePnPRansac(..., flags=EPNP, ...) / cv2.Rodrigues      -> oracle/pnp_oracle (C restatement of OpenCV 3.4.2)
     generator_train.predict(x)                                    -> fixed decoder maps by call order (pix2pose_amd.synthetic)
-and numpy's removed aliases (np.int) are restored.  So the fixture pins this repository's restatement of the
+and numpy's removed aliases (np.int) are restored.
+
+    /opt/conda/bin/python3.9 tests/golden/make_reference_vectors.py --real-skimage     (writes reference_est_pose_skimage018.json)
+
+ROUND 4: the build image carries a second interpreter with the REAL scikit-image 0.18.3 (+ scipy 1.7.1, numpy 1.26).  With
+--real-skimage the skimage shim is NOT installed: all six resize call sites of est_pose (recognition.py:82,103,121,134,144,146)
+run the real library -- anti-aliasing on by default, float32 images kept float32 through warp -- and only cv2 / keras are stood
+in.  That file pins the oracle's (and the HIP path's) `anti_aliasing=True` mode to the real 0.17 - 0.18 generation.  So the fixture pins this repository's restatement of the
 reference's OWN code (SURVEY.md section 8 rows a-4 .. a-9) to the reference; the semantics of the three libraries stay
 unpinned.  Nothing of the reference is copied: the fixture holds seeds, inputs' parameters
 and the outputs.
@@ -38,7 +45,7 @@ TH_O, TH_I = [0.2, 0.3, 0.35], 0.2
 ANTI_ALIASING = [False]      # which scikit-image generation the resize stand-in plays (switched per pass in main())
 
 
-def install_shims():
+def install_shims(real_skimage=False):
     if not hasattr(np, "int"):
         np.int = int            # removed in numpy 1.24; the reference predates that
     keras = types.ModuleType("keras")
@@ -73,6 +80,10 @@ def install_shims():
     cv2.solvePnPRansac, cv2.Rodrigues = solvePnPRansac, Rodrigues
     sys.modules["cv2"] = cv2
 
+    if real_skimage:
+        import skimage                                   # the real library: nothing of it is shimmed
+        from skimage.transform import resize as _real_resize  # noqa: F401
+        return skimage.__version__
     sk = types.ModuleType("skimage")
     skt = types.ModuleType("skimage.transform")
 
@@ -83,6 +94,7 @@ def install_shims():
     skt.resize = resize
     sk.transform = skt
     sys.modules.update({"skimage": sk, "skimage.transform": skt})
+    return None
 
 
 class _Predict:
@@ -141,16 +153,9 @@ def bop_io_vectors():
     return {"targets": targets, "grouped": grouped, "model_param": mp, "obj_param": ref_io.get_model_params(mp).tolist()}
 
 
-def main():
-    install_shims()
-    sys.path.insert(0, REF)
-    from pix2pose_model import recognition as ref          # the reference module itself
-    out = {"note": "outputs of /root/reference/pix2pose_model/recognition.py (est_pose) with library calls shimmed, see "
-                   "tests/golden/make_reference_vectors.py", "th_outlier": TH_O, "th_inlier": TH_I, "scenes": []}
-    out["scenes_aa"] = []
-    for key, specs, aa_flag in (("scenes", SCENES, False), ("scenes_aa", SCENES_AA, True)):
-      ANTI_ALIASING[0] = aa_flag
-      for spec in specs:
+def run_scenes(ref, specs):
+    scenes = []
+    for spec in specs:
         sc = synthetic.make_scene(spec["n_det"], seed=spec["seed"], bbox_side=spec["bbox_side"], outlier_frac=spec.get("outlier_frac", 0.2))
         dets = []
         for i, (img_i, _, bbox, K) in enumerate(sc["dets"]):
@@ -173,7 +178,99 @@ def main():
                           "mask_sum": int(np.sum(r[1])), "mask_crc": crc(np.packbits(r[1])), "img_pred_shape": list(r[0].shape),
                           "img_pred_sum": int(r[0].astype(np.int64).sum()), "img_pred_crc": crc(r[0])})
             dets.append(d)
-        out[key].append({"spec": {k: (list(v) if isinstance(v, tuple) else v) for k, v in spec.items()}, "dets": dets})
+        scenes.append({"spec": {k: (list(v) if isinstance(v, tuple) else v) for k, v in spec.items()}, "dets": dets})
+    return scenes
+
+
+SCENES_REAL = SCENES + SCENES_AA + [dict(seed=521, n_det=6, bbox_side=(40, 300)),      # the bench's general-crop distribution
+                                    dict(seed=522, n_det=4, bbox_side=(100, 180), outlier_frac=0.4)]
+
+
+def _discrete(d):
+    """the integer / byte results of a detection (what rounding noise either flips or leaves alone)"""
+    return [d.get(k) for k in ("ok", "bbox_t", "mask_sum", "mask_crc", "img_pred_crc", "frac_inlier")]
+
+
+def _exact_affine_patch():
+    """resize() obtains its scale-and-shift matrix from AffineTransform.estimate -- a least-squares fit through three corner
+    correspondences (numpy.linalg.svd -> LAPACK).  The fit returns the exact map only up to rounding noise (translation off by up to
+    4e-14, scale by a few ulp, different on the two axes), and the noise depends on the BLAS kernels the machine selects: the same
+    scikit-image / numpy wheels give different matrices under OPENBLAS_CORETYPE=Haswell, SkylakeX, Sandybridge and this container's
+    Prescott fallback (recorded below as "cores").  It matters where recognition.py thresholds a resized 0/1 mask at `> 0.9` (:103,
+    :146): for crop sides that are multiples of 10 the bilinear weight of a border pixel is EXACTLY 0.9 in real arithmetic and the noise
+    decides.  "scenes_exact_matrix" therefore runs the real library with estimate() returning the map it approximates
+    (scale = factors, shift = factors / 2 - 1 / 2, read from resize()'s own frame), everything else untouched -- that is what the
+    oracle and the HIP path reproduce bit for bit; "scenes_as_installed" is the unpatched library on this machine."""
+    from skimage.transform import _warps
+
+    class ExactAffine(_warps.AffineTransform):
+        def estimate(self, src, dst):
+            f = sys._getframe(1).f_locals["factors"]              # resize(): factors = input_shape / output_shape (float64)
+            self.params = np.array([[f[1], 0.0, f[1] * 0.5 - 0.5], [0.0, f[0], f[0] * 0.5 - 0.5], [0.0, 0.0, 1.0]])
+            return True
+    return _warps, ExactAffine
+
+
+def main_real_skimage():
+    """est_pose of the reference with the REAL scikit-image on all six resize call sites (cv2 / keras stood in by the oracle)."""
+    import subprocess
+    import warnings
+    warnings.filterwarnings("ignore")
+    version = install_shims(real_skimage=True)
+    import scipy
+    sys.path.insert(0, REF)
+    from pix2pose_model import recognition as ref
+    assert ref.resize.__module__.startswith("skimage."), ref.resize.__module__
+    if "--scenes-only" in sys.argv:                            # child process under another OPENBLAS_CORETYPE
+        print(json.dumps(run_scenes(ref, SCENES_REAL)))
+        return
+    installed = run_scenes(ref, SCENES_REAL)
+    _warps, ExactAffine = _exact_affine_patch()
+    real_affine = _warps.AffineTransform
+    _warps.AffineTransform = ExactAffine
+    try:
+        exact = run_scenes(ref, SCENES_REAL)
+    finally:
+        _warps.AffineTransform = real_affine
+    cores = {}
+    for core in ("Haswell", "SkylakeX", "Sandybridge"):
+        env = dict(os.environ, OPENBLAS_CORETYPE=core)
+        try:
+            got = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--real-skimage", "--scenes-only"], env=env,
+                                            capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+        except Exception as e:                                 # noqa: BLE001 -- a numpy without OpenBLAS: recorded, not fatal
+            cores[core] = "not run: %s" % (e,)
+            continue
+        a = [d for s in got for d in s["dets"]]
+        b = [d for s in installed for d in s["dets"]]
+        cores[core] = {"dets_differing_from_this_machine": sum(1 for x, y in zip(a, b) if _discrete(x) != _discrete(y)), "dets": len(a)}
+    out = {"note": "outputs of /root/reference/pix2pose_model/recognition.py (est_pose) with the REAL skimage.transform.resize on all six "
+                   "call sites; cv2.solvePnPRansac / Rodrigues and generator_train.predict stood in (oracle/pnp_oracle.c, injected maps); "
+                   "see tests/golden/make_reference_vectors.py --real-skimage",
+           "skimage_version": version, "scipy_version": scipy.__version__, "numpy_version": np.__version__,
+           "interpreter": "%s (python %s)" % (sys.executable, sys.version.split()[0]),
+           "th_outlier": TH_O, "th_inlier": TH_I, "scenes_exact_matrix": exact, "scenes_as_installed": installed, "cores": cores}
+    fn = os.path.join(HERE, "reference_est_pose_skimage018.json")
+    with open(fn, "w") as f:
+        json.dump(out, f)
+    de = [d for s in exact for d in s["dets"]]
+    di = [d for s in installed for d in s["dets"]]
+    print("wrote", fn, os.path.getsize(fn), "bytes; skimage", version, ";", sum(1 for d in de if d.get("ok")), "successful poses of", len(de),
+          ";", sum(1 for x, y in zip(de, di) if _discrete(x) != _discrete(y)), "detections differ between the exact and the fitted matrix; cores:", cores)
+
+
+def main():
+    if "--real-skimage" in sys.argv:
+        return main_real_skimage()
+    install_shims()
+    sys.path.insert(0, REF)
+    from pix2pose_model import recognition as ref          # the reference module itself
+    out = {"note": "outputs of /root/reference/pix2pose_model/recognition.py (est_pose) with library calls shimmed, see "
+                   "tests/golden/make_reference_vectors.py", "th_outlier": TH_O, "th_inlier": TH_I, "scenes": []}
+    out["scenes_aa"] = []
+    for key, specs, aa_flag in (("scenes", SCENES, False), ("scenes_aa", SCENES_AA, True)):
+        ANTI_ALIASING[0] = aa_flag
+        out[key] = run_scenes(ref, specs)
     ANTI_ALIASING[0] = False
     # degenerate boxes: no decoder maps needed where the reference returns before / right after stage 1
     sc = synthetic.make_scene(1, seed=505)

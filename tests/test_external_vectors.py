@@ -25,17 +25,32 @@ def _crc(a):
 
 # ------------------------------------------------------------------------------------------ consumers
 def check_resize(sec):
+    """float32 images (recognition.py:134 prob, :144 img_pred): scikit-image >= 0.16 keeps them float32 through the warp, and the oracle
+    reproduces the result BIT FOR BIT (crc of the float32 array, of its uint8 truncation and of the < 0.2 decision).  float64 / bool
+    images: the affine matrix comes out of a least-squares fit (LAPACK: ~1e-16 relative noise that differs between installs), so those
+    are held to 1e-12 -- and their uint8 / threshold decisions to exact equality."""
     import make_external_vectors as M
     from oracle.est_pose_oracle import resize_bilinear
     aa = bool(sec["anti_aliasing_default"])
+    n_f32 = 0
     for i, c in enumerate(sec["cases"]):
         a = M.resize_input(i, c["n_in"], c["dtype"], c["channels"])
-        r = resize_bilinear(a, (c["n_out"], c["n_out"]), c["mode"], c["cval"], anti_aliasing=aa)
+        raw = resize_bilinear(a, (c["n_out"], c["n_out"]), c["mode"], c["cval"], anti_aliasing=aa)
+        r = np.asarray(raw, np.float64)
         r2 = r.reshape(c["n_out"], c["n_out"], -1)[:, :, 0]
         assert abs(float(r.sum()) - c["sum"]) < 1e-9 * max(1.0, abs(c["sum"])), (i, c)
         assert np.abs(r2[np.arange(c["n_out"]), np.arange(c["n_out"])] - np.array(c["diag"])).max() < 1e-12, (i, c)
         assert np.abs(r2[0] - np.array(c["first_row"])).max() < 1e-12, (i, c)
         assert abs(float(r.min()) - c["min"]) < 1e-12 and abs(float(r.max()) - c["max"]) < 1e-12, (i, c)
+        if "crc" not in c:
+            continue                                       # a file written before round 4
+        assert str(raw.dtype) == c["out_dtype"], (i, c["dtype"], raw.dtype, c["out_dtype"])
+        assert _crc((raw * 255).astype(np.uint8)) == c["u8_crc"], (i, "uint8 truncation differs")
+        assert _crc(np.packbits(raw < 0.2)) == c["lt02_crc"], (i, "< 0.2 decisions differ")
+        if c["out_dtype"] == "float32":
+            assert _crc(raw) == c["crc"], (i, "float32 result is not bit-identical to scikit-image's")
+            n_f32 += 1
+    return n_f32
 
 
 def check_pnp(sec, solver):

@@ -36,13 +36,20 @@ def test_shim_get_boxes_matches_reference():
         assert [int(v) for v in out] == c["out"], c
 
 
-@pytest.mark.parametrize("key", ["scenes", "scenes_aa"])
+GS = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage018.json")))
+
+
+@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage"])
 def test_est_pose_matches_reference(key):
     """"scenes": resize stand-in without anti-aliasing (scikit-image <= 0.14); "scenes_aa": with the Gaussian pre-filter of
-    scikit-image 0.17 - 0.18 (scipy.ndimage.gaussian_filter itself)."""
+    scikit-image 0.17 - 0.18 (scipy.ndimage.gaussian_filter itself) and float32 images kept float32 through the warp;
+    "real_skimage": reference_est_pose_skimage018.json["scenes_exact_matrix"] -- the reference's est_pose run under
+    /opt/conda/bin/python3.9 with the REAL scikit-image 0.18.3 on all six resize call sites (only cv2 / keras stood in; the affine fit
+    of resize() returning the exact map, see the generator): masks, uint8 images, boxes, inlier fractions and poses of the oracle's
+    anti_aliasing=True mode are IDENTICAL to it."""
     n = 0
-    aa = key == "scenes_aa"
-    for s in G[key]:
+    aa = key != "scenes"
+    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G[key]):
         spec = s["spec"]
         sc = synthetic.make_scene(spec["n_det"], seed=spec["seed"], bbox_side=tuple(spec["bbox_side"]), outlier_frac=spec.get("outlier_frac", 0.2))
         for i, gd in enumerate(s["dets"]):
@@ -68,6 +75,33 @@ def test_est_pose_matches_reference(key):
             assert int(np.sum(r[1])) == gd["mask_sum"] and _crc(np.packbits(r[1])) == gd["mask_crc"]
             assert list(r[0].shape) == gd["img_pred_shape"] and _crc(r[0]) == gd["img_pred_crc"]
     assert n >= 10
+
+
+def test_unpatched_skimage_differs_only_by_its_matrix_noise():
+    """"scenes_as_installed": the same run with scikit-image 0.18.3 entirely unpatched.  Its resize() fits the scale-and-shift matrix by
+    SVD; the fit's rounding noise (1e-14) decides `> 0.9` on mask pixels whose bilinear weight is exactly 0.9, and depends on the BLAS
+    kernels of the machine (GS["cores"]: the same wheels under OPENBLAS_CORETYPE=Haswell / SkylakeX give other bytes than this
+    container's default).  So against the unpatched library: status and boxes identical, >= 90 % of the detections byte-identical,
+    the others a border row / column of the masks apart -- which moves RANSAC's correspondence set and with it the pose by up to
+    several mm (6.5 mm / 1.7 deg in this fixture): the reference does not reproduce ITSELF to 1 mm across machines at those crop sizes."""
+    n_same = n_all = 0
+    worst = (0.0, 0.0)
+    for se, si in zip(GS["scenes_exact_matrix"], GS["scenes_as_installed"]):
+        for de, di in zip(se["dets"], si["dets"]):
+            assert de["ok"] == di["ok"] and de["bbox_t"] == di["bbox_t"] and de["img_pred_shape"] == di["img_pred_shape"]
+            n_all += 1
+            same = all(de[k] == di[k] for k in ("mask_sum", "mask_crc", "img_pred_crc", "frac_inlier"))
+            n_same += same
+            dt, dr = synthetic.pose_error(np.array(di["R"]), np.array(di["t"]), np.array(de["R"]), np.array(de["t"]))
+            assert abs(de["mask_sum"] - di["mask_sum"]) <= 0.03 * di["mask_sum"] + 2      # a tie is a whole border row or column of the mask
+            if same:
+                assert dt < 1e-6 and dr < 1e-4          # (the angle goes through an arccos: 1e-6 deg is its noise floor)
+            else:
+                worst = (max(worst[0], dt), max(worst[1], dr))
+    assert n_same >= 0.9 * n_all and n_all >= 30
+    assert worst[0] < 10.0 and worst[1] < 3.0, worst
+    assert any(isinstance(v, dict) and v["dets_differing_from_this_machine"] > 0 for v in GS["cores"].values()), \
+        "fixture no longer shows the machine dependence of the unpatched library"
 
 
 def test_anti_aliasing_changes_the_result():

@@ -61,11 +61,20 @@ def version_tuple(v):
 
 
 # ---------------------------------------------------------------------------------------------- resize
-RESIZE_CASES = [  # (n_in, n_out, mode, cval, dtype)
+RESIZE_CASES = [  # (n_in, n_out, mode, cval, dtype[, channels])
     (128, 190, "constant", 1.0, "float32"), (128, 190, "constant", 0.5, "float32"), (128, 190, "constant", 0.0, "bool"),
     (128, 74, "constant", 1.0, "float32"), (128, 74, "constant", 0.0, "bool"), (128, 74, "constant", 0.5, "float32"),
     (300, 128, "reflect", 0.0, "float64"), (90, 128, "reflect", 0.0, "float64"), (128, 128, "reflect", 0.0, "float64"),
-    (128, 160, "constant", 0.0, "float64"), (17, 128, "reflect", 0.0, "float64"), (128, 9, "constant", 1.0, "float32")]
+    (128, 160, "constant", 0.0, "float64"), (17, 128, "reflect", 0.0, "float64"), (128, 9, "constant", 1.0, "float32"),
+    # round 4: the float32 images of the path at more scales -- prob (:134, cval 1) single channel, img_pred (:144, cval 0.5) 3 channels
+    (128, 263, "constant", 1.0, "float32"), (128, 301, "constant", 0.5, "float32", True), (128, 450, "constant", 1.0, "float32"),
+    (128, 129, "constant", 0.5, "float32", True), (128, 127, "constant", 1.0, "float32"), (128, 100, "constant", 0.5, "float32", True),
+    (128, 41, "constant", 1.0, "float32"), (128, 128, "constant", 0.5, "float32", True), (128, 200, "constant", 0.0, "float64")]
+
+
+def case_channels(case):
+    """3-channel input?  The float64 'reflect' cases are the canvases of :82,121; a 6th tuple element says so explicitly."""
+    return bool(case[5]) if len(case) > 5 else (case[4] == "float64" and case[2] == "reflect")
 
 
 def resize_input(case_idx, n_in, dtype, channels):
@@ -81,16 +90,23 @@ def section_resize():
     import skimage
     from skimage.transform import resize
     cases = []
-    for i, (n_in, n_out, mode, cval, dtype) in enumerate(RESIZE_CASES):
-        channels = dtype == "float64" and mode == "reflect"            # the 3-channel canvases of :82,121
+    for i, case in enumerate(RESIZE_CASES):
+        n_in, n_out, mode, cval, dtype = case[:5]
+        channels = case_channels(case)
         a = resize_input(i, n_in, dtype, channels)
-        r = np.asarray(resize(a, (n_out, n_out), order=1, mode=mode, cval=cval), np.float64)
+        raw = resize(a, (n_out, n_out), order=1, mode=mode, cval=cval)
+        r = np.asarray(raw, np.float64)
         cases.append({"n_in": n_in, "n_out": n_out, "mode": mode, "cval": cval, "dtype": dtype, "channels": bool(channels),
+                      "out_dtype": str(raw.dtype), "crc": crc(raw),            # the result's own bits (a float32 image stays float32 from 0.16 on)
+                      "u8_crc": crc((raw * 255).astype(np.uint8)),            # recognition.py:144,152: (resize(...) * 255) stored into a uint8 canvas
+                      "lt02_crc": crc(np.packbits(raw < 0.2)),                # recognition.py:203: img_prob_ori < th_inlier
                       "sum": float(r.sum()), "min": float(r.min()), "max": float(r.max()),
                       "diag": [float(v) for v in (r[np.arange(n_out), np.arange(n_out)].reshape(n_out, -1)[:, 0])],
                       "first_row": [float(v) for v in r[0].reshape(n_out, -1)[:, 0]]})
     v = skimage.__version__
-    return {"version": v, "anti_aliasing_default": version_tuple(v) >= [0, 15, 0], "cases": cases}
+    import scipy
+    return {"version": v, "scipy_version": scipy.__version__, "numpy_version": np.__version__,
+            "anti_aliasing_default": version_tuple(v) >= [0, 15, 0], "cases": cases}
 
 
 # ---------------------------------------------------------------------------------------------- PnP
@@ -305,7 +321,8 @@ def main():
     ap.add_argument("--reference", default=None, help="checkout of kirumang/Pix2Pose (enables the graphs and est_pose sections)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "external_vectors.json"))
     args = ap.parse_args()
-    out = {"note": "outputs of the real third-party libraries (tools/make_external_vectors.py)", "skipped": {}}
+    out = {"note": "outputs of the real third-party libraries (tools/make_external_vectors.py)", "skipped": {},
+           "interpreter": "%s (python %s)" % (sys.executable, sys.version.split()[0])}
     sections = [("resize", section_resize), ("pnp", section_pnp), ("layers", section_layers)]
     if args.reference:
         sections += [("graphs", lambda: section_graphs(args.reference)), ("est_pose", lambda: section_est_pose(args.reference))]
