@@ -18,7 +18,15 @@
 extern "C" {
 #endif
 
-#define P2P_ABI_VERSION 6
+#define P2P_ABI_VERSION 7
+
+/* The library is built with -fvisibility=hidden: the entry points declared here (P2P_API) are its ONLY dynamic symbols
+ * (tests/test_host_cpu.py holds `nm -D` to exactly this list). */
+#if defined(__GNUC__)
+#define P2P_API __attribute__((visibility("default")))
+#else
+#define P2P_API
+#endif
 
 typedef enum {
     P2P_OK = 0,
@@ -45,37 +53,38 @@ typedef struct {
     int64_t numel;
 } p2p_tensor;
 
-int p2p_abi_version(void);
+P2P_API int p2p_abi_version(void);
 /* Binding self-checks: sizeof() of the public structs as this build of the library sees them
  * (which: 0 p2p_tensor, 1 p2p_image, 2 p2p_object, 3 p2p_detection, 4 p2p_pose, 5 p2p_est_pose_opts,
  * 6 p2p_kernel_stats; -1 otherwise), and the hash of the sources the library was built from
  * (pix2pose_amd/build.py) -- a foreign-language binding compares both with its own declarations / tree
  * before the first call, so that a stale .so is an error and not a silent struct mismatch. */
-int p2p_abi_sizeof(int which);
-const char* p2p_build_id(void);
+P2P_API int p2p_abi_sizeof(int which);
+P2P_API const char* p2p_build_id(void);
 /* Test hook, no GPU needed: the one-sided Gaussian weights (centre first) the anti-aliased resize uses for crop side
  * `side` against the 128-px network resolution; w must hold 256 doubles.  Returns the radius (0: no filtering), -1 on a bad
  * side.  tests/ hold it against scipy.ndimage's own kernel bit for bit. */
-int p2p_aa_weights(int side, double* w);
-const char* p2p_last_error(void);
-int p2p_device_count(int* count);
+P2P_API int p2p_aa_weights(int side, double* w);
+P2P_API const char* p2p_last_error(void);
+P2P_API int p2p_device_count(int* count);
 
 /* Create a context on `device`.  `max_batch` = largest number of 128x128 network inputs
  * processed per pass (activation workspace is sized for it; larger requests are chunked).
- * `max_image_side` bounds the crop side used to size the PnP correspondence workspace. */
-int p2p_ctx_create(int device, int max_batch, p2p_ctx** out);
-void p2p_ctx_destroy(p2p_ctx* ctx);
-int p2p_ctx_synchronize(p2p_ctx* ctx);
+ * The est_pose workspaces (correspondences, canvases, landing buffers) are grow-only and sized by the batches
+ * that arrive: nothing about frame or crop sizes is fixed here. */
+P2P_API int p2p_ctx_create(int device, int max_batch, p2p_ctx** out);
+P2P_API void p2p_ctx_destroy(p2p_ctx* ctx);
+P2P_API int p2p_ctx_synchronize(p2p_ctx* ctx);
 /* HIP stream handle (hipStream_t) the context launches on, for callers that time kernels
  * with HIP events or chain their own work. */
-void* p2p_ctx_stream(p2p_ctx* ctx);
+P2P_API void* p2p_ctx_stream(p2p_ctx* ctx);
 
 /* Replaces `ae.aemodel_unet_*(p=1.0)` + `generator_train.load_weights(weight_fn)`
  * (reference recognition.py:21-26; graphs ae_model.py:70-150,175-240): uploads the
  * tensors, folds BatchNorm into per-channel scale/shift and re-packs kernels for the
  * MFMA implicit-GEMM kernels.  All tensors of pix2pose_amd.weights.tensor_specs(backbone)
  * must be present. */
-int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone,
+P2P_API int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone,
                      p2p_model** out);
 
 /* Arithmetic of the generator's dense contractions (the reference computes them in fp32 through
@@ -87,19 +96,19 @@ int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int
  * (f16 max); weights are pre-scaled per layer.  p2p_model_create uses P2P_PREC_DEFAULT. */
 typedef enum { P2P_PREC_F32 = 0, P2P_PREC_F16X3 = 1 } p2p_precision;
 #define P2P_PREC_DEFAULT P2P_PREC_F16X3
-int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone,
+P2P_API int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone,
                         int precision, p2p_model** out);
-void p2p_model_destroy(p2p_model* model);
+P2P_API void p2p_model_destroy(p2p_model* model);
 
 /* Replaces `self.generator_train.predict(x)` (reference recognition.py:84,129):
  * x [n,128,128,3] float32 NHWC -> xyz [n,128,128,3] (tanh) and prob [n,128,128,1] (sigmoid).
  * `mem` says whether x/xyz/prob are host or device pointers.  Blocking. */
-int p2p_predict(p2p_ctx* ctx, const p2p_model* model, const float* x, int n, float* xyz,
+P2P_API int p2p_predict(p2p_ctx* ctx, const p2p_model* model, const float* x, int n, float* xyz,
                 float* prob, int mem);
 
 /* Same forward pass, device buffers only, asynchronous on the context stream, output
  * interleaved [n,128,128,4] = (x,y,z,prob).  Used by the pipeline and by bench.py. */
-int p2p_forward_async(p2p_ctx* ctx, const p2p_model* model, const float* x_dev, int n,
+P2P_API int p2p_forward_async(p2p_ctx* ctx, const p2p_model* model, const float* x_dev, int n,
                       float* xyzp_dev);
 
 
@@ -201,15 +210,25 @@ typedef struct {
     const unsigned char* det_mask;
     int64_t det_mask_stride;
     int64_t* mask_stats;
-    /* skimage.transform.resize version switch.  The reference calls resize(order=1) six times per detection
+    /* skimage.transform.resize GENERATION switch.  The reference calls resize(order=1) six times per detection
      * (recognition.py:82,103,121,134,144,146) and does not pin scikit-image (requirements.txt does not list it):
-     *   0 (default): scikit-image <= 0.14 -- plain bilinear warp;
-     *   1: scikit-image 0.17 - 0.18: anti_aliasing is on by default for float images -- every DOWN-scaling resize of one is preceded
-     *      by scipy.ndimage.gaussian_filter(sigma = (in/out - 1)/2, truncate 4, border 'mirror' / 'constant'+cval, result
-     *      kept in the array's dtype), restated in csrc/resize_aa.hip -- and off for BOOL images (the keep mask of
-     *      recognition.py:103: "Gaussian convolution is not defined with bool data type").  0.15 / 0.16, where the default first became
-     *      True, ran the filter on that bool array as well, whose bool result is an erosion to the pixels whose weighted sum is
-     *      exactly 1.0; that generation is NOT modelled.
+     *   0 (default): scikit-image <= 0.14 -- plain bilinear warp, every image warped in double (the 0.14 _warp_fast takes doubles only).
+     *      Restated from the published semantics; no such version exists in the build image, so this mode is NOT pinned to a real library.
+     *   1: scikit-image 0.17 - 0.18, PINNED bit for bit to the real 0.18.3 (+ scipy 1.7.1) of the build image's /opt/conda/bin/python3.9
+     *      (tests/golden/external_vectors.json: resize itself; tests/golden/reference_est_pose_skimage018.json: the reference's est_pose
+     *      with the real library on all six call sites -- masks, uint8 images, boxes identical):
+     *      - anti_aliasing is on by default for float images: every DOWN-scaling resize of one is preceded by
+     *        scipy.ndimage.gaussian_filter(sigma = (in/out - 1)/2, truncate 4, border 'mirror' / 'constant'+cval, result kept in the
+     *        array's dtype), restated in csrc/resize_aa.hip -- and off for BOOL images (the keep mask of recognition.py:103);
+     *      - warp() keeps a FLOAT32 image float32: the prob map of :134 and img_pred of :144 are interpolated by
+     *        _warp_fast[float32] (matrix, source coordinates and taps in float32, the blend as the 0.18.3 wheel compiles it), the
+     *        result is compared with th_inlier in float32 (:203) and multiplied by 255 in float32 (:144) before the uint8 truncation.
+     *      One thing of the real library is NOT reproduced because it is not reproducible: resize() fits its scale-and-shift matrix by SVD,
+     *      and the fit's 1e-14 noise -- which depends on the BLAS kernels the machine selects -- decides `> 0.9` on mask pixels whose
+     *      bilinear weight is exactly 0.9 (crop sides that are multiples of 10).  This library uses the exact map the fit approximates;
+     *      the fixture records both and shows the same wheels disagreeing with themselves across OPENBLAS_CORETYPE settings.
+     *      0.15 / 0.16, where anti_aliasing first defaulted to True, ran the filter on the bool array of :103 as well (an erosion to
+     *      the pixels whose weighted sum is exactly 1.0); that generation is NOT modelled.
      * (scikit-image >= 0.19 rejects the bool array of recognition.py:103, so the reference does not run there.)
      * clip=True of resize (output clamped to the input's range, cval preserved) is common to all versions and always on. */
     int resize_anti_aliasing;
@@ -220,12 +239,15 @@ typedef struct {
     int merge_stream_passes;
     /* The valid_mask buffers are zero-filled already (freshly calloc'ed pages, numpy.zeros): the library then writes only the rows of
      * each detection's crop instead of clearing H x W bytes per detection first (256 detections of 640 x 480 frames: 79 MB of page
-     * touching per batch on the calling thread).  0 = the library clears them (valid_mask_full = zeros, recognition.py:175). */
+     * touching per batch on the calling thread).  0 = the library clears them (valid_mask_full = zeros, recognition.py:175).
+     * PRECONDITION, not checked: with 1 the buffer must be all-zero before EVERY call that names it -- the library writes the crop rows
+     * of detections with status OK and nothing else, so a buffer reused across calls (the natural pattern with submit / collect) keeps
+     * the previous batch's rows, and the rows of detections that fail this time.  Re-zero it, allocate a fresh one, or pass 0. */
     int mask_prezeroed;
 } p2p_est_pose_opts;
 
 /* Blocking.  poses[i] corresponds to dets[i]. */
-int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images,
+P2P_API int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images,
                        int n_images, const p2p_detection* dets, int n_dets, p2p_pose* poses,
                        const p2p_est_pose_opts* opts);
 
@@ -238,17 +260,17 @@ int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, c
  * and the score_type-2 sums (det_mask -> mask_stats) are available here too: name the host buffers in the
  * options of `submit`, keep them alive, and `collect` fills them (rendered on the tail stream, landed in pinned
  * memory, copied out at collect time).  det_mask is read during `submit`.  Only the debug taps are blocking-only. */
-int p2p_est_pose_submit(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images,
+P2P_API int p2p_est_pose_submit(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images,
                         int n_images, const p2p_detection* dets, int n_dets, const p2p_est_pose_opts* opts,
                         int* ticket);
-int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses);
+P2P_API int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses);
 
 /* Replaces `cv2.solvePnPRansac(obj, img, camK, None, flags=EPNP, reprojectionError, iterationsCount)`
  * + `cv2.Rodrigues` (reference recognition.py:216-223) for a batch of independent problems.
  * Problem p owns points [offsets[p], offsets[p+1]) of obj_pts [N,3] (mm, double) and img_pts
  * [N,2] (pixels, double); camK [n_problems][9].  Host pointers.  ok[p]=0 reproduces cv2 returning
  * inliers=None.  inlier_mask (may be null) is [N] bytes.  info[p] = {n_inliers, iterations, best_iter}. */
-int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts, const double* img_pts,
+P2P_API int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts, const double* img_pts,
                          const int* offsets, int n_problems, int iterations, double reprojection_error,
                          double confidence, double* R, double* t, int* info, int* ok,
                          unsigned char* inlier_mask);
@@ -271,10 +293,10 @@ typedef struct {
     double algo_flops;
 } p2p_kernel_stats;
 
-int p2p_profile_enable(p2p_ctx* ctx, int on);
+P2P_API int p2p_profile_enable(p2p_ctx* ctx, int on);
 /* Harvest finished events (synchronises the stream) and return the accumulated stats; reset
  * clears the accumulators afterwards.  stats must hold P2P_PROFILE_SLOTS entries. */
-int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset);
+P2P_API int p2p_profile_read(p2p_ctx* ctx, p2p_kernel_stats* stats, int reset);
 
 #ifdef __cplusplus
 }

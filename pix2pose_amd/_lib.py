@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P2P_LIB", os.path.join(_HERE, "libp2p_mi355.so"))     # P2P_LIB: development override
 
 P2P_OK = 0
-ABI_VERSION = 6            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
+ABI_VERSION = 7            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
 MAX_RANSAC_ITERATIONS = 128
 BACKBONE = {"paper": 0, "resnet50": 1}
 PRECISION = {"f32": 0, "f16x3": 1}

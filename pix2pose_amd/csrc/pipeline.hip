@@ -473,11 +473,98 @@ __device__ inline void cand_raw(const float* q, double* prob, double* ng, double
     }
 }
 
+// scikit-image 0.17 / 0.18 keep a FLOAT32 image float32 through warp() -- the prob map of recognition.py:134 and img_pred of :144 are
+// float32 arrays (Keras output; (decode + 1) / 2 stays float32) -- and the compiled _warp_fast[float32] / bilinear_interpolation[float32]
+// of the 0.18.3 wheel do, per output pixel (disassembled; the test suite's CPU restatement of exactly this is checked bit for bit against
+// the real library, tests/golden/external_vectors.json, and this kernel against both):
+//   matrix cast to float32: ms = (float)(n_in / n_out), mt = (float)(0.5 * n_in / n_out - 0.5)
+//   c = ms * (float)col + mt                 two float32 roundings (mulss, addss)
+//   taps floorf(c), ceilf(c); dc = c - floorf(c) in float32
+//   top = (1.0 - (double)dc) * (double)tl + (double)(dc * tr)          dc * tr is a float32 product
+//   out = (float)((1.0 - (double)dr) * top + (double)dr * bottom)
+struct TapF {
+    int i0, i1;
+    float d;
+};
+
+__device__ inline TapF axis_tap_f32(int o, int n_in, int n_out)
+{
+    const double s = (double)n_in / (double)n_out;
+    const float ms = (float)s, mt = (float)(s * 0.5 - 0.5);
+    const float src = ms * (float)o + mt;            // contraction is off in this file
+    const float lo = floorf(src);
+    TapF t;
+    t.i0 = (int)lo;
+    t.i1 = (int)ceilf(src);
+    t.d = src - lo;
+    return t;
+}
+
+__device__ inline float lerp2_f32(float tl, float tr, float bl, float br, float dr, float dc)
+{
+    const double top = (1.0 - (double)dc) * (double)tl + (double)(dc * tr);
+    const double bot = (1.0 - (double)dc) * (double)bl + (double)(dc * br);
+    return (float)((1.0 - (double)dr) * top + (double)dr * bot);
+}
+
 // bk: the candidate's five anti-aliased planes [prob | pred r | g | b | non_gray][128*128] (null: raw maps from y2c)
-__device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const CandRange& R, int r, int c, int S2, int S2w, double th_i)
+// gen: 0 = scikit-image <= 0.14 (every image warped in double), 1 = 0.17 / 0.18 (prob and img_pred warped in float32, compared with
+// th_inlier and multiplied by 255 in float32; the non_gray image of :146 is a float64 array in every version)
+__device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const CandRange& R, int r, int c, int S2, int S2w, double th_i, int gen)
 {
     const Tap tr = axis_tap(r, 128, S2), tc = axis_tap(c, 128, S2w);
     const int ri[2] = {tr.i0, tr.i1}, cj[2] = {tc.i0, tc.i1};
+    CandPixel o;
+    if (gen) {
+        // float64 image: non_gray
+        double ng[2][2];
+        for (int a = 0; a < 2; ++a)
+            for (int e = 0; e < 2; ++e) {
+                ng[a][e] = 0.0;
+                if (P2P_TAP_LIVE(a, e, tr, tc) && ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
+                    const int idx = ri[a] * 128 + cj[e];
+                    if (bk) ng[a][e] = bk[4 * 16384 + idx];
+                    else {
+                        const float* q = y2c + (size_t)idx * 4;
+                        ng[a][e] = sqrtf((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) < 0.3f ? 0.0 : 1.0;
+                    }
+                }
+            }
+        o.non_gray = clip_warp(lerp2(ng[0][0], ng[0][1], ng[1][0], ng[1][1], tr.d, tc.d), R.gmin, R.gmax, 0.0) > 0.9;
+        // float32 images: prob, img_pred -- their own (float32) source coordinates and taps
+        const TapF fr = axis_tap_f32(r, 128, S2), fc = axis_tap_f32(c, 128, S2w);
+        const int fi[2] = {fr.i0, fr.i1}, fj[2] = {fc.i0, fc.i1};
+        float prob[2][2], pred[3][2][2];
+        for (int a = 0; a < 2; ++a)
+            for (int e = 0; e < 2; ++e) {
+                if (!P2P_TAP_LIVE(a, e, fr, fc)) {
+                    prob[a][e] = 0.f;
+                    pred[0][a][e] = pred[1][a][e] = pred[2][a][e] = 0.f;
+                } else if (fi[a] >= 0 && fi[a] < 128 && fj[e] >= 0 && fj[e] < 128) {
+                    const int idx = fi[a] * 128 + fj[e];
+                    if (bk) {                      // filtered planes of a float32 image hold float32 values (AaItem::round32)
+                        prob[a][e] = (float)bk[idx];
+                        for (int ch = 0; ch < 3; ++ch) pred[ch][a][e] = (float)bk[(1 + ch) * 16384 + idx];
+                    } else {
+                        double pr, g, pr3[3];
+                        cand_raw(y2c + (size_t)idx * 4, &pr, &g, pr3);
+                        prob[a][e] = (float)pr;
+                        for (int ch = 0; ch < 3; ++ch) pred[ch][a][e] = (float)pr3[ch];
+                    }
+                } else {
+                    prob[a][e] = 1.f;
+                    pred[0][a][e] = pred[1][a][e] = pred[2][a][e] = 0.5f;
+                }
+            }
+        const float pr = (float)clip_warp((double)lerp2_f32(prob[0][0], prob[0][1], prob[1][0], prob[1][1], fr.d, fc.d), R.pmin, R.pmax, 1.0);
+        o.valid = o.non_gray && pr < (float)th_i;                                       // float32 array < python float: a float32 comparison
+        for (int ch = 0; ch < 3; ++ch) {
+            const float w = (float)clip_warp((double)lerp2_f32(pred[ch][0][0], pred[ch][0][1], pred[ch][1][0], pred[ch][1][1], fr.d, fc.d), R.qmin, R.qmax, 0.5);
+            const float v = w * 255.0f;                                                 // :144  float32 array * 255
+            o.q[ch] = (unsigned char)(int)v;                                            // uint8 canvas: truncation (:152-154)
+        }
+        return o;
+    }
     double prob[2][2], ng[2][2], pred[3][2][2];
     for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 2; ++e) {
@@ -500,7 +587,6 @@ __device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const
                 pred[0][a][e] = pred[1][a][e] = pred[2][a][e] = 0.5;
             }
         }
-    CandPixel o;
     o.non_gray = clip_warp(lerp2(ng[0][0], ng[0][1], ng[1][0], ng[1][1], tr.d, tc.d), R.gmin, R.gmax, 0.0) > 0.9;
     const double pr = clip_warp(lerp2(prob[0][0], prob[0][1], prob[1][0], prob[1][1], tr.d, tc.d), R.pmin, R.pmax, 1.0);
     o.valid = o.non_gray && pr < th_i;                                              // :203-204
@@ -581,7 +667,7 @@ __global__ __launch_bounds__(1024) void cand_corr_kernel(const DetInfo* __restri
             int rr = 0, cc = 0;
             if (p < npx) {
                 rr = p / w; cc = p - rr * w;
-                cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+                cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
                 valid = cp.valid;
                 if (cp.non_gray) { ++ng_cnt; sv += (unsigned)(b.v1 + rr); su += (unsigned)(b.u1 + cc); }
             }
@@ -659,7 +745,7 @@ __global__ __launch_bounds__(256) void cand_eval_kernel(const DetInfo* __restric
         unsigned* r = rec + D.corr_off / 5 + (size_t)slot * D.corr_cap;
         for (int p = seg * per + tid; p < min(npx, (seg + 1) * per); p += 256) {
             const int rr = p / w, cc = p - rr * w;
-            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
             r[p] = (unsigned)cp.q[0] | ((unsigned)cp.q[1] << 8) | ((unsigned)cp.q[2] << 16) | (cp.valid ? 1u << 24 : 0u);
             nv += cp.valid;
             if (cp.non_gray) { ++ng; sv += (unsigned)(b.v1 + rr); su += (unsigned)(b.u1 + cc); }
@@ -833,7 +919,7 @@ __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restr
     const CandRange R = crange[cand];
     for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
         const int rr = p / w, cc = p - rr * w;
-        const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+        const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
         if (mask && p < mask_stride) mask[(size_t)d * mask_stride + p] = cp.valid ? 1 : 0;      // compact: row-major over the clipped box
         if (pred && (long long)(p + 1) * 3 <= pred_stride) {
             unsigned char* q = pred + (size_t)d * pred_stride + (size_t)p * 3;
@@ -871,7 +957,7 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict
         const CandRange R = crange[cand];
         for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
             const int rr = p / w, cc = p - rr * w;
-            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i);
+            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
             if (cp.valid) {
                 ++vcount;
                 inter += dm[(size_t)(b.v1 + rr) * D.W + (b.u1 + cc)] != 0;
@@ -1398,7 +1484,11 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
         HIP_TRY(hipEventRecord(P.corr_ready, st));
         HIP_TRY(hipStreamWaitEvent(ts, P.corr_ready, 0));
     }
-    static const bool skip_pnp = getenv("P2P_SKIP_PNP") != nullptr;      // timing experiment: what the PnP tail costs a stream of batches (poses are garbage)
+#ifdef P2P_DEV_SWITCHES      // tools/ab_build.sh pipeline.hip -DP2P_DEV_SWITCHES: never in the shipped library (poses are garbage with it)
+    static const bool skip_pnp = getenv("P2P_SKIP_PNP") != nullptr;      // timing experiment: what the PnP tail costs a stream of batches
+#else
+    constexpr bool skip_pnp = false;
+#endif
     if (!skip_pnp)
     HIP_TRY(launch_pnp_ransac(SL.probs.as<PnpProblem>(), SL.results.as<PnpResult>(), n * K, iters, rerr, conf, 6, std::max(1, SL.max_side * SL.max_side),
                               SL.hyp.as<double>(), ts));

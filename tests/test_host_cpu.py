@@ -24,6 +24,13 @@ def test_c_abi_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libp2p_mi355.so does not export %s" % n
     assert _lib.lib().p2p_abi_version() == _lib.ABI_VERSION
+    # ... and nothing else: the library is built with -fvisibility=hidden, its C entry points are its whole dynamic symbol table
+    # (no mangled C++ helpers, no kernel host stubs).  The few linker-provided names every shared object carries are filtered out.
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = sorted({ln.split()[-1] for ln in out.splitlines() if ln.strip()})
+    extra = [d for d in defined if d not in names and d not in ("_init", "_fini", "__bss_start", "_edata", "_end")]
+    assert extra == [], "symbols exported beside the C ABI: %s" % extra[:10]
 
 
 def test_no_gpu_fails_loudly_not_silently():
@@ -263,7 +270,10 @@ def test_resize_restatement_anti_aliasing_and_clip(n_in, mode, cval, f32):
     r = resize_bilinear(a, (128, 128), mode, cval, anti_aliasing=True)
     if z.shape == (128, 128):
         zc = np.clip(z, filt.min(), filt.max())
-        assert np.abs(zc - r).max() < 1e-12
+        # a float32 map is warped in float32 by the 0.17 / 0.18 generation (coordinates, taps, result: 1e-7 from the double warp);
+        # with keep_float32=False the restatement is the all-double warp zoom() performs
+        assert np.abs(zc - r).max() < (5e-7 if f32 else 1e-12)
+        assert np.abs(zc - resize_bilinear(a, (128, 128), mode, cval, anti_aliasing=True, keep_float32=False)).max() < 1e-12
     assert r.min() >= float(filt.min()) and r.max() <= float(filt.max())
 
 
