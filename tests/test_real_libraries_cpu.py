@@ -1,0 +1,71 @@
+"""The REAL third-party libraries this image does carry -- scikit-image 0.18.3, scipy 1.7.1 and h5py 3.3.0 under
+/opt/conda/bin/python3.9 (the default interpreter has none of them) -- executed from the CPU suite, so that every recorded run
+re-derives the committed fixtures from the libraries themselves instead of trusting a file:
+
+  * tests/golden/external_vectors.json ["resize"]            == tools/make_external_vectors.py run now
+  * tests/golden/reference_est_pose_skimage018.json          == tests/golden/make_reference_vectors.py --real-skimage run now
+    (needs /root/reference, i.e. the build container; the GPU box has no reference checkout)
+  * tests/test_convert_keras.py::test_read_hdf5_on_real_files under python3.9 (real h5py files; skipped under python3.10)
+
+Skipped where that interpreter is missing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PY39 = "/opt/conda/bin/python3.9"
+
+
+def _have(mod):
+    if not os.path.exists(PY39):
+        return False
+    return subprocess.run([PY39, "-c", "import %s" % mod], capture_output=True).returncode == 0
+
+
+def _run(args, timeout=600):
+    env = dict(os.environ, PYTHONWARNINGS="ignore", PYTHONDONTWRITEBYTECODE="1")
+    return subprocess.run([PY39] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(not _have("skimage"), reason="no /opt/conda/bin/python3.9 with scikit-image")
+def test_committed_resize_vectors_are_what_the_real_skimage_produces(tmp_path):
+    out = str(tmp_path / "ext.json")
+    r = _run([os.path.join("tools", "make_external_vectors.py"), "--out", out])
+    assert r.returncode == 0, r.stderr[-2000:]
+    fresh = json.load(open(out))["resize"]
+    committed = json.load(open(os.path.join(ROOT, "tests", "golden", "external_vectors.json")))["resize"]
+    assert fresh["version"] == committed["version"] == "0.18.3"
+    assert len(fresh["cases"]) == len(committed["cases"]) >= 20
+    for a, b in zip(fresh["cases"], committed["cases"]):
+        for k in ("out_dtype", "crc", "u8_crc", "lt02_crc"):
+            if b["out_dtype"] == "float32" or k != "crc":      # float64 results carry the machine's LAPACK noise (1e-14) in their bits
+                assert a[k] == b[k], (k, a["n_in"], a["n_out"], a["dtype"])
+        assert abs(a["sum"] - b["sum"]) < 1e-9 * max(1.0, abs(b["sum"]))
+
+
+@pytest.mark.skipif(not _have("skimage") or not os.path.isdir("/root/reference"), reason="needs the conda interpreter and /root/reference")
+def test_committed_est_pose_vectors_are_what_the_reference_produces_with_the_real_skimage():
+    """as-installed scenes only (the exact-matrix scenes differ from them in the two tie detections, see the generator)."""
+    r = _run([os.path.join("tests", "golden", "make_reference_vectors.py"), "--real-skimage", "--scenes-only"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    fresh = json.loads(r.stdout.strip().splitlines()[-1])
+    committed = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_est_pose_skimage018.json")))["scenes_as_installed"]
+    keys = ("ok", "bbox_t", "mask_sum", "mask_crc", "img_pred_crc", "frac_inlier", "R", "t")
+    n = 0
+    for sf, sc in zip(fresh, committed):
+        for df, dc in zip(sf["dets"], sc["dets"]):
+            assert [df.get(k) for k in keys] == [dc.get(k) for k in keys]
+            n += 1
+    assert n >= 30
+
+
+@pytest.mark.skipif(not _have("h5py"), reason="no /opt/conda/bin/python3.9 with h5py")
+def test_hdf5_reader_on_real_h5py_files():
+    """pix2pose_amd.convert_keras.read_hdf5 on files written by the real h5py 3.3.0: both Keras layouts, both backbones (row f-2)."""
+    r = _run(["-m", "pytest", os.path.join("tests", "test_convert_keras.py"), "-q", "-p", "no:cacheprovider"])
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail

@@ -6,7 +6,7 @@
 #      --sys-trace / HIP trace domain) -- and the bench lines (default, 30 objects, strict fp32, 2 ranks on one device)
 #   2. here: summarise the rocpd databases into profiles/
 set -e
-R=${1:-r03}
+R=${1:-r04}
 PROF="--steps 3 --warmup 1 --blocking --no-legs"
 PMC="--steps 1 --warmup 1 --blocking --no-legs"
 /usr/local/graft/bin/gpurun --timeout 2400 -- '
@@ -55,6 +55,9 @@ for f in bench_final:bench_line bench_objects30:bench_line_objects30 bench_f32:b
     grep '^{' gpurun_out/${f%%:*}.json | tail -1 > profiles/${R}_${f##*:}.json
 done
 cp gpurun_out/gpu_tests.log profiles/${R}_gpu_tests.log
+# the real libraries of the image's second interpreter (scikit-image 0.18.3, h5py 3.3.0): HDF5 reader on real files, fixtures re-derived
+(echo "# /opt/conda/bin/python3.9 -m pytest tests/test_convert_keras.py"; PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 -W ignore -m pytest tests/test_convert_keras.py -q -p no:cacheprovider 2>&1 | tail -3
+ echo "# python -m pytest tests/test_real_libraries_cpu.py tests/test_external_vectors.py tests/test_reference_vectors_cpu.py"; python -m pytest tests/test_real_libraries_cpu.py tests/test_external_vectors.py tests/test_reference_vectors_cpu.py -q -m "not gpu" 2>&1 | tail -3) > profiles/${R}_real_libraries.log
 [ -f gpurun_out/pnp_exact_match.json ] && cp gpurun_out/pnp_exact_match.json profiles/${R}_pnp_exact_match.json
 [ -f gpurun_out/precision_report.json ] && cp gpurun_out/precision_report.json profiles/${R}_precision_report.json
 head -14 profiles/${R}_bench_kernel_stats.txt | cut -c1-175
