@@ -207,7 +207,9 @@ def main():
     pinned = None
     if world > 1 and not args.no_pin:
         from pix2pose_amd.parallel import pin_rank_to_cpus
-        pinned = pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), world, _usable_cpus())
+        # ranks of THIS node share its CPUs: LOCAL_WORLD_SIZE (torchrun), not the global world size; the affinity is inherited by every
+        # thread the process starts later (torch, the HIP runtime)
+        pinned = pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)), _usable_cpus())
     if use_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:                       # --collective from a plain shell: a one-rank group on the loopback
@@ -505,10 +507,11 @@ def main():
         cj2 = torch.from_numpy(scc["inject2"]).cuda()
         torch.cuda.synchronize()
         gp, _ = est_pose_batch(ctx, specs[:1], list(scc["images"]), scc["dets"], inject1=cj1.data_ptr(), inject2=cj2.data_ptr(), inject_slots=3)
-        dts, drs, exact, both = [], [], 0, 0
+        dts, drs, exact, both, status_mismatches = [], [], 0, 0, 0
         for q, r in zip(gp, refs):
             ok_ref = not (isinstance(r[4], int) and r[4] == -1)
-            if (q.status == 0) != ok_ref:
+            if (q.status == 0) != ok_ref:                   # one side produced a pose the other rejected: counted, never skipped silently
+                status_mismatches += 1
                 continue
             if not ok_ref:
                 exact += list(q.bbox_t) == [int(v) for v in r[5]]
@@ -519,8 +522,11 @@ def main():
             exact += (list(q.bbox_t) == [int(v) for v in r[5]]) and (q.frac_inlier == r[4])
         out["pose_delta_vs_oracle"] = {"detections": len(refs), "poses_compared": both, "max_dt_mm": float(max(dts)) if dts else None,
                                        "max_drot_deg": float(max(drs)) if drs else None, "exact_integer_matches": int(exact),
+                                       "status_mismatches": int(status_mismatches),       # expected 0; > 0 voids the delta figures
                                        "note": "GPU path vs the CPU restatement on the cpu_baseline sample: pose delta, and detections whose returned box and "
                                                "inlier fraction (n_inliers / n_init_mask: the RANSAC outcome) are identical; north_star bar 1 mm / 1 deg"}
+        if status_mismatches:                               # a pose on one side only is an infinite delta, not a missing sample
+            out["pose_delta_vs_oracle"]["max_dt_mm"] = out["pose_delta_vs_oracle"]["max_drot_deg"] = float("inf")
         out["pose_delta_vs_oracle_max_mm_deg"] = [out["pose_delta_vs_oracle"]["max_dt_mm"], out["pose_delta_vs_oracle"]["max_drot_deg"]]
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -33,7 +33,8 @@ typedef enum {
     P2P_ERR_INVALID_ARG = -1,   /* null pointer, bad size, unknown enum */
     P2P_ERR_HIP = -2,           /* a HIP runtime call failed (no GPU, OOM, launch failure) */
     P2P_ERR_WEIGHTS = -3,       /* missing / mis-sized weight tensor */
-    P2P_ERR_CAPACITY = -4       /* request exceeds a capacity fixed at ctx creation */
+    P2P_ERR_CAPACITY = -4,      /* request exceeds a capacity fixed at ctx creation */
+    P2P_ERR_RANGE = -5          /* a P2P_PREC_F16X3 generator pass stored an activation beyond the split-f16 operand range (see p2p_precision) */
 } p2p_status;
 
 /* reference: recognition.py:21-26 selects the generator graph from the `backbone` string */
@@ -92,13 +93,27 @@ P2P_API int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tens
  * emulated on the f16 matrix pipe -- every operand is split into two f16 halves (22 significant
  * bits), three MFMAs per product block, fp32 accumulation; ~2.7x faster on the large layers, output
  * differs from the fp32 mode by ~1e-6 and is measured as close to a double-accumulating reference as
- * the fp32 mode is (max 2.5e-5 vs 3.3e-5 on the tanh outputs).  Operand range: |activation| < 65504
- * (f16 max); weights are pre-scaled per layer.  p2p_model_create uses P2P_PREC_DEFAULT. */
-typedef enum { P2P_PREC_F32 = 0, P2P_PREC_F16X3 = 1 } p2p_precision;
+ * the fp32 mode is (max 2.5e-5 vs 3.3e-5 on the tanh outputs).  Weights are pre-scaled per output channel.
+ * OPERAND RANGE of the split: |activation| < 65504 (f16 max).  Batch-normalised layers sit orders of magnitude below; the two
+ * linear Dense layers (ae_model.py:199-200) have no BatchNorm behind them.  The range is GUARDED: every layer epilogue tracks the
+ * largest magnitude it stores and raises a device-side flag beyond 6e4; the flag travels with the results and
+ *   p2p_predict / p2p_est_pose_batch / p2p_est_pose_collect return P2P_ERR_RANGE (outputs / poses of that call are not to be used);
+ *   p2p_forward_async cannot report -- ask p2p_ctx_range_event() after synchronising.
+ * P2P_PREC_AUTO: split-f16 with a strict-fp32 twin of the same weights kept beside it (+ the model's size in HBM).  On a range event the
+ * object switches to the twin for good: p2p_predict and p2p_est_pose_batch repeat the work in fp32 themselves and return P2P_OK;
+ * p2p_est_pose_collect returns P2P_ERR_RANGE once and the re-submitted batch runs in fp32.  p2p_model_precision() tells which
+ * arithmetic an object currently uses.  p2p_model_create uses P2P_PREC_DEFAULT. */
+typedef enum { P2P_PREC_F32 = 0, P2P_PREC_F16X3 = 1, P2P_PREC_AUTO = 2 } p2p_precision;
 #define P2P_PREC_DEFAULT P2P_PREC_F16X3
 P2P_API int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone,
                         int precision, p2p_model** out);
 P2P_API void p2p_model_destroy(p2p_model* model);
+/* P2P_PREC_F32 or P2P_PREC_F16X3: the arithmetic the object's next pass will use (a P2P_PREC_AUTO object reports F16X3 until a
+ * range event switched it to its fp32 twin); negative on a null handle. */
+P2P_API int p2p_model_precision(const p2p_model* model);
+/* Operand-range events of direct forward calls (p2p_forward_async) since the last query: synchronises the context stream, stores the
+ * largest offending magnitude in *max_abs (0 = none) and clears the flag.  No reference counterpart (TensorFlow computes in fp32). */
+P2P_API int p2p_ctx_range_event(p2p_ctx* ctx, float* max_abs);
 
 /* Replaces `self.generator_train.predict(x)` (reference recognition.py:84,129):
  * x [n,128,128,3] float32 NHWC -> xyz [n,128,128,3] (tanh) and prob [n,128,128,1] (sigmoid).
@@ -158,6 +173,7 @@ typedef struct {
 /* est_pose status: the reference signals failure in-band with -1 sentinels (recognition.py:79,
  * 127,191); the shim maps any status != 0 back to those sentinels. */
 typedef enum {
+    P2P_POSE_ABSENT = -1,          /* padding record of a gathered batch (p2p_est_pose_collect_gathered): no detection here */
     P2P_POSE_OK = 0,
     P2P_POSE_CROP_TOO_SMALL = 1,   /* recognition.py:78-79  */
     P2P_POSE_NO_CANDIDATE = 2,     /* recognition.py:125-127 */
@@ -264,6 +280,29 @@ P2P_API int p2p_est_pose_submit(p2p_ctx* ctx, const p2p_object* objects, int n_o
                         int n_images, const p2p_detection* dets, int n_dets, const p2p_est_pose_opts* opts,
                         int* ticket);
 P2P_API int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU (no reference call site -- tools/5_evaluation_bop_basic.py:289-304 walks the detections of an
+ * image one by one on one GPU).  Detections are independent: one process per GPU, each with its own p2p_ctx, runs the whole
+ * pipeline on its shard.  The only exchange is one RCCL all-gather (xGMI) of the final p2p_pose records per batch.
+ *   p2p_comm_unique_id   rank 0 draws the 128-byte id; the host program hands it to the other ranks by whatever it has
+ *                        (MPI, a file, torch.distributed, a socket).
+ *   p2p_comm_create      every rank: joins the communicator on its context's device (ncclCommInitRank -- collective).
+ *   p2p_est_pose_collect_gathered   p2p_est_pose_collect + the gather: the batch's records go DEVICE to DEVICE over the
+ *                        communicator on the batch's tail stream (they never visit the host first) and are copied out once.
+ *                        `poses[n_dets]` = this rank's own results as from collect; `gathered[world][n_max]` = every rank's records in
+ *                        its caller's detection order, padded with status = P2P_POSE_ABSENT.  n_max >= the largest batch of any rank
+ *                        and equal on all ranks.  Collective: every rank calls it once per step, in the same order.
+ * RCCL is bound at run time (an RCCL already mapped into the process -- PyTorch's wheel carries one -- is reused, else librccl.so.1;
+ * P2P_RCCL_LIB overrides): the library loads and runs single-GPU on machines without RCCL; these calls then fail with P2P_ERR_HIP.
+ * ---------------------------------------------------------------------------------------- */
+#define P2P_COMM_ID_BYTES 128
+typedef struct p2p_comm p2p_comm;
+P2P_API int p2p_comm_unique_id(char* id /* [P2P_COMM_ID_BYTES] */);
+P2P_API int p2p_comm_create(p2p_ctx* ctx, int rank, int world, const char* id /* [P2P_COMM_ID_BYTES] */, p2p_comm** out);
+P2P_API void p2p_comm_destroy(p2p_comm* comm);
+P2P_API const char* p2p_comm_library(void);   /* path of the RCCL the calls above bound ("" if none could be) */
+P2P_API int p2p_est_pose_collect_gathered(p2p_ctx* ctx, p2p_comm* comm, int ticket, p2p_pose* poses, int n_max, p2p_pose* gathered);
 
 /* Replaces `cv2.solvePnPRansac(obj, img, camK, None, flags=EPNP, reprojectionError, iterationsCount)`
  * + `cv2.Rodrigues` (reference recognition.py:216-223) for a batch of independent problems.

@@ -14,12 +14,17 @@ P2P_OK = 0
 ABI_VERSION = 7            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
 MAX_RANSAC_ITERATIONS = 128
 BACKBONE = {"paper": 0, "resnet50": 1}
-PRECISION = {"f32": 0, "f16x3": 1}
+PRECISION = {"f32": 0, "f16x3": 1, "auto": 2}     # p2p_precision; "auto" = split-f16 with an fp32 twin it falls back to on a range event
+ERR_RANGE = -5
 MEM_HOST, MEM_DEVICE = 0, 1
 
 
 class P2PError(RuntimeError):
     pass
+
+
+class P2PRangeError(P2PError):
+    """P2P_ERR_RANGE: a split-f16 generator pass stored an activation beyond the f16 operand range (include/p2p_mi355.h)."""
 
 
 class Tensor(C.Structure):
@@ -194,6 +199,8 @@ def lib():
     L.p2p_model_create_ex.argtypes = [vp, C.POINTER(Tensor), ci, ci, ci, C.POINTER(vp)]
     L.p2p_model_destroy.argtypes = [vp]
     L.p2p_model_destroy.restype = None
+    L.p2p_model_precision.argtypes = [vp]
+    L.p2p_ctx_range_event.argtypes = [vp, C.POINTER(C.c_float)]
     L.p2p_predict.argtypes = [vp, vp, vp, ci, vp, vp, ci]
     L.p2p_forward_async.argtypes = [vp, vp, vp, ci, vp]
     L.p2p_est_pose_batch.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,
@@ -213,4 +220,4 @@ def lib():
 def check(rc: int, what: str) -> None:
     if rc != P2P_OK:
         msg = lib().p2p_last_error()
-        raise P2PError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))
+        raise (P2PRangeError if rc == ERR_RANGE else P2PError)("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -50,8 +50,9 @@ __device__ __forceinline__ float dpp_row(const float v)       // lane i of a 16-
 template <int C1_KH, int C1_PAD, int NCO, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __restrict__ x, int N, const Conv1Groups G,
                                                              int act, float alpha, float* __restrict__ out, int tiles_per_wg,
-                                                             float* __restrict__ pool_out)
+                                                             float* __restrict__ pool_out, unsigned* __restrict__ range_acc)
 {
+    float amax = 0.f;      // operand-range guard (kernels.h)
     constexpr int C1_ROWS_IN = (C1_ROWS_OUT - 1) * 2 + C1_KH;        // 9 / 7 input rows
     constexpr int C1_PLANE = C1_ROWS_IN * C1_ROW_BYTES;              // hi plane, then lo plane
     constexpr int C1_W_BYTES = C1_KH * 2 * 4 * C1_COUT * 16;         // [kh][hi,lo][k-group][cout][8 halves] = 57344 / 40960
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
                         else if (act == ACT_LEAKY) u = u > 0.f ? u : u * alpha;
                         v[m][q][e] = u;
                     }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) amax = range_note4(amax, v[m][q]);      // the pooled values are maxima of these
             }
             if (t < tiles_per_wg) {          // the skip connection's channels 0 .. 31 of both rows
 #pragma unroll
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
                     else if (act == ACT_LEAKY) u = u > 0.f ? u : u * alpha;
                     v[e] = u;
                 }
+                amax = range_note4(amax, v);
                 *reinterpret_cast<f32x4*>(op + q * 16) = v;
             }
         }
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
         __syncthreads();                           // the last emit's exchange reads are done
         emit(carry, (C1_HOUT >> 1) - 1);
     }
+    range_commit(range_acc, amax);
 }
 
 }  // namespace
@@ -259,7 +264,7 @@ bool conv1_f16x3_supported(int KH, int Cout) { return (KH == 7 && Cout == 64) ||
 // pool_out (KH = 7 only): also produce MaxPooling2D(3, 2, 'same') of the layer, [N][32][32][64]; `out` is then only guaranteed to hold
 // channels 0 .. 31 (the decoder's skip connection)
 hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, float* pool_out,
-                              hipStream_t s)
+                              unsigned* range_acc, hipStream_t s)
 {
     if (N <= 0) return hipSuccess;
     if (!conv1_f16x3_supported(KH, Cout) || G.n_groups < 1 || G.n_groups > IGEMM_MAX_GROUPS) return hipErrorInvalidValue;
@@ -270,11 +275,11 @@ hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Con
     const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * tpw));
     static const bool no_fuse = getenv("P2P_NO_POOL_FUSE") != nullptr;      // development switch (A/B)
     if (KH == 7 && pool_out && tpw == C1_TILES_PER_WG && !no_fuse) {
-        hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, true>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, pool_out);
+        hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, true>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, pool_out, range_acc);
         return hipGetLastError();
     }
-    if (KH == 7) hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, false>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, nullptr);
-    else hipLaunchKernelGGL((conv1_f16x3_kernel<5, 1, 128, false>), dim3(wgs, 2), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, nullptr);
+    if (KH == 7) hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, false>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, nullptr, range_acc);
+    else hipLaunchKernelGGL((conv1_f16x3_kernel<5, 1, 128, false>), dim3(wgs, 2), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, nullptr, range_acc);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && KH == 7 && pool_out) e = launch_maxpool3s2(out, N, C1_HOUT, C1_HOUT, Cout, pool_out, s);
     return e;

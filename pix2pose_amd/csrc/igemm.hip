@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
         if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + col);
         if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
     }
+    float amax = 0.f;      // operand-range guard (kernels.h)
 #pragma unroll 1
     for (int h = 0; h < WGM; ++h) {
         if (wm == h) {
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
                         }
+                        amax = range_note4(amax, v);
                         *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
                     }
                 }
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
         }
         if (h + 1 < WGM) __syncthreads();
     }
+    range_commit(p.range_acc, amax);
 }
 
 template <int WGM, int WGN, int TM, int TN, int PREC>
@@ -399,9 +402,10 @@ hipError_t launch_igemm(const IgemmParams& p, int cfg, hipStream_t s)
 // ------------------------------------------------------------------------------------------
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int M, int Cout,
                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                     int act, float alpha, float* __restrict__ out)
+                                     int act, float alpha, float* __restrict__ out, unsigned* __restrict__ range_acc)
 {
     const size_t total = (size_t)M * Cout;
+    float amax = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < ksplit; ++z) s += partial[(size_t)z * total + i];
@@ -409,40 +413,47 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int kspl
         float v = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
         if (act == ACT_RELU) v = fmaxf(v, 0.f);
         else if (act == ACT_LEAKY) v = v > 0.f ? v : v * alpha;
+        amax = fmaxf(amax, fabsf(v));
         out[i] = v;
     }
+    range_commit(range_acc, amax);
 }
 
 hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cout, const float* scale,
-                                const float* shift, int act, float alpha, float* out, hipStream_t s)
+                                const float* shift, int act, float alpha, float* out, unsigned* range_acc, hipStream_t s)
 {
     const size_t total = (size_t)M * Cout;
     const int blocks = (int)min((size_t)2048, (total + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, ksplit, M, Cout, scale,
-                       shift, act, alpha, out);
+                       shift, act, alpha, out, range_acc);
     return hipGetLastError();
 }
 
 __global__ void splitk_reduce_rows_kernel(const float* __restrict__ partial, int ksplit, int M, int Cout, int row0, int rows,
-                                          const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out)
+                                          const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+                                          unsigned* __restrict__ range_acc)
 {
     const size_t total = (size_t)rows * Cout, slab = (size_t)M * Cout;
+    float amax = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t o = (size_t)row0 * Cout + i;
         float s = 0.f;
         for (int z = 0; z < ksplit; ++z) s += partial[(size_t)z * slab + o];
         const int c = (int)(i % Cout);
-        out[o] = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+        const float v = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+        amax = fmaxf(amax, fabsf(v));
+        out[o] = v;
     }
+    range_commit(range_acc, amax);
 }
 
 hipError_t launch_splitk_reduce_rows(const float* partial, int ksplit, int M, int Cout, int row0, int rows, const float* scale,
-                                     const float* shift, float* out, hipStream_t s)
+                                     const float* shift, float* out, unsigned* range_acc, hipStream_t s)
 {
     if (rows <= 0) return hipSuccess;
     const size_t total = (size_t)rows * Cout;
     const int blocks = (int)min((size_t)1024, (total + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(blocks), dim3(256), 0, s, partial, ksplit, M, Cout, row0, rows, scale, shift, out);
+    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(blocks), dim3(256), 0, s, partial, ksplit, M, Cout, row0, rows, scale, shift, out, range_acc);
     return hipGetLastError();
 }
 

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
         if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + col);
         if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
     }
+    float amax = 0.f;      // operand-range guard (kernels.h)
 #pragma unroll 1
     for (int h = 0; h < WGM; ++h) {
         if (wm == h) {
@@ -292,11 +293,13 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
                 }
+                amax = range_note4(amax, v);
                 *reinterpret_cast<f32x4*>(p.out + (size_t)ops[it] * p.out_cstride + p.out_coff + col) = v;
             }
         }
         if (h + 1 < WGM) __syncthreads();
     }
+    range_commit(p.range_acc, amax);
 }
 
 }  // namespace

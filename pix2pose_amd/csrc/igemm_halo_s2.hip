@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo_s2_kernel(const IgemmParams
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + col);
     if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
+    float amax = 0.f;      // operand-range guard (kernels.h)
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         if (wm == h) {
@@ -278,10 +279,11 @@ __global__ __launch_bounds__(256, 3) void igemm_halo_s2_kernel(const IgemmParams
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
             }
+            amax = range_note4(amax, v);
             *reinterpret_cast<f32x4*>(p.out + op * p.out_cstride + p.out_coff + col) = v;
         }
         if (h == 0) __syncthreads();
-    }
+    }    range_commit(p.range_acc, amax);
 }
 
 }  // namespace

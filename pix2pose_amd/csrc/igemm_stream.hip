@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
                 }
         return;
     }
+    float amax = 0.f;      // operand-range guard (kernels.h)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + j * 32 + li;
@@ -251,10 +252,12 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
                 float v = fmaf(acc[i][j][r], sc, sh) + rs[r];
                 if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == ACT_LEAKY) v = v > 0.f ? v : v * p.alpha;
+                amax = fmaxf(amax, fabsf(v));
                 p.out[(size_t)ops[r] * p.out_cstride + p.out_coff + col] = v;
             }
         }
     }
+    range_commit(p.range_acc, amax);
 }
 
 }  // namespace

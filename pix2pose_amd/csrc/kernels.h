@@ -9,6 +9,21 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum EpiMode { EPI_NORMAL = 0, EPI_HEAD = 1 };
 enum Prec { PREC_F32 = 0, PREC_F16X3 = 1 };   // igemm arithmetic: fp32 MFMA, or fp32 emulated with 3 split-f16 MFMAs
 
+// Operand-range guard of the split-f16 arithmetic (PREC_F16X3): an activation is split as hi = f16(x), lo = f16(x - hi), so |x| must stay
+// below the f16 maximum (65504).  Every epilogue that writes a tensor a later layer reads as a matrix operand tracks the largest magnitude
+// it stores (two VALU instructions per float4) and, only if that exceeds the limit, raises a device-side word with atomicMax (float bits of
+// a non-negative value order like unsigned integers).  No atomic is issued on the normal path.  Batch-normalised networks sit orders of
+// magnitude below; the two linear Dense layers (ae_model.py:199-200) have no BatchNorm behind them.
+constexpr float RANGE_LIMIT = 6.0e4f;
+template <typename V4> __device__ __forceinline__ float range_note4(float amax, const V4& v)
+{
+    return fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+}
+__device__ __forceinline__ void range_commit(unsigned* acc, float amax)
+{
+    if (acc && amax > RANGE_LIMIT) atomicMax(acc, __float_as_uint(amax));
+}
+
 constexpr int IGEMM_MAX_TAPS = 25;
 constexpr int IGEMM_BK = 32;
 constexpr int IGEMM_MAX_GROUPS = 48;  // object models one launch can serve (mixed-object batches)          // K-step (floats); every channel segment is a multiple of it
@@ -69,6 +84,7 @@ struct IgemmParams {
     // grouped launch (n_groups > 1): detections of several objects in one batch, sorted by object;
     // grp[n_groups] is a sentinel {row0 = M, tile0 = number of M-tiles}.  n_groups <= 1: w/scale/shift above.
     int n_groups;
+    unsigned* range_acc;   // operand-range guard (see RANGE_LIMIT): raised when a stored magnitude exceeds the limit; may be null
     IgemmGroup grp[IGEMM_MAX_GROUPS + 1];
 };
 
@@ -128,11 +144,11 @@ hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s);
 
 // out[m][co] = act(sum_z partial[z][m][co] * scale + shift)
 hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cout, const float* scale,
-                                const float* shift, int act, float alpha, float* out, hipStream_t s);
+                                const float* shift, int act, float alpha, float* out, unsigned* range_acc, hipStream_t s);
 
 // same, rows [row0, row0+rows) only (grouped launches: per-object bias); no activation
 hipError_t launch_splitk_reduce_rows(const float* partial, int ksplit, int M, int Cout, int row0, int rows, const float* scale,
-                                     const float* shift, float* out, hipStream_t s);
+                                     const float* shift, float* out, unsigned* range_acc, hipStream_t s);
 
 // First-layer direct convolution, Cin = 3 (conv1 7x7/2 of the ResNet front, conv1_x 5x5/2 of
 // the paper encoder), fused scale/shift + activation.  w_packed: [kh*kw*3][Cout].
@@ -155,7 +171,7 @@ struct Conv1Groups {
     const float* shift[IGEMM_MAX_GROUPS];
 };
 hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, float* pool_out,
-                              hipStream_t s);
+                              unsigned* range_acc, hipStream_t s);
 
 // MaxPooling2D 3x3 stride 2, TF 'SAME' (pad 0 before / 1 after), NHWC, C % 4 == 0.
 hipError_t launch_maxpool3s2(const float* x, int N, int H, int W, int C, float* out, hipStream_t s);

@@ -31,6 +31,11 @@ struct Model {
     int prec = PREC_F32;
     int device = 0;
     std::map<std::string, ConvLayer> L;
+    // P2P_PREC_AUTO: a split-f16 model with a strict-fp32 twin of the same weights.  The generator runs split-f16 until an operand-range
+    // event (kernels.h: RANGE_LIMIT) is seen on a pass of this object; from then on every pass of the object uses the twin.
+    Model* twin = nullptr;
+    mutable bool use_twin = false;
+    const Model* effective() const { return (use_twin && twin) ? twin : this; }
     ~Model();
 };
 
@@ -66,6 +71,11 @@ struct Ctx {
     float* xyz_stage = nullptr;
     float* prob_stage = nullptr;
     Pipeline* pipe = nullptr;
+    // operand-range guard (kernels.h): device words raised by the epilogues of split-f16 passes.  Word 0: direct forward calls
+    // (p2p_predict / p2p_forward_async), words 1.. : one per est_pose batch slot.  range_cur = where the passes being enqueued report.
+    unsigned* range_words = nullptr;
+    unsigned* range_cur = nullptr;
+    int range_read(int word, float* out);      // synchronous read-and-clear of a word (after the stream that wrote it is idle)
     // measurement hooks (p2p_profile_*)
     bool profiling = false;
     struct ProfEvent { hipEvent_t a, b; int cfg; double flops; };

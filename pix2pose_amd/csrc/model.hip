@@ -507,6 +507,19 @@ int Ctx::ensure_lane(int i)
     return P2P_OK;
 }
 
+int Ctx::range_read(int word, float* out)
+{
+    unsigned bits = 0;
+    *out = 0.f;
+    if (!range_words) return P2P_OK;
+    HIP_TRY(hipMemcpy(&bits, range_words + word, sizeof(bits), hipMemcpyDeviceToHost));
+    if (bits) {
+        HIP_TRY(hipMemset(range_words + word, 0, sizeof(bits)));
+        memcpy(out, &bits, sizeof(bits));
+    }
+    return P2P_OK;
+}
+
 int Ctx::ensure_workspace()
 {
     if (x_stage) return P2P_OK;
@@ -593,6 +606,7 @@ static int prepare_conv(Ctx& X, const ConvLayer& L, const ConvCall& c, PreparedC
     p.out_cstride = c.out_cstride; p.out_coff = c.out_coff;
     p.mode = c.mode;
     p.prec = L.prec;
+    p.range_acc = (L.prec == PREC_F16X3 && c.mode == EPI_NORMAL) ? X.range_cur : nullptr;      // the heads' outputs are bounded (tanh / sigmoid)
     const int cfg = L.Cout > 64 ? 0 : (L.Cout > 32 ? 1 : 2);      // 128x128 / 128x64 / 128x32 tiles
     if (X.grp && X.grp->models.size() > 1) {
         const GroupCtx& G = *X.grp;
@@ -794,7 +808,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
                 G.start[g] = g0(g); G.w[g] = c1.w; G.scale[g] = c1.scale; G.shift[g] = c1.shift;
             }
             G.start[n_grp] = n;
-            HIP_TRY(launch_conv1_f16x3(x, n, 7, 64, G, ACT_RELU, LEAKY, A["f1"], A["p1"], st));      // + the max-pool (f1: skip channels)
+            HIP_TRY(launch_conv1_f16x3(x, n, 7, 64, G, ACT_RELU, LEAKY, A["f1"], A["p1"], X.range_cur, st));      // + the max-pool (f1: skip channels)
         } else {
         for (int g = 0; g < n_grp; ++g) {      // VALU first layer: one launch per object (tiny)
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
@@ -828,7 +842,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
                 G.start[g] = g0(g); G.w[g] = c1.w; G.scale[g] = c1.scale; G.shift[g] = c1.shift;
             }
             G.start[n_grp] = n;
-            HIP_TRY(launch_conv1_f16x3(x, n, 5, 128, G, ACT_LEAKY, LEAKY, A["f1"], nullptr, st));
+            HIP_TRY(launch_conv1_f16x3(x, n, 5, 128, G, ACT_LEAKY, LEAKY, A["f1"], nullptr, X.range_cur, st));
         } else
         for (int g = 0; g < n_grp; ++g) {
             const ConvLayer& c1 = grp_model(g).L.at("conv1");
@@ -852,13 +866,13 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         c.ksplit = 32; c.partial = A["part"];
         if ((rc = run_conv(X, L, c))) return rc;
         if (n_grp == 1) {
-            HIP_TRY(launch_splitk_reduce(A["part"], 32, n, 256, L.scale, L.shift, ACT_NONE, LEAKY, A["enc"], st));
+            HIP_TRY(launch_splitk_reduce(A["part"], 32, n, 256, L.scale, L.shift, ACT_NONE, LEAKY, A["enc"], M.prec == PREC_F16X3 ? X.range_cur : nullptr, st));
         } else {
             // per-object bias: reduce each object's sample rows with its own shift.  The partial slabs are
             // [z][n][256]; a row range is strided by n*256 between slabs, so reduce through a strided view
             for (int g = 0; g < n_grp; ++g) {
                 const ConvLayer& Lg = grp_model(g).L.at("dense_enc");
-                HIP_TRY(launch_splitk_reduce_rows(A["part"], 32, n, 256, g0(g), g0(g + 1) - g0(g), Lg.scale, Lg.shift, A["enc"], st));
+                HIP_TRY(launch_splitk_reduce_rows(A["part"], 32, n, 256, g0(g), g0(g + 1) - g0(g), Lg.scale, Lg.shift, A["enc"], M.prec == PREC_F16X3 ? X.range_cur : nullptr, st));
             }
         }
     }
@@ -965,6 +979,7 @@ int forward_grouped(Ctx& X, const std::vector<const Model*>& models, const std::
 Model::~Model()
 {
     for (auto& kv : L) free_layer(kv.second);
+    delete twin;
 }
 
 Ctx::~Ctx()
@@ -975,6 +990,7 @@ Ctx::~Ctx()
         if (ln.stream && ln.stream != stream) hipStreamDestroy(ln.stream);
     }
     if (fork) hipEventDestroy(fork);
+    if (range_words) hipFree(range_words);
     if (x_stage) hipFree(x_stage);
     if (xyzp_stage) hipFree(xyzp_stage);
     if (xyz_stage) hipFree(xyz_stage);
@@ -1031,6 +1047,12 @@ int p2p_ctx_create(int device, int max_batch, p2p_ctx** out)
     c->max_batch = max_batch;
     hipError_t e = hipStreamCreate(&c->stream);
     if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return P2P_ERR_HIP; }
+    if ((e = hipMalloc((void**)&c->range_words, 8 * sizeof(unsigned))) != hipSuccess || (e = hipMemset(c->range_words, 0, 8 * sizeof(unsigned))) != hipSuccess) {
+        set_error("p2p_ctx_create: %s", hipGetErrorString(e));
+        delete c;
+        return P2P_ERR_HIP;
+    }
+    c->range_cur = c->range_words;
     *out = reinterpret_cast<p2p_ctx*>(c);
     return P2P_OK;
 }
@@ -1080,7 +1102,7 @@ int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int
 int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, int backbone, int precision, p2p_model** out)
 {
     if (!ctx || !tensors || !out || n_tensors <= 0) { set_error("p2p_model_create: bad arguments"); return P2P_ERR_INVALID_ARG; }
-    if (precision != P2P_PREC_F32 && precision != P2P_PREC_F16X3) { set_error("p2p_model_create: unknown precision %d", precision); return P2P_ERR_INVALID_ARG; }
+    if (precision != P2P_PREC_F32 && precision != P2P_PREC_F16X3 && precision != P2P_PREC_AUTO) { set_error("p2p_model_create: unknown precision %d", precision); return P2P_ERR_INVALID_ARG; }
     *out = nullptr;
     if (backbone != P2P_BACKBONE_PAPER && backbone != P2P_BACKBONE_RESNET50) {
         // the reference silently leaves generator_train undefined here (recognition.py:21-26)
@@ -1096,11 +1118,18 @@ int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, 
     }
     Model* m = new Model();
     m->backbone = backbone;
-    m->prec = precision == P2P_PREC_F16X3 ? PREC_F16X3 : PREC_F32;
+    m->prec = precision == P2P_PREC_F32 ? PREC_F32 : PREC_F16X3;
     m->device = c->device;
     int rc = build_model(T, *m);
     if (rc) { delete m; return rc; }
     for (auto& kv : m->L) kv.second.name = kv.first;
+    if (precision == P2P_PREC_AUTO) {          // the strict-fp32 twin the object falls back to after an operand-range event
+        Model* t = new Model();
+        t->backbone = backbone; t->prec = PREC_F32; t->device = c->device;
+        m->twin = t;
+        if ((rc = build_model(T, *t))) { delete m; return rc; }
+        for (auto& kv : t->L) kv.second.name = kv.first;
+    }
     *out = reinterpret_cast<p2p_model*>(m);
     return P2P_OK;
 }
@@ -1118,7 +1147,23 @@ int p2p_forward_async(p2p_ctx* ctx, const p2p_model* model, const float* x_dev, 
     if (!ctx || !model || !x_dev || !xyzp_dev || n < 0) { set_error("p2p_forward_async: bad arguments"); return P2P_ERR_INVALID_ARG; }
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     HIP_TRY(hipSetDevice(c->device));
-    return forward_async(*c, *reinterpret_cast<const Model*>(model), x_dev, n, xyzp_dev);
+    c->range_cur = c->range_words;
+    return forward_async(*c, *reinterpret_cast<const Model*>(model)->effective(), x_dev, n, xyzp_dev);
+}
+
+int p2p_ctx_range_event(p2p_ctx* ctx, float* max_abs)
+{
+    if (!ctx || !max_abs) { set_error("p2p_ctx_range_event: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return c->range_read(0, max_abs);
+}
+
+int p2p_model_precision(const p2p_model* model)
+{
+    if (!model) return P2P_ERR_INVALID_ARG;
+    return reinterpret_cast<const Model*>(model)->effective()->prec == PREC_F32 ? P2P_PREC_F32 : P2P_PREC_F16X3;
 }
 
 int p2p_predict(p2p_ctx* ctx, const p2p_model* model, const float* x, int n, float* xyz, float* prob, int mem)
@@ -1126,12 +1171,14 @@ int p2p_predict(p2p_ctx* ctx, const p2p_model* model, const float* x, int n, flo
     if (!ctx || !model || n < 0 || (n > 0 && (!x || !xyz || !prob))) { set_error("p2p_predict: bad arguments"); return P2P_ERR_INVALID_ARG; }
     if (mem != P2P_MEM_HOST && mem != P2P_MEM_DEVICE) { set_error("p2p_predict: bad mem flag %d", mem); return P2P_ERR_INVALID_ARG; }
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    const Model& m = *reinterpret_cast<const Model*>(model);
+    const Model& m0 = *reinterpret_cast<const Model*>(model);
     HIP_TRY(hipSetDevice(c->device));
     int rc = c->ensure_workspace();
     if (rc) return rc;
     const size_t px = 128 * 128;
+    c->range_cur = c->range_words;
     for (int i = 0; i < n; i += c->max_batch) {
+        const Model& m = *m0.effective();
         const int k = std::min(c->max_batch, n - i);
         const float* xin = x + (size_t)i * px * 3;
         if (mem == P2P_MEM_HOST) {
@@ -1147,6 +1194,16 @@ int p2p_predict(p2p_ctx* ctx, const p2p_model* model, const float* x, int n, flo
             HIP_TRY(hipMemcpyAsync(prob + (size_t)i * px, oprob, (size_t)k * px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (m.prec == PREC_F16X3) {          // operand-range guard of the split-f16 arithmetic
+            float amax = 0.f;
+            if ((rc = c->range_read(0, &amax))) return rc;
+            if (amax > 0.f) {
+                if (m0.twin) { m0.use_twin = true; i -= c->max_batch; continue; }      // P2P_PREC_AUTO: this chunk again, and all later ones, in fp32
+                set_error("p2p_predict: an activation of magnitude %g exceeds the split-f16 operand range (%g): create the model with "
+                          "P2P_PREC_F32 or P2P_PREC_AUTO", (double)amax, (double)RANGE_LIMIT);
+                return P2P_ERR_RANGE;
+            }
+        }
     }
     return P2P_OK;
 }

@@ -158,6 +158,9 @@ struct Slot {
     size_t host_cap = 0;
     PinnedBuf h_mask, h_pred, h_stat;   // pinned landing buffers of the optional outputs (sorted order)
     PinnedBuf h_frames;                 // pinned staging of host frames (pageable caller memory -> here -> DMA)
+    PinnedBuf h_range;                  // operand-range word of this batch's generator passes (kernels.h: RANGE_LIMIT), landed with the poses
+    int range_word = 0;                 // index into Ctx::range_words (1 + slot index)
+    unsigned* range_dev = nullptr;      // = Ctx::range_words + range_word
     // host-side description of the batch (kept from submit to collect: the stage-2 pass of an asynchronous batch is enqueued
     // by the NEXT submit, merged with that batch's stage-1 pass, or by collect)
     std::vector<int> perm;
@@ -188,5 +191,10 @@ struct Pipeline {
     int next_ticket = 0;
     ~Pipeline();
 };
+
+// RCCL all-gather of a batch's pose records (comm.hip)
+struct Comm;
+int comm_world(const Comm& C);
+int comm_gather(Ctx& X, Comm& C, Slot& s, hipStream_t ts, int n_max, p2p_pose* gathered);
 
 }  // namespace p2p

@@ -74,7 +74,7 @@ Pipeline::~Pipeline()
     for (Slot& s : slot) {
         for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images, &s.crec, &s.cseg, &s.sacc,
                           &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
-        for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat, &s.h_frames}) b->release();
+        for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat, &s.h_frames, &s.h_range}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
         if (s.done) (void)hipEventDestroy(s.done);
     }
@@ -1115,6 +1115,25 @@ __global__ void aa_back_range_kernel(CandRange* __restrict__ crange, int n_cand,
 
 // Hand a finished batch over to the caller: sorted order -> caller order, pinned landing buffers -> the caller's
 // (pageable) output arrays named in the options of the submit / blocking call.
+// -> 0, or P2P_ERR_RANGE when a generator pass of the batch stored an activation beyond the split-f16 operand range: objects created with
+// P2P_PREC_AUTO switch to their fp32 twin (all_have_twin tells the blocking caller that running the batch again will succeed)
+static int range_verdict(const Slot& s, bool* all_have_twin)
+{
+    *all_have_twin = false;
+    float amax = 0.f;
+    if (s.h_range.p) memcpy(&amax, s.h_range.p, sizeof(amax));
+    if (!(amax > 0.f)) return P2P_OK;
+    bool all = true;
+    for (const BatchGroup& g : s.groups) {
+        const Model* m = reinterpret_cast<const Model*>(s.objs[g.obj].model);
+        if (m->twin) m->use_twin = true; else all = false;
+    }
+    *all_have_twin = all;
+    set_error("est_pose: an activation of magnitude %g exceeds the split-f16 operand range (%g)%s", (double)amax, (double)RANGE_LIMIT,
+              all ? "; the batch's objects (P2P_PREC_AUTO) now run in fp32" : ": create the model with P2P_PREC_F32 or P2P_PREC_AUTO");
+    return P2P_ERR_RANGE;
+}
+
 static void finish_batch(const Slot& s, p2p_pose* poses)
 {
     const p2p_est_pose_opts& opt = s.opt;
@@ -1152,7 +1171,7 @@ static int forward_parts(Ctx& X, hipStream_t st, const Slot* const* parts, const
     bool same_backbone = true;
     for (int k = 0; k < n_parts; ++k)
         for (const BatchGroup& g : parts[k]->groups) {
-            const Model* m = reinterpret_cast<const Model*>(parts[k]->objs[g.obj].model);
+            const Model* m = reinterpret_cast<const Model*>(parts[k]->objs[g.obj].model)->effective();
             const int c = (g.end - g.begin) * per_det[k];
             if (!ms.empty() && ms.back() == m) { cnt.back() += c; continue; }      // the same network on both sides of a part boundary: one run
             ms.push_back(m);
@@ -1160,9 +1179,12 @@ static int forward_parts(Ctx& X, hipStream_t st, const Slot* const* parts, const
             same_backbone = same_backbone && m->backbone == ms[0]->backbone;
         }
     X.cur = &X.lane[0];
+    X.range_cur = X.range_words + parts[0]->range_word;      // operand-range events of this pass are reported with parts[0]'s batch
+    bool same_prec = true;
+    for (const Model* m : ms) same_prec = same_prec && m->prec == ms[0]->prec;
     if (ms.size() == 1) return forward_async(X, *ms[0], xin, cnt[0], yout);
-    if (same_backbone) return forward_grouped(X, ms, cnt, xin, yout);      // one grouped pass: every M-tile uses its object's weights
-    // mixed backbones: per-object passes round-robin over the context's lanes (stream + private activation workspace) so that
+    if (same_backbone && same_prec) return forward_grouped(X, ms, cnt, xin, yout);      // one grouped pass: every M-tile uses its object's weights
+    // mixed backbones (or precisions: an object that fell back to its fp32 twin): per-object passes round-robin over the context's lanes (stream + private activation workspace) so that
     // the small per-object launch sequences overlap; fork/join with events around them
     const int nl = std::min<int>((int)ms.size(), Ctx::N_LANES);
     for (int l = 1; l < nl; ++l) { int r = X.ensure_lane(l); if (r) return r; }
@@ -1320,6 +1342,12 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
         }
     }
     SL.max_side = max_side;
+    // operand-range word of this batch's generator passes: cleared in stream order before pass 1, landed with the poses
+    SL.range_word = 1 + (int)(&SL - P.slot);
+    SL.range_dev = X.range_words + SL.range_word;
+    if ((rc = SL.h_range.reserve(sizeof(unsigned)))) return rc;
+    memset(SL.h_range.p, 0, sizeof(unsigned));
+    HIP_TRY(hipMemsetAsync(SL.range_dev, 0, sizeof(unsigned), st));
     SL.img_hw.resize(n);
     SL.img_w.resize(n);
     for (int i = 0; i < n; ++i) { SL.img_hw[i] = hd[i].H * hd[i].W; SL.img_w[i] = hd[i].W; }
@@ -1496,6 +1524,7 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
                        SL.results.as<PnpResult>(), K, n, SL.poses.as<p2p_pose>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(SL.host_poses, SL.poses.p, sizeof(p2p_pose) * n, hipMemcpyDeviceToHost, ts));
+    HIP_TRY(hipMemcpyAsync(SL.h_range.p, SL.range_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ts));      // both generator passes are behind us on this stream
 
     // -- optional outputs of the reference's return tuple (recognition.py:189-193: img_pred_f, valid_mask_full) and the
     //    score_type-2 mask sums: rendered on the tail stream, landed in the slot's pinned buffers, handed over by finish_batch()
@@ -1600,6 +1629,8 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
             const int per[2] = {PS->K, 1};
             if ((rc = forward_parts(X, st, parts, per, 2, PS->x2.as<float>(), PS->y2.as<float>()))) return rc;
             y1 = PS->y2.as<float>() + (size_t)PS->n * PS->K * 16384 * 4;
+            // the merged pass reported to PS's range word: the newcomer inherits it (over-reports PS's stage-1 events, never misses its own)
+            HIP_TRY(hipMemcpyAsync(SL.range_dev, PS->range_dev, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
             if ((rc = enqueue_tail(P, *PS, st, true))) return rc;
         } else {
             if ((rc = flush_stage2(X, P, *PS, st, true))) return rc;
@@ -1641,6 +1672,17 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     }
     HIP_TRY(hipStreamSynchronize(st));
     finish_batch(SL, poses);
+    {
+        bool twins = false;
+        if ((rc = range_verdict(SL, &twins))) {
+            static thread_local int depth = 0;
+            if (!twins || depth > 0) return rc;
+            ++depth;                               // every object of the batch has an fp32 twin (P2P_PREC_AUTO) and now uses it: once more
+            rc = run_est_pose(X, objects, n_obj, images, n_img, dets, n, poses, opt, nullptr);
+            --depth;
+            return rc;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const int o = SL.perm[i];
         if (opt.dbg_x1) memcpy(opt.dbg_x1 + (size_t)o * 16384 * 3, hx1.data() + (size_t)i * 16384 * 3, 16384 * 3 * 4);
@@ -1657,19 +1699,27 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     return P2P_OK;
 }
 
-static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses)
+// comm != nullptr: the records of every rank's batch are all-gathered (device to device, on the tail stream, behind this batch's tail)
+// into gathered[world][n_max] before anything is handed to the host
+static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses, Comm* comm = nullptr, int n_max = 0, p2p_pose* gathered = nullptr)
 {
     if (!X.pipe) { set_error("no batch was submitted"); return P2P_ERR_INVALID_ARG; }
     for (Slot& s : X.pipe->slot)
         if (s.ticket == ticket) {
+            if (comm && s.n > n_max) { set_error("p2p_est_pose_collect_gathered: the batch holds %d detections, n_max is %d", s.n, n_max); return P2P_ERR_INVALID_ARG; }
             if (s.stage2_pending) {            // no later submit picked the stage-2 pass up: run it by itself
                 int rc = flush_stage2(X, *X.pipe, s, X.lane[0].stream, true);
+                if (rc) return rc;
+            }
+            if (comm) {
+                int rc = comm_gather(X, *comm, s, X.pipe->tail_stream, n_max, gathered);
                 if (rc) return rc;
             }
             HIP_TRY(hipEventSynchronize(s.done));
             finish_batch(s, poses);
             s.ticket = -1;
-            return P2P_OK;
+            bool twins = false;
+            return range_verdict(s, &twins);       // P2P_ERR_RANGE: the poses are not to be used; with P2P_PREC_AUTO objects a re-submission runs in fp32
         }
     set_error("ticket %d is not in flight", ticket);
     return P2P_ERR_INVALID_ARG;
@@ -1702,6 +1752,14 @@ int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses)
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     HIP_TRY(hipSetDevice(c->device));
     return collect_est_pose(*c, ticket, poses);
+}
+
+int p2p_est_pose_collect_gathered(p2p_ctx* ctx, p2p_comm* comm, int ticket, p2p_pose* poses, int n_max, p2p_pose* gathered)
+{
+    if (!ctx || !comm || !poses || !gathered || n_max < 1) { set_error("p2p_est_pose_collect_gathered: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    return collect_est_pose(*c, ticket, poses, reinterpret_cast<Comm*>(comm), n_max, gathered);
 }
 
 int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images, int n_images,

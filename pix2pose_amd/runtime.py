@@ -65,8 +65,9 @@ class Generator:
     (reference recognition.py:21-26): ``predict(x) -> [decode, prob]`` (recognition.py:84,129)."""
 
     def __init__(self, weights: dict, backbone: str, ctx: Context | None = None, precision: str = "f16x3"):
-        """precision: 'f32' (fp32 matrix instructions) or 'f16x3' (fp32 emulated with three split-f16
-        MFMAs per product block, fp32 accumulate; see include/p2p_mi355.h)."""
+        """precision: 'f32' (fp32 matrix instructions), 'f16x3' (fp32 emulated with three split-f16
+        MFMAs per product block, fp32 accumulate; see include/p2p_mi355.h) or 'auto' (f16x3 with an fp32 twin the object
+        falls back to when an activation leaves the f16 operand range; without a twin such a pass raises P2PRangeError)."""
         if backbone not in _lib.BACKBONE:
             raise ValueError("unknown backbone %r" % (backbone,))
         if precision not in _lib.PRECISION:
@@ -103,6 +104,11 @@ class Generator:
         _lib.check(_lib.lib().p2p_predict(self.ctx.handle, self._h, x.ctypes.data, n, xyz.ctypes.data,
                                           prob.ctypes.data, _lib.MEM_HOST), "p2p_predict")
         return [xyz, prob]
+
+    @property
+    def active_precision(self) -> str:
+        """'f32' or 'f16x3': what the next pass computes in (an 'auto' generator reports 'f16x3' until a range event)."""
+        return "f32" if _lib.lib().p2p_model_precision(self._h) == 0 else "f16x3"
 
     def forward_device(self, x_ptr: int, n: int, xyzp_ptr: int):
         """Asynchronous forward on device pointers (ints), interleaved [n,128,128,4] output."""

@@ -50,7 +50,9 @@ def test_bench_two_ranks_host_time_and_pinning():
     out = _bench()
     assert out["collective"] == {"backend": "gloo", "device": "cpu", "async": True, "world": 2}
     assert out["rank_cpus"] is None or out["rank_cpus"] >= 1
-    assert out["host_submit_ms_per_step"] is not None and out["host_submit_ms_per_step"] < 2.0, out["host_submit_ms_per_step"]
+    # relative to the GPU's step time (a loaded or throttled box slows both): the host side is 1 - 2 % of a step, 25 % is the alarm
+    assert out["host_submit_ms_per_step"] is not None and out["host_submit_ms_per_step"] < 0.25 * out["ms_per_step"], \
+        (out["host_submit_ms_per_step"], out["ms_per_step"])
 
 
 def test_bench_rccl_path_with_one_rank():
@@ -60,8 +62,12 @@ def test_bench_rccl_path_with_one_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["MASTER_ADDR"] = "127.0.0.1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import socket
+    with socket.socket() as so:                              # a free port, not a fixed one (parallel runs, lingering processes)
+        so.bind(("127.0.0.1", 0))
+        port = str(so.getsockname()[1])
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29747", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--collective",
+                        "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--collective",
                         "--steps", "3", "--warmup", "1", "--no-legs"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

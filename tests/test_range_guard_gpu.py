@@ -1,0 +1,87 @@
+"""Operand-range guard of the split-f16 arithmetic (include/p2p_mi355.h: p2p_precision, P2P_ERR_RANGE, P2P_PREC_AUTO).
+P2P_PREC_F16X3 splits every fp32 activation into two f16 halves, so |activation| must stay below 65504; the layer epilogues track the
+largest magnitude they store.  The reference computes in fp32 (TensorFlow) and has no such limit -- the two linear Dense layers
+(ae_model.py:199-200) have no BatchNorm behind them -- so the test scales the first Dense layer until its output leaves the range:
+  f16x3 alone  -> P2PRangeError from predict() and from est_pose (blocking and submit / collect), nothing returned silently;
+  auto         -> the object falls back to its strict-fp32 twin: same bits as an 'f32' generator, calls succeed;
+  normal weights never trip the guard."""
+import numpy as np
+import pytest
+
+from pix2pose_amd import synthetic as S
+from pix2pose_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _overflowing(backbone, seed=3, gain=3e5):
+    w = dict(W.synthetic_weights(backbone, seed))
+    w["dense_enc.kernel"] = (w["dense_enc.kernel"] * np.float32(gain)).astype(np.float32)       # |dense_enc output| ~ 1e5 .. 1e6
+    w["dense_dec.kernel"] = (w["dense_dec.kernel"] / np.float32(gain)).astype(np.float32)       # the rest of the network sees normal values again
+    return w
+
+
+def _x(n, seed=0):
+    return ((np.random.RandomState(seed).randint(0, 256, (n, 128, 128, 3)).astype(np.float32)) - 128) / 128
+
+
+@pytest.mark.parametrize("backbone", ["paper", "resnet50"])
+def test_predict_guard_and_fp32_fallback(backbone):
+    from pix2pose_amd import _lib
+    from pix2pose_amd.runtime import Context, Generator
+    ctx = Context(0, max_batch=4)
+    w = _overflowing(backbone)
+    x = _x(6)                                                   # two chunks of max_batch
+    ref = Generator(w, backbone, ctx, precision="f32").predict(x)
+    assert np.isfinite(ref[0]).all() and np.abs(ref[0]).max() > 0.05
+    g = Generator(w, backbone, ctx, precision="f16x3")
+    with pytest.raises(_lib.P2PRangeError) as e:
+        g.predict(x)
+    assert "operand range" in str(e.value)
+    # the flag does not stick: a normal model on the same context is not blamed for it
+    ok = Generator(W.synthetic_weights(backbone, 3), backbone, ctx, precision="f16x3")
+    ok.predict(x)
+    ga = Generator(w, backbone, ctx, precision="auto")
+    assert ga.active_precision == "f16x3"
+    out = ga.predict(x)
+    assert ga.active_precision == "f32"
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])       # the twin IS the fp32 model
+
+
+def test_est_pose_guard_blocking_and_async():
+    from pix2pose_amd import _lib
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch, est_pose_submit
+    ctx = Context(0, max_batch=16)
+    w = _overflowing("paper")
+    sc = S.make_scene(3, seed=77)
+    imgs = list(sc["images"])
+    ths = ([0.2, 0.3, 0.35], 0.2)
+    normal = ObjectSpec(Generator(W.synthetic_weights("paper", 3), "paper", ctx), S.OBJ_PARAM, *ths)
+    p_ok, _ = est_pose_batch(ctx, [normal], imgs, sc["dets"])          # real generator output (no injection): whatever it gives, no range error
+    assert len(p_ok) == 3
+    bad = ObjectSpec(Generator(w, "paper", ctx, precision="f16x3"), S.OBJ_PARAM, *ths)
+    with pytest.raises(_lib.P2PRangeError):
+        est_pose_batch(ctx, [bad], imgs, sc["dets"])
+    pend = est_pose_submit(ctx, [bad], imgs, sc["dets"])
+    with pytest.raises(_lib.P2PRangeError):
+        pend.collect()
+    # a following batch of a normal object is clean again (per-batch flags)
+    p2, _ = est_pose_batch(ctx, [normal], imgs, sc["dets"])
+    assert [p.status for p in p2] == [p.status for p in p_ok] and [tuple(p.t) for p in p2] == [tuple(p.t) for p in p_ok]
+    # auto: the blocking call repeats the batch in fp32 by itself and equals an f32 object's result
+    f32 = ObjectSpec(Generator(w, "paper", ctx, precision="f32"), S.OBJ_PARAM, *ths)
+    want, _ = est_pose_batch(ctx, [f32], imgs, sc["dets"])
+    ga = Generator(w, "paper", ctx, precision="auto")
+    got, _ = est_pose_batch(ctx, [ObjectSpec(ga, S.OBJ_PARAM, *ths)], imgs, sc["dets"])
+    assert ga.active_precision == "f32"
+    key = lambda p: (p.status, p.n_inliers, p.n_init_mask, tuple(p.bbox_t), tuple(p.R), tuple(p.t))
+    assert [key(p) for p in got] == [key(p) for p in want]
+    # auto + async: one P2P_ERR_RANGE at collect, the re-submitted batch runs in fp32
+    gb = Generator(w, "paper", ctx, precision="auto")
+    spec_b = ObjectSpec(gb, S.OBJ_PARAM, *ths)
+    pend = est_pose_submit(ctx, [spec_b], imgs, sc["dets"])
+    with pytest.raises(_lib.P2PRangeError):
+        pend.collect()
+    assert gb.active_precision == "f32"
+    again = est_pose_submit(ctx, [spec_b], imgs, sc["dets"]).collect()
+    assert [key(p) for p in again] == [key(p) for p in want]
