@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 AE_GFLOP = {"resnet50": 10.70, "paper": 12.58}        # SURVEY.md section 8a-L / BASELINE.md section 2
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_F16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
+PEAK_HBM_TBPS = 8.0                                    # MI355X_MICROARCH.md: HBM3E peak
 TH_O, TH_I = [0.2, 0.3, 0.35], 0.2                     # cfg/cfg_bop2020.json:8-9
 
 
@@ -168,6 +169,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="stream mode: batches in flight before the oldest is collected (the library holds 2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="debug: all ranks share cuda:0 (needs --backend gloo)")
+    ap.add_argument("--torch-gather", action="store_true", help="gather the pose records with torch.distributed (all_gather_into_tensor) instead of "
+                    "the C ABI's own RCCL all-gather (p2p_est_pose_collect_gathered; the default with --backend nccl in stream mode)")
     ap.add_argument("--collective", action="store_true", help="create the process group and run the pose all-gather even with one rank "
                     "(exercises the RCCL path -- communicator with device_id, device-side all_gather_into_tensor -- on a single GPU)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the ranks of a node to disjoint CPU slices")
@@ -247,6 +250,18 @@ def main():
     torch.cuda.synchronize()
     kw = {} if args.no_inject else dict(inject1=inj1.data_ptr(), inject2=inj2.data_ptr(), inject_slots=3)
 
+    # Pose gather: with the RCCL backend the records go through the library's own communicator (C ABI: p2p_comm_create /
+    # p2p_est_pose_collect_gathered -- ncclAllGather on device-resident records, behind the batch's tail on its stream);
+    # torch.distributed only hands the communicator id round.  Blocking steps and the gloo dry runs keep the torch gather.
+    comm, comm_note = None, None
+    if use_dist and args.backend == "nccl" and not args.torch_gather:
+        try:
+            from pix2pose_amd.parallel import create_comm, gathered_to_records
+            comm = create_comm(ctx)
+            from pix2pose_amd.runtime import Comm as _Comm
+            comm_note = "C ABI ncclAllGather (%s)" % _Comm.library()
+        except Exception as e:      # noqa: BLE001 -- an RCCL that cannot be bound: the torch path still works
+            comm, comm_note = None, "torch.distributed (C ABI communicator unavailable: %s)" % (e,)
     submit_s = []           # host seconds inside every est_pose_submit call (marshalling + enqueueing one batch)
     gather_q = []           # all-gathers in flight: started when a step is collected, waited for one step later
 
@@ -281,11 +296,17 @@ def main():
             pending.append(est_pose_submit(ctx, specs, imgs(i), dets, want_masks=masks, merge_passes=args.merge, anti_aliasing=aa, **kw))
             submit_s.append(time.perf_counter() - t_s)
             if len(pending) >= args.inflight:
-                out = finish(pending.pop(0).collect())
+                out = collect(pending.pop(0))
         while pending:
             pb = pending.pop(0)
-            out = finish(pb.collect(), last=not pending)
+            out = collect(pb, last=not pending)
         return out
+
+    def collect(pb, last=False):
+        if comm is None:
+            return finish(pb.collect(), last=last)
+        poses, allp = pb.collect_gathered(comm, args.batch)
+        return poses, gathered_to_records(allp, world, args.batch, args.batch)
 
     def barrier():
         if use_dist:
@@ -379,6 +400,23 @@ def main():
              "traffic": None}
         return r, dom_name
 
+    def hbm_rooflines(stats):
+        """north_star: "achieved HBM GB/s for the decoder".  The decoder's 5x5 layers sit at ~780 FLOP/B and are held to the MFMA roofline
+        above; the bandwidth-leaning kernel families are priced here: compulsory bytes of their launches (inputs + residual + weights read
+        once, outputs written once, fp32; p2p_kernel_stats.algo_bytes) / HIP-event time of the same launches, against 8 TB/s."""
+        out = []
+        for i, label in ((5, "decoder output heads"), (0, "ResNet 1x1 bottleneck layers (+ dense_dec)"), (1, "Cout = 64 1x1 layers (res2 2a)")):
+            st = stats[i]
+            if not st["launches"] or st["total_ms"] <= 0:
+                continue
+            name = _lib.PROFILE_KERNELS[i][1]
+            tbps = st["algo_bytes"] / (st["total_ms"] * 1e-3) / 1e12
+            out.append({"kernel": (name % 1 if "%d" in name else name), "layers": label, "bound": "hbm", "achieved_TBps": tbps, "peak_TBps": PEAK_HBM_TBPS,
+                        "frac": tbps / PEAK_HBM_TBPS, "algo_MB_per_launch": st["algo_bytes"] / st["launches"] / 1e6,
+                        "avg_launch_ms": st["total_ms"] / st["launches"], "launches": st["launches"],
+                        "algo_tflops": st["algo_flops"] / (st["total_ms"] * 1e-3) / 1e12})
+        return out
+
     roof, dom_name = roofline_of(stats, prof_dt, args.precision, prof_note)
     out = {
         "metric": "crops/sec (AE fwd + PnP-RANSAC) at 128x128", "value": value, "unit": "crops/s",
@@ -397,11 +435,13 @@ def main():
         "ae_inputs_per_s": 4 * value,
         "ae_tflops_per_gpu": 4 * value * AE_GFLOP[args.backbone] / 1e3 / world,
         "gathered_records": int(len(rec)),
-        "collective": ({"backend": args.backend, "device": str(coll_dev), "async": True, "world": world} if use_dist else None),
+        "collective": ({"backend": args.backend, "device": str(coll_dev), "async": comm is None, "world": world} if use_dist else None),
+        "gather_impl": comm_note if use_dist else None,
         "host_submit_ms_per_step": host_submit_ms, "rank_cpus": (len(pinned) if pinned else None),
         "poses_ok": n_ok, "ransac_iters_mean_of_selected": float(np.mean([p.ransac_iters for p in poses])),
         "pose_err_vs_gt_median_mm_deg": [float(np.median([e[0] for e in errs])), float(np.median([e[1] for e in errs]))] if errs else None,
         "roofline": roof,
+        "roofline_hbm": hbm_rooflines(stats) if args.precision == "f16x3" else None,
     }
     # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes of this same
     # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py), committed under profiles/

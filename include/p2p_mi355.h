@@ -330,6 +330,8 @@ typedef struct {
     int64_t launches;
     double total_ms;
     double algo_flops;
+    double algo_bytes;   /* compulsory HBM bytes of the launches: the layer's input tensor(s) + residual + weights read once, its output
+                          * written once, fp32 -- what an HBM roofline of the bandwidth-leaning kernels is priced on */
 } p2p_kernel_stats;
 
 P2P_API int p2p_profile_enable(p2p_ctx* ctx, int on);

@@ -17,6 +17,8 @@ BACKBONE = {"paper": 0, "resnet50": 1}
 PRECISION = {"f32": 0, "f16x3": 1, "auto": 2}     # p2p_precision; "auto" = split-f16 with an fp32 twin it falls back to on a range event
 ERR_RANGE = -5
 MEM_HOST, MEM_DEVICE = 0, 1
+COMM_ID_BYTES = 128
+POSE_ABSENT = -1
 
 
 class P2PError(RuntimeError):
@@ -87,7 +89,7 @@ PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"
 
 
 class KernelStats(C.Structure):
-    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("algo_flops", C.c_double)]
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("algo_flops", C.c_double), ("algo_bytes", C.c_double)]
 
 
 _lib = None
@@ -208,6 +210,12 @@ def lib():
     L.p2p_est_pose_submit.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,
                                       C.POINTER(EstPoseOpts), C.POINTER(ci)]
     L.p2p_est_pose_collect.argtypes = [vp, ci, C.POINTER(Pose)]
+    L.p2p_comm_unique_id.argtypes = [C.c_char_p]
+    L.p2p_comm_create.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(vp)]
+    L.p2p_comm_destroy.argtypes = [vp]
+    L.p2p_comm_destroy.restype = None
+    L.p2p_comm_library.restype = C.c_char_p
+    L.p2p_est_pose_collect_gathered.argtypes = [vp, vp, ci, C.POINTER(Pose), ci, C.POINTER(Pose)]
     L.p2p_profile_enable.argtypes = [vp, ci]
     L.p2p_profile_read.argtypes = [vp, C.POINTER(KernelStats), ci]
     dp = C.POINTER(C.c_double)

@@ -78,7 +78,7 @@ struct Ctx {
     int range_read(int word, float* out);      // synchronous read-and-clear of a word (after the stream that wrote it is idle)
     // measurement hooks (p2p_profile_*)
     bool profiling = false;
-    struct ProfEvent { hipEvent_t a, b; int cfg; double flops; };
+    struct ProfEvent { hipEvent_t a, b; int cfg; double flops, bytes; };
     std::vector<ProfEvent> prof_pending;
     std::vector<hipEvent_t> prof_pool;
     p2p_kernel_stats prof_stats[P2P_PROFILE_SLOTS] = {};   // per kernel family (p2p_mi355.h)

@@ -560,7 +560,7 @@ struct PreparedConv {
     StreamOrder so;
     bool stream = false, halo = false, halo_conv = false, halo8 = false, halo_s2 = false;
     int cfg = 0, prof_slot = 0;
-    double flops = 0;
+    double flops = 0, bytes = 0;
 };
 
 static int prepare_conv(Ctx& X, const ConvLayer& L, const ConvCall& c, PreparedConv& pc)
@@ -666,6 +666,13 @@ static int prepare_conv(Ctx& X, const ConvLayer& L, const ConvCall& c, PreparedC
     pc.stream = stream; pc.halo = halo; pc.halo_conv = halo_conv; pc.halo8 = halo8; pc.halo_s2 = halo_s2; pc.cfg = cfg;
     pc.prof_slot = stream ? 8 : halo ? 5 : halo_conv ? (L.Cout % 128 == 0 ? 3 : 4) : halo8 ? 6 : halo_s2 ? 7 : cfg;
     pc.flops = 2.0 * (c.algo_macs >= 0 ? c.algo_macs : (double)p.M * L.Cout * L.K);
+    {   // compulsory bytes: the channels of each input segment the layer reads (once), the residual, the weight panel, the output
+        const double in_px = (double)c.N * c.Hin * c.Win / (L.ntaps == 1 ? (double)c.in_stride * c.in_stride : 1.0);      // a strided 1x1 reads every s-th pixel
+        const double in1_px = c.s1_stride ? (double)c.N * c.Hg * c.Wg : in_px;
+        const double out_el = (double)p.M * L.Cout;
+        pc.bytes = 4.0 * (in_px * c.s0.C + in1_px * c.s1.C + (c.residual ? out_el : 0.0) + (double)L.K * L.Cout +
+                          (c.mode == EPI_HEAD ? (double)p.M * 16 : out_el));
+    }
     return P2P_OK;
 }
 
@@ -683,9 +690,9 @@ static int launch_prepared(Ctx& X, const PreparedConv* pc, int n)
     auto launch = [&]() { return c0.stream ? launch_igemm_stream(p, mp, st) : c0.halo ? launch_heads_halo(p, st) : c0.halo_conv ? launch_igemm_halo(p, st) :
                                  c0.halo8 ? launch_igemm_halo8(p, st) : c0.halo_s2 ? launch_igemm_halo_s2(p, st) : launch_igemm(p, c0.cfg, st); };
     if (X.profiling) {
-        double fl = 0;
-        for (int i = 0; i < n; ++i) fl += pc[i].flops;
-        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), c0.prof_slot, fl};
+        double fl = 0, by = 0;
+        for (int i = 0; i < n; ++i) { fl += pc[i].flops; by += pc[i].bytes; }
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), c0.prof_slot, fl, by};
         if (!ev.a || !ev.b) return P2P_ERR_HIP;
         HIP_TRY(hipEventRecord(ev.a, st));
         HIP_TRY(launch());
@@ -935,6 +942,7 @@ int Ctx::prof_harvest()
         prof_stats[ev.cfg].launches += 1;
         prof_stats[ev.cfg].total_ms += ms;
         prof_stats[ev.cfg].algo_flops += ev.flops;
+        prof_stats[ev.cfg].algo_bytes += ev.bytes;
         prof_pool.push_back(ev.a);
         prof_pool.push_back(ev.b);
     }

@@ -92,6 +92,40 @@ def gather_poses(records: np.ndarray, device=None, pad_to: int | None = None) ->
     return gather_poses_async(records, device, pad_to).result()
 
 
+def create_comm(ctx):
+    """The C ABI's RCCL communicator for this rank (runtime.Comm), its 128-byte id drawn on rank 0 and handed round through the
+    torch.distributed group the launcher set up -- the only thing torch.distributed is used for on this path; the gather itself is
+    ncclAllGather inside libp2p_mi355.so (p2p_est_pose_collect_gathered), on device-resident records."""
+    import torch.distributed as dist
+    from .runtime import Comm
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return Comm(ctx, rank, world, box[0])
+
+
+def gathered_to_records(all_poses, world: int, n_max: int, ids_per_rank: int | None = None) -> np.ndarray:
+    """The world * n_max p2p_pose records p2p_est_pose_collect_gathered returns -> [n, REC] records sorted by id
+    (id = rank * ids_per_rank + position in the rank's batch), padding records dropped."""
+    from . import _lib
+    v = np.frombuffer(all_poses, dtype=_lib.POSE_DTYPE, count=world * n_max)
+    keep = v["status"] != _lib.POSE_ABSENT
+    stride = n_max if ids_per_rank is None else ids_per_rank
+    ids = (np.arange(world * n_max) // n_max) * stride + (np.arange(world * n_max) % n_max)
+    out = np.zeros((int(keep.sum()), REC), np.float64)
+    vk = v[keep]
+    out[:, 0] = ids[keep]
+    out[:, 1] = vk["status"]
+    out[:, 2] = vk["frac_inlier"]
+    out[:, 3] = vk["n_inliers"]
+    out[:, 4] = vk["n_init_mask"]
+    out[:, 5] = vk["best_slot"]
+    out[:, 6:15] = vk["R"]
+    out[:, 15:18] = vk["t"]
+    return out
+
+
 def pin_rank_to_cpus(rank: int, world: int, usable: int | None = None):
     """Give every rank of a node its own slice of the CPUs this container may use (affinity mask, capped by the cgroup quota ``usable``):
     the GPU boxes show 256 CPUs but own a quota of 16, and eight Python ranks plus their HIP runtime threads otherwise migrate over

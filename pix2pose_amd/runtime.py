@@ -34,10 +34,10 @@ class Context:
         _lib.check(_lib.lib().p2p_profile_enable(self._h, 1 if on else 0), "p2p_profile_enable")
 
     def profile_read(self, reset=True):
-        """-> list of PROFILE_SLOTS dicts (kernel families, see PROFILE_KERNELS): launches, total_ms, algo_flops."""
+        """-> list of PROFILE_SLOTS dicts (kernel families, see PROFILE_KERNELS): launches, total_ms, algo_flops, algo_bytes."""
         st = (_lib.KernelStats * _lib.PROFILE_SLOTS)()
         _lib.check(_lib.lib().p2p_profile_read(self._h, st, 1 if reset else 0), "p2p_profile_read")
-        return [{"launches": int(s.launches), "total_ms": float(s.total_ms), "algo_flops": float(s.algo_flops)} for s in st]
+        return [{"launches": int(s.launches), "total_ms": float(s.total_ms), "algo_flops": float(s.algo_flops), "algo_bytes": float(s.algo_bytes)} for s in st]
 
     def close(self):
         if self._h:
@@ -261,6 +261,43 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
     return [poses[i] for i in range(n)], extras
 
 
+class Comm:
+    """RCCL communicator of the C ABI (p2p_comm_*): one per rank, on the rank's context.  ``Comm.unique_id()`` on rank 0, the 128 bytes
+    handed to every rank by the host program, ``Comm(ctx, rank, world, id)`` on all of them (collective)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().p2p_comm_unique_id(buf), "p2p_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, ctx: Context, rank: int, world: int, uid: bytes):
+        if len(uid) != _lib.COMM_ID_BYTES:
+            raise ValueError("the communicator id has %d bytes" % _lib.COMM_ID_BYTES)
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().p2p_comm_create(ctx.handle, rank, world, uid, C.byref(self._h)), "p2p_comm_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @staticmethod
+    def library() -> str:
+        return (_lib.lib().p2p_comm_library() or b"").decode()
+
+    def close(self):
+        if self._h:
+            _lib.lib().p2p_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PendingBatch:
     """Handle of a batch enqueued with est_pose_submit (keeps the argument and output buffers alive)."""
 
@@ -275,6 +312,18 @@ class PendingBatch:
         self._keep = None
         self.pose_array = poses          # the ctypes array itself (parallel.poses_to_records takes it without a Python loop)
         return [poses[i] for i in range(self.n)]
+
+    def collect_gathered(self, comm: "Comm", n_max: int):
+        """collect() + the RCCL all-gather of every rank's records (p2p_est_pose_collect_gathered: device to device on the batch's tail
+        stream, one D2H afterwards).  Collective.  -> (this rank's poses, ctypes array of world * n_max records in rank order, each
+        rank's block in its caller's detection order, padded with status = POSE_ABSENT)."""
+        poses = (_lib.Pose * max(self.n, 1))()
+        allp = (_lib.Pose * (comm.world * n_max))()
+        _lib.check(_lib.lib().p2p_est_pose_collect_gathered(self.ctx.handle, comm.handle, self.ticket, poses, n_max, allp),
+                   "p2p_est_pose_collect_gathered")
+        self._keep = None
+        self.pose_array = poses
+        return [poses[i] for i in range(self.n)], allp
 
 
 def est_pose_submit(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,

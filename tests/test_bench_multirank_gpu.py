@@ -55,10 +55,13 @@ def test_bench_two_ranks_host_time_and_pinning():
         (out["host_submit_ms_per_step"], out["ms_per_step"])
 
 
-def test_bench_rccl_path_with_one_rank():
+@pytest.mark.parametrize("impl", ["cabi", "torch"])
+def test_bench_rccl_path_with_one_rank(impl):
     """The RCCL branch on the single GPU a test box has: `--backend nccl --collective` under the launcher with WORLD_SIZE=1 goes through
-    init_process_group("nccl", device_id=...), the barrier, the device-side asynchronous all_gather_into_tensor of float64 pose records
-    and the all-reduce(MAX) of the step time -- everything the 8-GPU run does except talking to a second GPU."""
+    init_process_group("nccl", device_id=...), the barrier, the pose gather and the all-reduce(MAX) of the step time -- everything the
+    8-GPU run does except talking to a second GPU.  "cabi" (the default): the library's own communicator (p2p_comm_create with the id
+    handed round by torch.distributed, p2p_est_pose_collect_gathered = ncclAllGather on the device-resident records); "torch"
+    (--torch-gather): all_gather_into_tensor of float64 records."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["MASTER_ADDR"] = "127.0.0.1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -68,11 +71,12 @@ def test_bench_rccl_path_with_one_rank():
         port = str(so.getsockname()[1])
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--collective",
-                        "--steps", "3", "--warmup", "1", "--no-legs"],
+                        "--steps", "3", "--warmup", "1", "--no-legs"] + (["--torch-gather"] if impl == "torch" else []),
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["collective"] == {"backend": "nccl", "device": "cuda:0", "async": True, "world": 1}
+    assert out["collective"] == {"backend": "nccl", "device": "cuda:0", "async": impl == "torch", "world": 1}
+    assert (out["gather_impl"] or "").startswith("C ABI ncclAllGather" if impl == "cabi" else "") and (impl == "cabi") == ("librccl" in (out["gather_impl"] or ""))
     assert out["n_gpus"] == 1 and out["gathered_records"] == 256 and out["poses_ok"] >= 250

@@ -1,0 +1,60 @@
+"""RCCL gather of the C ABI (include/p2p_mi355.h: p2p_comm_*, p2p_est_pose_collect_gathered; SURVEY.md section 8e -- no reference call
+site) on the one GPU a test box has: a one-rank communicator goes through ncclGetUniqueId, ncclCommInitRank, the device-side packing of
+the records into the caller's order, ncclAllGather on the tail stream and the single D2H -- everything but a second GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pix2pose_amd import synthetic as S
+from pix2pose_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _key(p):
+    return (p.status, p.n_inliers, p.n_init_mask, p.best_slot, tuple(p.bbox_t), tuple(p.R), tuple(p.t), p.frac_inlier)
+
+
+def test_collect_gathered_equals_collect_in_caller_order():
+    import torch
+    from pix2pose_amd import _lib
+    from pix2pose_amd.parallel import gathered_to_records, poses_to_records
+    from pix2pose_amd.runtime import Comm, Context, Generator, ObjectSpec, est_pose_submit
+    ctx = Context(0, max_batch=64)
+    specs = [ObjectSpec(Generator(W.synthetic_weights("paper", 1 + k), "paper", ctx), S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2) for k in range(3)]
+    sc = S.make_scene(10, seed=31)
+    dets = [(d[0], (7 * i) % 3, d[2], d[3]) for i, d in enumerate(sc["dets"])]        # objects interleaved: the batch is processed in sorted order
+    j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
+    torch.cuda.synchronize()
+    kw = dict(inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3)
+    want = est_pose_submit(ctx, specs, list(sc["images"]), dets, **kw).collect()
+    comm = Comm(ctx, 0, 1, Comm.unique_id())
+    assert "librccl" in Comm.library()
+    n_max = 16
+    for _ in range(2):                                                                # twice: the communicator and its buffers are reused
+        own, allp = est_pose_submit(ctx, specs, list(sc["images"]), dets, **kw).collect_gathered(comm, n_max)
+        assert [_key(p) for p in own] == [_key(p) for p in want]
+        assert [_key(allp[i]) for i in range(10)] == [_key(p) for p in want]          # caller order, bit for bit
+        assert all(allp[i].status == _lib.POSE_ABSENT for i in range(10, n_max))      # padding
+        rec = gathered_to_records(allp, 1, n_max)
+        assert np.array_equal(rec, poses_to_records(want))
+    # a batch larger than n_max is refused, not truncated
+    pend = est_pose_submit(ctx, specs, list(sc["images"]), dets, **kw)
+    with pytest.raises(_lib.P2PError):
+        pend.collect_gathered(comm, 4)
+    assert [_key(p) for p in pend.collect()] == [_key(p) for p in want]
+    comm.close()
+
+
+def test_comm_argument_validation():
+    from pix2pose_amd import _lib
+    from pix2pose_amd.runtime import Comm, Context
+    ctx = Context(0, max_batch=8)
+    with pytest.raises(ValueError):
+        Comm(ctx, 0, 1, b"short")
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.p2p_comm_create(ctx.handle, 2, 2, b"\0" * 128, C.byref(h)) == -1        # rank out of range
+    assert L.p2p_comm_create(None, 0, 1, b"\0" * 128, C.byref(h)) == -1
+    assert L.p2p_comm_unique_id(None) == -1
