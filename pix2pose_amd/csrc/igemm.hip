@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
     float amax = 0.f;      // operand-range guard (kernels.h)
 #pragma unroll 1
     for (int h = 0; h < WGM; ++h) {
+#ifndef P2P_ABL_CS      // (ablation builds: what the transpose through LDS costs the HBM-bound 1x1 layers)
         if (wm == h) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
                         Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
         }
         __syncthreads();
+#endif
         if (cok) {
             constexpr int NIT = PROWS / RPP;
             if (p.ksplit > 1) {
@@ -336,7 +338,12 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
                     ops[it] = row_out[h * PROWS + r0 + it * RPP];
                     rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (p.residual) {
+#ifndef P2P_ABL_RES
+                if (p.residual)
+#else
+                if (false)
+#endif
+                {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it)
                         if (ops[it] >= 0) rs[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ops[it] * p.res_cstride + col);
@@ -371,7 +378,9 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
                 }
             }
         }
+#ifndef P2P_ABL_CS
         if (h + 1 < WGM) __syncthreads();
+#endif
     }
     range_commit(p.range_acc, amax);
 }

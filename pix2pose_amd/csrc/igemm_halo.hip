@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
         int ntap = tap + 1, nchunk = chunk;
         if (ntap == p.ntaps) { ntap = 0; ++nchunk; }
         const bool more = ks + 1 < total;
+#ifndef P2P_ABL_B
         if (more) bload(ntap, nchunk);
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f16x8 ah[2], al[2], bh[TN], bl[TN];
@@ -227,12 +229,22 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+#ifndef P2P_ABL_BAR
         __syncthreads();                  // everyone is done reading the weight tile (and, at a slice end, the halo)
+#endif
         if (more) {
+#ifndef P2P_ABL_B
             bstore();
+#endif
+#ifndef P2P_ABL_HSTORE
             if (nchunk != chunk) hstore();                       // next slice's halo (prefetched at the start of this one)
+#endif
+#ifndef P2P_ABL_BAR
             __syncthreads();
+#endif
+#ifndef P2P_ABL_HLOAD
             if (nchunk != chunk && nchunk + 1 < n_chunks) hload(nchunk + 1);
+#endif
         }
         tap = ntap; chunk = nchunk;
     }

@@ -793,6 +793,10 @@ static int res_block(const Model& M, Ctx& X, const std::string& n, const float* 
     return conv_layer(X, M.L.at(n + "_2c"), tb, N, Ho, Ho, f1, 1, out, ACT_RELU, res);
 }
 
+#ifdef P2P_DEV_SWITCHES      // A/B builds only (tools/ab_build.sh model.hip -DP2P_DEV_SWITCHES): timing experiments, results are garbage
+#define dev_part() (X.dev_part)      // per context, from P2P_DEV_PART at p2p_ctx_create: 1 = ResNet front only, 2 = everything after it only
+#endif
+
 // x_dev [n,128,128,3] -> xyzp_dev [n,128,128,4]; n <= ctx.max_batch
 int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
 {
@@ -805,6 +809,9 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
     const float *s1, *s2, *s3;      // skip tensors and their pixel strides / channel offsets
     int s1_stride, s1_off, s1_C, s2_stride, s2_off, s3_stride, s3_off;
     if (M.backbone == P2P_BACKBONE_RESNET50) {
+#ifdef P2P_DEV_SWITCHES
+        if (dev_part() == 2) goto after_front;
+#endif
         if (M.L.at("conv1").prec == PREC_F16X3) {       // matrix-core first layer: one launch, per-sample panel lookup
             if (n_grp > IGEMM_MAX_GROUPS) { set_error("forward: %d object groups exceed IGEMM_MAX_GROUPS", n_grp); return P2P_ERR_CAPACITY; }
             Conv1Groups G;
@@ -831,6 +838,10 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         if ((rc = res_block(M, X, "res3b", A["o_a"], n, 16, 512, 128, 1, false, A["o_b"]))) return rc;
         if ((rc = res_block(M, X, "res3c", A["o_b"], n, 16, 512, 128, 1, false, A["o_a"]))) return rc;
         if ((rc = res_block(M, X, "res3d", A["o_a"], n, 16, 512, 128, 1, false, A["f3"]))) return rc;
+#ifdef P2P_DEV_SWITCHES
+        if (dev_part() == 1) return P2P_OK;
+    after_front:
+#endif
         if ((rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 512, 2, A["f4"], ACT_LEAKY))) return rc;
         // ae_model.py:186-188: f1[..., :32], f2[..., :128], f3[..., :128]
         s1 = A["f1"]; s1_stride = 64; s1_off = 0; s1_C = 32;
@@ -1053,7 +1064,18 @@ int p2p_ctx_create(int device, int max_batch, p2p_ctx** out)
     Ctx* c = new Ctx();
     c->device = device;
     c->max_batch = max_batch;
-    hipError_t e = hipStreamCreate(&c->stream);
+    hipError_t e;
+#ifdef P2P_DEV_SWITCHES
+    c->dev_part = getenv("P2P_DEV_PART") ? atoi(getenv("P2P_DEV_PART")) : 0;
+    if (const char* cus = getenv("P2P_DEV_CUS")) {      // "lo:hi": the context's stream may only use CUs [lo, hi) (mask bits; KFD deals them round-robin over the XCDs)
+        int lo = 0, hi = 256;
+        sscanf(cus, "%d:%d", &lo, &hi);
+        uint32_t mask[8] = {0};
+        for (int i = lo; i < hi && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+        e = hipExtStreamCreateWithCUMask(&c->stream, 8, mask);
+    } else
+#endif
+    e = hipStreamCreate(&c->stream);
     if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); delete c; return P2P_ERR_HIP; }
     if ((e = hipMalloc((void**)&c->range_words, 8 * sizeof(unsigned))) != hipSuccess || (e = hipMemset(c->range_words, 0, 8 * sizeof(unsigned))) != hipSuccess) {
         set_error("p2p_ctx_create: %s", hipGetErrorString(e));

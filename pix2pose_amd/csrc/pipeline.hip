@@ -140,6 +140,9 @@ struct Tap {
 
 __device__ inline Tap axis_tap(int o, int n_in, int n_out)
 {
+    // identity resize (every resize of a 128-px crop): src = o * 1.0 + (0.5 - 0.5) = o exactly -- the same taps and weight without the
+    // fp64 division (a quarter of stage2_input_kernel's time at BASELINE.json configs[2])
+    if (n_in == n_out) { Tap t; t.i0 = t.i1 = o; t.d = 0.0; return t; }
     const double s = (double)n_in / (double)n_out;
     const double src = (double)o * s + (0.5 * s - 0.5);
     const double lo = floor(src);
@@ -489,6 +492,7 @@ struct TapF {
 
 __device__ inline TapF axis_tap_f32(int o, int n_in, int n_out)
 {
+    if (n_in == n_out) { TapF t; t.i0 = t.i1 = o; t.d = 0.f; return t; }      // ms = 1, mt = 0: src = (float)o exactly
     const double s = (double)n_in / (double)n_out;
     const float ms = (float)s, mt = (float)(s * 0.5 - 0.5);
     const float src = ms * (float)o + mt;            // contraction is off in this file
