@@ -22,7 +22,7 @@ struct DetInfo {
     int obj;
     int n_th;
     float th_o[MAX_TH];     // prob < th_o is evaluated in float32 (prob is a float32 array)
-    double th_i;            // img_prob_ori < th_i is evaluated in float64
+    double th_i;            // img_prob_ori < th_i: in float64 for scikit-image <= 0.14 (a float64 array), in float32 for 0.17 / 0.18 (the array stays float32)
     double box_size;
     double cx_o, cy_o;      // (bbox[3]+bbox[1])/2, (bbox[2]+bbox[0])/2   recognition.py:72-73
     double K[9];
@@ -31,7 +31,7 @@ struct DetInfo {
     int ok1;                // 0 => recognition.py:78-79 early return
     long long corr_off;     // float offset of this detection's correspondence storage
     int corr_cap;           // points per candidate (stage-1 side squared)
-    int aa;                 // anti-aliased resizes (scikit-image 0.17 - 0.18 default), p2p_est_pose_opts.resize_anti_aliasing
+    int aa;                 // scikit-image generation (p2p_est_pose_opts.resize_anti_aliasing): 1 = 0.17 / 0.18 -- anti-aliased resizes AND float32 images warped in float32
     long long cv_off;       // double offset of this detection's (1 + K) canvases of corr_cap * 3 doubles each (aa, side > 128)
     int src_index;          // index of this detection in the caller's array (detections are processed sorted by object)
 };

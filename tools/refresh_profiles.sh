@@ -10,7 +10,7 @@ R=${1:-r04}
 PROF="--steps 3 --warmup 1 --blocking --no-legs"
 PMC="--steps 1 --warmup 1 --blocking --no-legs"
 /usr/local/graft/bin/gpurun --timeout 2400 -- '
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/gpu_tests.log
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/gpu_tests.log
 cd /tmp && export TMPDIR=/tmp
 G=$GRAFT_REPO_ROOT/gpurun_out
 B=$GRAFT_REPO_ROOT/bench.py
