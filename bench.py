@@ -262,6 +262,12 @@ def main():
             comm_note = "C ABI ncclAllGather (%s)" % _Comm.library()
         except Exception as e:      # noqa: BLE001 -- an RCCL that cannot be bound: the torch path still works
             comm, comm_note = None, "torch.distributed (C ABI communicator unavailable: %s)" % (e,)
+        # the choice must be the same on every rank (a rank gathering through torch while the others sit in ncclAllGather would hang)
+        agree = torch.tensor([1 if comm is not None else 0], device=coll_dev, dtype=torch.int32)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0 and comm is not None:
+            comm.close()
+            comm, comm_note = None, "torch.distributed (another rank could not create the C ABI communicator)"
     submit_s = []           # host seconds inside every est_pose_submit call (marshalling + enqueueing one batch)
     gather_q = []           # all-gathers in flight: started when a step is collected, waited for one step later
 

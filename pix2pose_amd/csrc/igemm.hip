@@ -346,7 +346,11 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
                 {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it)
+#ifdef P2P_NT_LOAD
+                        if (ops[it] >= 0) rs[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.residual + (size_t)ops[it] * p.res_cstride + col));
+#else
                         if (ops[it] >= 0) rs[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)ops[it] * p.res_cstride + col);
+#endif
                 }
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -373,7 +377,11 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
                         }
                         amax = range_note4(amax, v);
+#ifdef P2P_NT_STORE
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col));
+#else
                         *reinterpret_cast<f32x4*>(p.out + (size_t)op * p.out_cstride + p.out_coff + col) = v;
+#endif
                     }
                 }
             }
