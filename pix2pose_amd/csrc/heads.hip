@@ -170,43 +170,54 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
             if (step + 1 < HEADS_TILES) gload(chunk, gy_first + 1 + 4 * (step + 1), 4);      // flies under this step's MFMAs
             else if (chunk + 1 < HEADS_CHUNKS) gload(chunk + 1, gy_first - 1, 2);
             __syncthreads();
-            const int gy = gy_first + 4 * step + wave;                        // this wave's grid row
-            // ring slots of rows gy - 1, gy, gy + 1
-            const int rs0 = (gy - 1 + HEADS_RING) % HEADS_RING, rs1 = gy % HEADS_RING, rs2 = (gy + 1) % HEADS_RING;
-            const char* xr[3] = {xs + rs0 * (HEADS_WP * 16), xs + rs1 * (HEADS_WP * 16), xs + rs2 * (HEADS_WP * 16)};
+            // This WAVE owns the 16-pixel column block `wave` of the step's four grid rows (not one full row): an input fragment
+            // (ring row, dx) then serves up to three output rows (dy = -1, 0, 1) out of one LDS read.  Loop nest (dx; input row; output
+            // row): per dx the three taps' weight fragments (6 reads) stay in registers while the six ring rows go by (12 reads):
+            // 54 ds_read_b128 per 108 MFMAs instead of 90 -- the kernel was bound by its LDS reads.  An output pixel's chain of MFMAs
+            // is now ordered (slice; dx; dy) with (wl xh, wh xl, wh xh) inside -- the same for every launch shape of this kernel.
+            const int gy0 = gy_first + 4 * step;                               // first grid row of the step
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dx = t % 3 - 1;
-                const char* xt = xr[t / 3] + dx * 16;
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(wsm + t * 256);
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(wsm + t * 256 + 4 * HEADS_WPLANE);
+            for (int dx = -1; dx <= 1; ++dx) {
+                f16x8 wh[3], wl[3];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(xt + m * 256);
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(xt + m * 256 + HEADS_LO);
-                    acc[step][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[step][m], 0, 0, 0);
-                    acc[step][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[step][m], 0, 0, 0);
-                    acc[step][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[step][m], 0, 0, 0);
+                for (int dy = 0; dy < 3; ++dy) {
+                    wh[dy] = *reinterpret_cast<const f16x8*>(wsm + (dy * 3 + dx + 1) * 256);
+                    wl[dy] = *reinterpret_cast<const f16x8*>(wsm + (dy * 3 + dx + 1) * 256 + 4 * HEADS_WPLANE);
+                }
+#pragma unroll
+                for (int rr = 0; rr < HEADS_RING; ++rr) {                      // input rows gy0 - 1 .. gy0 + 4
+                    const int slot = (gy0 - 1 + rr + HEADS_RING) % HEADS_RING;
+                    const char* xrow = xs + slot * (HEADS_WP * 16) + wave * 256 + dx * 16;
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + HEADS_LO);
+#pragma unroll
+                    for (int o = 0; o < HEADS_TH; ++o) {                       // output row gy0 + o reads input row gy0 + o + dy
+                        const int dy = rr - 1 - o;
+                        if (dy < -1 || dy > 1) continue;
+                        acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[dy + 1], xh, acc[step][o], 0, 0, 0);
+                        acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[dy + 1], xl, acc[step][o], 0, 0, 0);
+                        acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[dy + 1], xh, acc[step][o], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 
-    // epilogue.  lane: outputs 4 lg .. 4 lg + 3 = (x, y, z, prob) of phase lg for grid pixel (gy, 16 m + li)
+    // epilogue.  lane: outputs 4 lg .. 4 lg + 3 = (x, y, z, prob) of phase lg for grid pixel (gy_first + 4 step + o, 16 wave + li)
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + lg * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + lg * 4);
 #pragma unroll
     for (int step = 0; step < HEADS_TILES; ++step) {
-        const int oy = 2 * (gy_first + step * HEADS_TH + wave) + (lg >> 1);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int ox = 2 * (16 * m + li) + (lg & 1);
-            f32x4 v = acc[step][m], o;
+        for (int o = 0; o < HEADS_TH; ++o) {
+            const int oy = 2 * (gy_first + step * HEADS_TH + o) + (lg >> 1);
+            const int ox = 2 * (16 * wave + li) + (lg & 1);
+            f32x4 v = acc[step][o], q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-            o[0] = tanhf(v[0]); o[1] = tanhf(v[1]); o[2] = tanhf(v[2]);
-            o[3] = 1.f / (1.f + __expf(-v[3]));
-            *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Hout + oy) * p.Wout + ox) * 4) = o;
+            q[0] = tanhf(v[0]); q[1] = tanhf(v[1]); q[2] = tanhf(v[2]);
+            q[3] = 1.f / (1.f + __expf(-v[3]));
+            *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Hout + oy) * p.Wout + ox) * 4) = q;
         }
     }
 }
