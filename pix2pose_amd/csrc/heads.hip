@@ -14,6 +14,7 @@
 // ends up with (x, y, z, prob) of one output pixel and stores a float4.  PREC_F32 models keep the
 // generic kernel.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace p2p {
 
@@ -96,9 +97,10 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
     // A step brings in 4 new rows; the first step of a slice 6 (two extra passes over rows -1, 0 handled as a half step).
     const int lq = tid & 7;                                  // quad: k-chunk lq >> 1, 8-byte half lq & 1
     const int l_dst = heads_plane(lq >> 1) + (lq & 1) * 8;   // + (ring_row * 66 + x + 1) * 16
-    f32x4 rx[HEADS_LOADS];
+    constexpr int SETS = HEADS_TILES == 2 ? 2 : 1;          // HEADS_TILES == 2: fetches run TWO stages ahead (two register sets)
+    f32x4 rx[SETS][HEADS_LOADS];
     // rows row0 .. row0 + nrows - 1 of the sample (nrows <= 4) into registers
-    auto gload = [&](int chunk, int row0, int nrows) {
+    auto gload = [&](int chunk, int row0, int nrows, int set = 0) {
 #pragma unroll
         for (int j = 0; j < HEADS_LOADS; ++j) {
             const int pix = (tid + 256 * j) >> 3;
@@ -106,10 +108,10 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
             const int gy = row0 + r;
             const unsigned off = (r < nrows && gy >= 0 && gy < p.Hg)
                 ? (unsigned)(((((long long)n * p.Hg + gy) * HEADS_W + x) * HEADS_CIN + lq * 4) * 4) : 0xFFFFFFF0u;
-            rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, chunk * 128, 0));
+            rx[set][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, chunk * 128, 0));
         }
     };
-    auto lstore = [&](int row0, int nrows) {
+    auto lstore = [&](int row0, int nrows, int set = 0) {
 #pragma unroll
         for (int j = 0; j < HEADS_LOADS; ++j) {
             const int pix = (tid + 256 * j) >> 3;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
             if (r >= nrows) continue;
             const int ring = (row0 + r + HEADS_RING) % HEADS_RING;          // row -1 -> slot 5
             char* dst = smem + l_dst + (ring * HEADS_WP + x + 1) * 16;
-            const f32x4 v = rx[j];
+            const f32x4 v = rx[set][j];
             const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
             fp16x2 l01, l23;
             l01[0] = (__fp16)(v[0] - (float)h01[0]); l01[1] = (__fp16)(v[1] - (float)h01[1]);
@@ -142,11 +144,7 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
     // (18 rows fetched per 16 rows of output instead of 24); the four steps' accumulators stay in registers across the
     // slices.  Per slice: a 2-row preamble (rows gy_first - 1, gy_first), then four 4-row fetches (rows gy_first + 1 + 4 s ..);
     // the next fetch is in flight while a step computes.
-    gload(0, gy_first - 1, 2);
-#pragma unroll 1
-    for (int chunk = 0; chunk < HEADS_CHUNKS; ++chunk) {
-        // weight fragments of this slice: 9 taps x 16 rows x 128 B ([hi x32 | lo x32]; the panel's K order is (tap, cin))
-        f32x4 wq[5];
+    auto load_weights = [&](int chunk, f32x4* wq) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int i = tid + 256 * j;                      // 16-byte piece: tap i / 128, row (i % 128) / 8, piece i % 8
@@ -154,13 +152,95 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
             const unsigned off = i < 9 * 128 ? (unsigned)(row * p.K * 4 + (t * HEADS_CHUNKS + chunk) * 128 + c8 * 16) : 0xFFFFFFF0u;
             wq[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
         }
-        __syncthreads();                          // every wave is done with the previous slice's last step
+    };
+    auto store_weights = [&](const f32x4* wq) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int i = tid + 256 * j;
             const int t = i >> 7, row = (i >> 3) & 15, c8 = i & 7;
             if (i < 9 * 128) *reinterpret_cast<f32x4*>(smem + HEADS_XBYTES + c8 * HEADS_WPLANE + (t * 16 + row) * 16) = wq[j];
         }
+    };
+    auto compute = [&](int step) {
+            // This WAVE owns the 16-pixel column block `wave` of the step's four grid rows (not one full row): an input fragment
+        // (ring row, dx) then serves up to three output rows (dy = -1, 0, 1) out of one LDS read.  Loop nest (dx; input row; output
+        // row): per dx the three taps' weight fragments (6 reads) stay in registers while the six ring rows go by (12 reads):
+        // 54 ds_read_b128 per 108 MFMAs instead of 90 -- the kernel was bound by its LDS reads.  An output pixel's chain of MFMAs
+        // is now ordered (slice; dx; dy) with (wl xh, wh xl, wh xh) inside -- the same for every launch shape of this kernel.
+        const int gy0 = gy_first + 4 * step;                               // first grid row of the step
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            f16x8 wh[3], wl[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                wh[dy] = *reinterpret_cast<const f16x8*>(wsm + (dy * 3 + dx + 1) * 256);
+                wl[dy] = *reinterpret_cast<const f16x8*>(wsm + (dy * 3 + dx + 1) * 256 + 4 * HEADS_WPLANE);
+            }
+#pragma unroll
+            for (int rr = 0; rr < HEADS_RING; ++rr) {                      // input rows gy0 - 1 .. gy0 + 4
+                const int slot = (gy0 - 1 + rr + HEADS_RING) % HEADS_RING;
+                const char* xrow = xs + slot * (HEADS_WP * 16) + wave * 256 + dx * 16;
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + HEADS_LO);
+#pragma unroll
+                for (int o = 0; o < HEADS_TH; ++o) {                       // output row gy0 + o reads input row gy0 + o + dy
+                    const int dy = rr - 1 - o;
+                    if (dy < -1 || dy > 1) continue;
+                    acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[dy + 1], xh, acc[step][o], 0, 0, 0);
+                    acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[dy + 1], xl, acc[step][o], 0, 0, 0);
+                    acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[dy + 1], xh, acc[step][o], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if constexpr (HEADS_TILES == 2) {
+        // TWO-AHEAD schedule (large launches): the kernel is latency-bound on its input stream -- a step's compute (~1 us) is shorter than
+        // the fetch it hides --, so the fetch of stage k + 2 is issued when stage k's registers are free: twice the bytes in flight per
+        // workgroup.  Stages per slice: preamble (rows gy_first - 1, gy_first), step 0 (4 rows), step 1 (4 rows); 4 slices = 12 stages,
+        // register set k & 1.  The workgroup owns 8 rows (10 fetched per 8).
+        auto rows_of = [&](int k, int* row0, int* nrows) {
+            const int j = k % 3;
+            *row0 = j == 0 ? gy_first - 1 : gy_first + 1 + 4 * (j - 1);
+            *nrows = j == 0 ? 2 : 4;
+        };
+        auto fetch = [&](int k) {
+            if (k >= 3 * HEADS_CHUNKS) return;
+            int row0, nrows;
+            rows_of(k, &row0, &nrows);
+            gload(k / 3, row0, nrows, k & 1);
+        };
+        fetch(0);
+        fetch(1);
+#pragma unroll
+        for (int k = 0; k < 3 * HEADS_CHUNKS; ++k) {
+            const int j = k % 3;
+            int row0, nrows;
+            rows_of(k, &row0, &nrows);
+            if (j == 0) {
+                f32x4 wq[5];
+                load_weights(k / 3, wq);
+                __syncthreads();                      // every wave is done with the previous slice's last step
+                store_weights(wq);
+                lstore(row0, nrows, k & 1);
+                fetch(k + 2);
+            } else {
+                if (j == 2) __syncthreads();          // every wave is done reading the rows this store replaces
+                lstore(row0, nrows, k & 1);
+                fetch(k + 2);
+                __syncthreads();
+                compute(j - 1);
+            }
+        }
+    } else {
+    gload(0, gy_first - 1, 2);
+#pragma unroll 1
+    for (int chunk = 0; chunk < HEADS_CHUNKS; ++chunk) {
+        // weight fragments of this slice: 9 taps x 16 rows x 128 B ([hi x32 | lo x32]; the panel's K order is (tap, cin))
+        f32x4 wq[5];
+        load_weights(chunk, wq);
+        __syncthreads();                          // every wave is done with the previous slice's last step
+        store_weights(wq);
         lstore(gy_first - 1, 2);
         gload(chunk, gy_first + 1, 4);
 #pragma unroll
@@ -170,37 +250,9 @@ __global__ __launch_bounds__(256, 2) void heads_halo_kernel(const IgemmParams p)
             if (step + 1 < HEADS_TILES) gload(chunk, gy_first + 1 + 4 * (step + 1), 4);      // flies under this step's MFMAs
             else if (chunk + 1 < HEADS_CHUNKS) gload(chunk + 1, gy_first - 1, 2);
             __syncthreads();
-            // This WAVE owns the 16-pixel column block `wave` of the step's four grid rows (not one full row): an input fragment
-            // (ring row, dx) then serves up to three output rows (dy = -1, 0, 1) out of one LDS read.  Loop nest (dx; input row; output
-            // row): per dx the three taps' weight fragments (6 reads) stay in registers while the six ring rows go by (12 reads):
-            // 54 ds_read_b128 per 108 MFMAs instead of 90 -- the kernel was bound by its LDS reads.  An output pixel's chain of MFMAs
-            // is now ordered (slice; dx; dy) with (wl xh, wh xl, wh xh) inside -- the same for every launch shape of this kernel.
-            const int gy0 = gy_first + 4 * step;                               // first grid row of the step
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                f16x8 wh[3], wl[3];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    wh[dy] = *reinterpret_cast<const f16x8*>(wsm + (dy * 3 + dx + 1) * 256);
-                    wl[dy] = *reinterpret_cast<const f16x8*>(wsm + (dy * 3 + dx + 1) * 256 + 4 * HEADS_WPLANE);
-                }
-#pragma unroll
-                for (int rr = 0; rr < HEADS_RING; ++rr) {                      // input rows gy0 - 1 .. gy0 + 4
-                    const int slot = (gy0 - 1 + rr + HEADS_RING) % HEADS_RING;
-                    const char* xrow = xs + slot * (HEADS_WP * 16) + wave * 256 + dx * 16;
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow);
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + HEADS_LO);
-#pragma unroll
-                    for (int o = 0; o < HEADS_TH; ++o) {                       // output row gy0 + o reads input row gy0 + o + dy
-                        const int dy = rr - 1 - o;
-                        if (dy < -1 || dy > 1) continue;
-                        acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[dy + 1], xh, acc[step][o], 0, 0, 0);
-                        acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[dy + 1], xl, acc[step][o], 0, 0, 0);
-                        acc[step][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[dy + 1], xh, acc[step][o], 0, 0, 0);
-                    }
-                }
-            }
+            compute(step);
         }
+    }
     }
 
     // epilogue.  lane: outputs 4 lg .. 4 lg + 3 = (x, y, z, prob) of phase lg for grid pixel (gy_first + 4 step + o, 16 wave + li)
@@ -239,8 +291,12 @@ hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s)
     const bool small = p.N * (p.Hg / (HEADS_TH * HEADS_TILES_BIG)) < 64;
     const int n_wgs = p.N * (p.Hg / (HEADS_TH * (small ? 1 : HEADS_TILES_BIG)));
     const int per_xcd = (n_wgs + 7) / 8;
+    static const bool two_ahead = getenv("P2P_HEADS_TWO_AHEAD") != nullptr && atoi(getenv("P2P_HEADS_TWO_AHEAD")) != 0;      // development switch (A/B; same bits)
     if (small) hipLaunchKernelGGL(heads_halo_kernel<1>, dim3(per_xcd * 8), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(heads_halo_kernel<HEADS_TILES_BIG>, dim3(per_xcd * 8), dim3(256), 0, s, p);
+    else if (two_ahead && p.Hg % (HEADS_TH * 2) == 0) {
+        const int n2 = p.N * (p.Hg / (HEADS_TH * 2));
+        hipLaunchKernelGGL(heads_halo_kernel<2>, dim3((n2 + 7) / 8 * 8), dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL(heads_halo_kernel<HEADS_TILES_BIG>, dim3(per_xcd * 8), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
