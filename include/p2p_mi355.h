@@ -101,7 +101,9 @@ P2P_API int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tens
  *   p2p_forward_async cannot report -- ask p2p_ctx_range_event() after synchronising.
  * P2P_PREC_AUTO: split-f16 with a strict-fp32 twin of the same weights kept beside it (+ the model's size in HBM).  On a range event the
  * object switches to the twin for good: p2p_predict and p2p_est_pose_batch repeat the work in fp32 themselves and return P2P_OK;
- * p2p_est_pose_collect returns P2P_ERR_RANGE once and the re-submitted batch runs in fp32.  p2p_model_precision() tells which
+ * p2p_est_pose_collect returns P2P_ERR_RANGE once and the re-submitted batch runs in fp32.  The flag is per batch, not per object: in a
+ * mixed batch every P2P_PREC_AUTO object switches, objects without a twin keep their arithmetic (if one of THOSE overflowed, the repeated
+ * batch reports P2P_ERR_RANGE again).  p2p_model_precision() tells which
  * arithmetic an object currently uses.  p2p_model_create uses P2P_PREC_DEFAULT. */
 typedef enum { P2P_PREC_F32 = 0, P2P_PREC_F16X3 = 1, P2P_PREC_AUTO = 2 } p2p_precision;
 #define P2P_PREC_DEFAULT P2P_PREC_F16X3

@@ -1119,22 +1119,25 @@ __global__ void aa_back_range_kernel(CandRange* __restrict__ crange, int n_cand,
 
 // Hand a finished batch over to the caller: sorted order -> caller order, pinned landing buffers -> the caller's
 // (pageable) output arrays named in the options of the submit / blocking call.
-// -> 0, or P2P_ERR_RANGE when a generator pass of the batch stored an activation beyond the split-f16 operand range: objects created with
-// P2P_PREC_AUTO switch to their fp32 twin (all_have_twin tells the blocking caller that running the batch again will succeed)
-static int range_verdict(const Slot& s, bool* all_have_twin)
+// -> 0, or P2P_ERR_RANGE when a generator pass of the batch stored an activation beyond the split-f16 operand range.  The flag is per batch,
+// not per object: every split-f16 object of the batch that was created with P2P_PREC_AUTO switches to its fp32 twin (*switched = how many did);
+// the blocking caller then runs the batch once more -- if the offender was one of them the second run is clean, otherwise it reports again
+static int range_verdict(const Slot& s, int* switched)
 {
-    *all_have_twin = false;
+    *switched = 0;
     float amax = 0.f;
     if (s.h_range.p) memcpy(&amax, s.h_range.p, sizeof(amax));
     if (!(amax > 0.f)) return P2P_OK;
-    bool all = true;
+    int n_f16 = 0;
     for (const BatchGroup& g : s.groups) {
         const Model* m = reinterpret_cast<const Model*>(s.objs[g.obj].model);
-        if (m->twin) m->use_twin = true; else all = false;
+        if (m->effective()->prec != PREC_F16X3) continue;
+        ++n_f16;
+        if (m->twin) { m->use_twin = true; ++*switched; }
     }
-    *all_have_twin = all;
-    set_error("est_pose: an activation of magnitude %g exceeds the split-f16 operand range (%g)%s", (double)amax, (double)RANGE_LIMIT,
-              all ? "; the batch's objects (P2P_PREC_AUTO) now run in fp32" : ": create the model with P2P_PREC_F32 or P2P_PREC_AUTO");
+    set_error("est_pose: an activation of magnitude %g exceeds the split-f16 operand range (%g); %d of the batch's %d split-f16 objects switched to their "
+              "fp32 twin (P2P_PREC_AUTO)%s", (double)amax, (double)RANGE_LIMIT, *switched, n_f16,
+              *switched < n_f16 ? "; objects without one need P2P_PREC_F32 or P2P_PREC_AUTO at creation" : "");
     return P2P_ERR_RANGE;
 }
 
@@ -1677,11 +1680,11 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     HIP_TRY(hipStreamSynchronize(st));
     finish_batch(SL, poses);
     {
-        bool twins = false;
-        if ((rc = range_verdict(SL, &twins))) {
+        int switched = 0;
+        if ((rc = range_verdict(SL, &switched))) {
             static thread_local int depth = 0;
-            if (!twins || depth > 0) return rc;
-            ++depth;                               // every object of the batch has an fp32 twin (P2P_PREC_AUTO) and now uses it: once more
+            if (!switched || depth > 0) return rc;
+            ++depth;                               // objects with an fp32 twin (P2P_PREC_AUTO) now use it: once more (a second event = an object without one)
             rc = run_est_pose(X, objects, n_obj, images, n_img, dets, n, poses, opt, nullptr);
             --depth;
             return rc;
@@ -1722,8 +1725,8 @@ static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses, Comm* comm = nu
             HIP_TRY(hipEventSynchronize(s.done));
             finish_batch(s, poses);
             s.ticket = -1;
-            bool twins = false;
-            return range_verdict(s, &twins);       // P2P_ERR_RANGE: the poses are not to be used; with P2P_PREC_AUTO objects a re-submission runs in fp32
+            int switched = 0;
+            return range_verdict(s, &switched);       // P2P_ERR_RANGE: the poses are not to be used; with P2P_PREC_AUTO objects a re-submission runs in fp32
         }
     set_error("ticket %d is not in flight", ticket);
     return P2P_ERR_INVALID_ARG;

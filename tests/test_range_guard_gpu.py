@@ -85,3 +85,24 @@ def test_est_pose_guard_blocking_and_async():
     assert gb.active_precision == "f32"
     again = est_pose_submit(ctx, [spec_b], imgs, sc["dets"]).collect()
     assert [key(p) for p in again] == [key(p) for p in want]
+
+
+def test_mixed_batch_with_one_object_falling_back():
+    """Two objects in one batch (a grouped generator pass); one of them overflows and is P2P_PREC_AUTO: it switches to its fp32 twin, the
+    batch is repeated with the two objects on different arithmetics (per-object passes instead of the grouped one), and every detection
+    equals what its object returns alone."""
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
+    ctx = Context(0, max_batch=16)
+    ths = ([0.2, 0.3, 0.35], 0.2)
+    w_bad, w_ok = _overflowing("paper"), W.synthetic_weights("paper", 5)
+    sc = S.make_scene(6, seed=78)
+    imgs = list(sc["images"])
+    dets = [(d[0], i % 2, d[2], d[3]) for i, d in enumerate(sc["dets"])]
+    key = lambda p: (p.status, p.n_inliers, p.n_init_mask, tuple(p.bbox_t), tuple(p.R), tuple(p.t))
+    ga = Generator(w_bad, "paper", ctx, precision="auto")
+    got, _ = est_pose_batch(ctx, [ObjectSpec(ga, S.OBJ_PARAM, *ths), ObjectSpec(Generator(w_ok, "paper", ctx), S.OBJ_PARAM, *ths)], imgs, dets)
+    assert ga.active_precision == "f32"
+    alone = [ObjectSpec(Generator(w_bad, "paper", ctx, precision="f32"), S.OBJ_PARAM, *ths), ObjectSpec(Generator(w_ok, "paper", ctx), S.OBJ_PARAM, *ths)]
+    for i, d in enumerate(dets):
+        want, _ = est_pose_batch(ctx, [alone[d[1]]], imgs, [(d[0], 0, d[2], d[3])])
+        assert key(got[i]) == key(want[0]), i
