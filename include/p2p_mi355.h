@@ -66,6 +66,13 @@ P2P_API const char* p2p_build_id(void);
  * `side` against the 128-px network resolution; w must hold 256 doubles.  Returns the radius (0: no filtering), -1 on a bad
  * side.  tests/ hold it against scipy.ndimage's own kernel bit for bit. */
 P2P_API int p2p_aa_weights(int side, double* w);
+/* Test hook (GPU): the back-resizes of recognition.py:134,144,146 on caller-supplied 128 x 128 maps through the code the pipeline runs --
+ * prob [128*128] (cval 1), pred [128*128*3] (img_pred, cval 0.5), non_gray [128*128] (0 / 1, cval 0), host float32 -- at out_h x out_w;
+ * generation = p2p_est_pose_opts.resize_anti_aliasing.  Outputs (host): q [out_h*out_w*3] = (resize(pred) * 255) truncated to uint8,
+ * below [out_h*out_w] = resize(prob) < th_inlier, ng_out = resize(non_gray) > 0.9.  tests/test_external_vectors.py holds it against the
+ * vectors of the real scikit-image 0.18.3. */
+P2P_API int p2p_debug_back_resize(p2p_ctx* ctx, const float* prob, const float* pred, const float* non_gray, int out_h, int out_w,
+                                  double th_inlier, int generation, unsigned char* q, unsigned char* below, unsigned char* ng_out);
 P2P_API const char* p2p_last_error(void);
 P2P_API int p2p_device_count(int* count);
 

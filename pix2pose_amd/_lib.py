@@ -210,6 +210,7 @@ def lib():
     L.p2p_est_pose_submit.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,
                                       C.POINTER(EstPoseOpts), C.POINTER(ci)]
     L.p2p_est_pose_collect.argtypes = [vp, ci, C.POINTER(Pose)]
+    L.p2p_debug_back_resize.argtypes = [vp, vp, vp, vp, ci, ci, C.c_double, ci, vp, vp, vp]
     L.p2p_comm_unique_id.argtypes = [C.c_char_p]
     L.p2p_comm_create.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(vp)]
     L.p2p_comm_destroy.argtypes = [vp]

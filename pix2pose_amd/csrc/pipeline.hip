@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __rest
 struct CandPixel {
     bool non_gray;
     bool valid;
+    bool below;            // img_prob_ori < th_inlier by itself (p2p_debug_back_resize; dead code elsewhere)
     unsigned char q[3];
 };
 
@@ -561,7 +562,8 @@ __device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const
                 }
             }
         const float pr = (float)clip_warp((double)lerp2_f32(prob[0][0], prob[0][1], prob[1][0], prob[1][1], fr.d, fc.d), R.pmin, R.pmax, 1.0);
-        o.valid = o.non_gray && pr < (float)th_i;                                       // float32 array < python float: a float32 comparison
+        o.below = pr < (float)th_i;                                                     // float32 array < python float: a float32 comparison
+        o.valid = o.non_gray && o.below;
         for (int ch = 0; ch < 3; ++ch) {
             const float w = (float)clip_warp((double)lerp2_f32(pred[ch][0][0], pred[ch][0][1], pred[ch][1][0], pred[ch][1][1], fr.d, fc.d), R.qmin, R.qmax, 0.5);
             const float v = w * 255.0f;                                                 // :144  float32 array * 255
@@ -593,7 +595,8 @@ __device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const
         }
     o.non_gray = clip_warp(lerp2(ng[0][0], ng[0][1], ng[1][0], ng[1][1], tr.d, tc.d), R.gmin, R.gmax, 0.0) > 0.9;
     const double pr = clip_warp(lerp2(prob[0][0], prob[0][1], prob[1][0], prob[1][1], tr.d, tc.d), R.pmin, R.pmax, 1.0);
-    o.valid = o.non_gray && pr < th_i;                                              // :203-204
+    o.below = pr < th_i;
+    o.valid = o.non_gray && o.below;                                                // :203-204
     for (int ch = 0; ch < 3; ++ch) {
         const double v = clip_warp(lerp2(pred[ch][0][0], pred[ch][0][1], pred[ch][1][0], pred[ch][1][1], tr.d, tc.d), R.qmin, R.qmax, 0.5) * 255;
         o.q[ch] = (unsigned char)(int)v;                                            // uint8 canvas: truncation (:152-154)
@@ -1706,6 +1709,23 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     return P2P_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Test hook (p2p_debug_back_resize): the back-resizes of recognition.py:134,144,146 on caller-supplied 128 x 128 planes, through
+// exactly the code the pipeline runs (cand_pixel, the anti-aliasing filter, the clip ranges).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void back_resize_probe_kernel(const double* __restrict__ planes, CandRange R, int S2, int S2w, double th_i, int gen,
+                                                                unsigned char* __restrict__ q, unsigned char* __restrict__ below,
+                                                                unsigned char* __restrict__ non_gray)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= S2 * S2w) return;
+    const int r = p / S2w, c = p - r * S2w;
+    const CandPixel cp = cand_pixel(nullptr, planes, R, r, c, S2, S2w, th_i, gen);
+    q[3 * p] = cp.q[0]; q[3 * p + 1] = cp.q[1]; q[3 * p + 2] = cp.q[2];
+    below[p] = cp.below ? 1 : 0;
+    non_gray[p] = cp.non_gray ? 1 : 0;
+}
+
 // comm != nullptr: the records of every rank's batch are all-gathered (device to device, on the tail stream, behind this batch's tail)
 // into gathered[world][n_max] before anything is handed to the host
 static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses, Comm* comm = nullptr, int n_max = 0, p2p_pose* gathered = nullptr)
@@ -1767,6 +1787,76 @@ int p2p_est_pose_collect_gathered(p2p_ctx* ctx, p2p_comm* comm, int ticket, p2p_
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     HIP_TRY(hipSetDevice(c->device));
     return collect_est_pose(*c, ticket, poses, reinterpret_cast<Comm*>(comm), n_max, gathered);
+}
+
+int p2p_debug_back_resize(p2p_ctx* ctx, const float* prob, const float* pred, const float* non_gray, int out_h, int out_w, double th_inlier,
+                          int generation, unsigned char* q, unsigned char* below, unsigned char* ng_out)
+{
+    if (!ctx || !prob || !pred || !non_gray || !q || !below || !ng_out || out_h < 1 || out_w < 1 || out_h > 1024 || out_w > 1024) {
+        set_error("p2p_debug_back_resize: bad arguments");
+        return P2P_ERR_INVALID_ARG;
+    }
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // five planes as the pipeline keeps them: [prob | pred r | g | b | non_gray][128 * 128] doubles (float32-valued where the reference's array is float32)
+    std::vector<double> h(5 * 16384);
+    double lo[5], hi[5];
+    for (int k = 0; k < 5; ++k) { lo[k] = 1e300; hi[k] = -1e300; }
+    for (int i = 0; i < 16384; ++i) {
+        h[i] = prob[i];
+        for (int ch = 0; ch < 3; ++ch) h[(1 + ch) * 16384 + i] = pred[3 * i + ch];
+        h[4 * 16384 + i] = non_gray[i];
+        for (int k = 0; k < 5; ++k) { lo[k] = std::min(lo[k], h[k * 16384 + i]); hi[k] = std::max(hi[k], h[k * 16384 + i]); }
+    }
+    DevBuf planes, tmp, items, dq, db, dg;
+    int rc;
+    const size_t npx = (size_t)out_h * out_w;
+    if ((rc = planes.reserve(h.size() * 8)) || (rc = tmp.reserve(h.size() * 8)) || (rc = items.reserve(5 * sizeof(AaItem))) ||
+        (rc = dq.reserve(npx * 3)) || (rc = db.reserve(npx)) || (rc = dg.reserve(npx))) return rc;
+    auto cleanup = [&]() { planes.release(); tmp.release(); items.release(); dq.release(); db.release(); dg.release(); };
+    hipError_t e = hipMemcpyAsync(planes.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, st);
+    CandRange R;
+    R.pmin = lo[0]; R.pmax = hi[0];
+    R.qmin = std::min(lo[1], std::min(lo[2], lo[3])); R.qmax = std::max(hi[1], std::max(hi[2], hi[3]));
+    R.gmin = lo[4]; R.gmax = hi[4];
+    if (e == hipSuccess && generation && out_h < 128) {          // scikit-image 0.17 / 0.18: anti-aliasing filter before a shrinking resize (square outputs, like the path's)
+        AaTable tab;
+        if ((rc = aa_table_get(c->device, &tab))) { cleanup(); return rc; }
+        std::vector<int> rad(tab.max_side + 1), off(tab.max_side + 1);
+        e = hipMemcpy(rad.data(), tab.rad, rad.size() * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(off.data(), tab.off, off.size() * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rad[out_h] > 0) {
+            AaItem it[5];
+            for (int k = 0; k < 5; ++k) {
+                memset(&it[k], 0, sizeof(AaItem));
+                it[k].a = planes.as<double>() + (size_t)k * 16384; it[k].tmp = tmp.as<double>() + (size_t)k * 16384;
+                it[k].H = it[k].W = 128; it[k].C = 1; it[k].radius = rad[out_h]; it[k].w = tab.w + off[out_h];
+                it[k].mode = 1; it[k].cval = k == 0 ? 1.0 : (k == 4 ? 0.0 : 0.5); it[k].round32 = k < 4;
+            }
+            e = hipMemcpyAsync(items.p, it, sizeof(it), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = launch_aa_filter(items.as<AaItem>(), 5, 16384, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(it, items.p, sizeof(it), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) {
+                R.pmin = it[0].vmin; R.pmax = it[0].vmax;
+                R.qmin = std::min(it[1].vmin, std::min(it[2].vmin, it[3].vmin)); R.qmax = std::max(it[1].vmax, std::max(it[2].vmax, it[3].vmax));
+                R.gmin = it[4].vmin; R.gmax = it[4].vmax;
+            }
+        }
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(back_resize_probe_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, planes.as<double>(), R, out_h, out_w, th_inlier,
+                           generation ? 1 : 0, dq.as<unsigned char>(), db.as<unsigned char>(), dg.as<unsigned char>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(q, dq.p, npx * 3, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(below, db.p, npx, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ng_out, dg.p, npx, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) { set_error("p2p_debug_back_resize: %s", hipGetErrorString(e)); return P2P_ERR_HIP; }
+    return P2P_OK;
 }
 
 int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, const p2p_image* images, int n_images,
