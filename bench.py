@@ -46,6 +46,7 @@ AE_GFLOP = {"resnet50": 10.70, "paper": 12.58}        # SURVEY.md section 8a-L /
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_F16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_HBM_TBPS = 8.0                                    # MI355X_MICROARCH.md: HBM3E peak
+STREAM_HBM_TBPS = 5.9                                  # what a plain 2-reads-1-write elementwise stream sustains on this chip (tools/bw_probe.py: copy 5.45, add 5.91)
 TH_O, TH_I = [0.2, 0.3, 0.35], 0.2                     # cfg/cfg_bop2020.json:8-9
 
 
@@ -418,7 +419,7 @@ def main():
             name = _lib.PROFILE_KERNELS[i][1]
             tbps = st["algo_bytes"] / (st["total_ms"] * 1e-3) / 1e12
             out.append({"kernel": (name % 1 if "%d" in name else name), "layers": label, "bound": "hbm", "achieved_TBps": tbps, "peak_TBps": PEAK_HBM_TBPS,
-                        "frac": tbps / PEAK_HBM_TBPS, "algo_MB_per_launch": st["algo_bytes"] / st["launches"] / 1e6,
+                        "frac": tbps / PEAK_HBM_TBPS, "frac_of_plain_stream": tbps / STREAM_HBM_TBPS, "algo_MB_per_launch": st["algo_bytes"] / st["launches"] / 1e6,
                         "avg_launch_ms": st["total_ms"] / st["launches"], "launches": st["launches"],
                         "algo_tflops": st["algo_flops"] / (st["total_ms"] * 1e-3) / 1e12})
         return out
@@ -579,6 +580,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
+    if comm is not None:
+        comm.close()                   # ncclCommDestroy before torch tears its own communicator (and the shared RCCL) down
     if use_dist:
         dist.destroy_process_group()
 
