@@ -1812,9 +1812,9 @@ int p2p_debug_back_resize(p2p_ctx* ctx, const float* prob, const float* pred, co
     DevBuf planes, tmp, items, dq, db, dg;
     int rc;
     const size_t npx = (size_t)out_h * out_w;
-    if ((rc = planes.reserve(h.size() * 8)) || (rc = tmp.reserve(h.size() * 8)) || (rc = items.reserve(5 * sizeof(AaItem))) ||
-        (rc = dq.reserve(npx * 3)) || (rc = db.reserve(npx)) || (rc = dg.reserve(npx))) return rc;
     auto cleanup = [&]() { planes.release(); tmp.release(); items.release(); dq.release(); db.release(); dg.release(); };
+    if ((rc = planes.reserve(h.size() * 8)) || (rc = tmp.reserve(h.size() * 8)) || (rc = items.reserve(5 * sizeof(AaItem))) ||
+        (rc = dq.reserve(npx * 3)) || (rc = db.reserve(npx)) || (rc = dg.reserve(npx))) { cleanup(); return rc; }
     hipError_t e = hipMemcpyAsync(planes.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, st);
     CandRange R;
     R.pmin = lo[0]; R.pmax = hi[0];
