@@ -221,7 +221,10 @@ def main_real_skimage():
     sys.path.insert(0, REF)
     from pix2pose_model import recognition as ref
     assert ref.resize.__module__.startswith("skimage."), ref.resize.__module__
-    if "--scenes-only" in sys.argv:                            # child process under another OPENBLAS_CORETYPE
+    if "--scenes-only" in sys.argv:                            # child process under another OPENBLAS_CORETYPE; --exact-matrix: with the exact affine map
+        if "--exact-matrix" in sys.argv:
+            _w, _Exact = _exact_affine_patch()
+            _w.AffineTransform = _Exact
         print(json.dumps(run_scenes(ref, SCENES_REAL)))
         return
     installed = run_scenes(ref, SCENES_REAL)
