@@ -19,7 +19,8 @@ sys.path.insert(0, %r)
 from pix2pose_amd import weights as W
 from pix2pose_amd.runtime import Generator
 backbone, precision, out = sys.argv[1], sys.argv[2], sys.argv[3]
-x = (np.random.RandomState(11).randint(0, 256, (5, 128, 128, 3)).astype(np.float32) - 128) / 128
+import os
+x = (np.random.RandomState(11).randint(0, 256, (int(os.environ.get("P2P_TEST_N", "5")), 128, 128, 3)).astype(np.float32) - 128) / 128
 x[3] *= 40.0            # activations far outside [-1, 1]
 g = Generator(W.synthetic_weights(backbone, 4), backbone, precision=precision)
 dec, prob = g.predict(x)
@@ -55,3 +56,11 @@ def test_specialised_kernels_track_fp32_mode(tmp_path):
     assert np.abs(a["dec"][rest] - c["dec"][rest]).max() < 1e-4
     assert np.abs(a["prob"][rest] - c["prob"][rest]).max() < 1e-4
     assert np.abs(a["dec"][3] - c["dec"][3]).max() < 40 * 1e-4
+
+
+def test_heads_two_ahead_schedule_is_bit_identical(tmp_path):
+    """heads_halo_kernel<2> (P2P_HEADS_TWO_AHEAD=1: 8-row workgroups fetching two stages ahead) computes an output pixel with the same chain
+    of MFMAs as the default 16-row schedule: identical bits."""
+    a = _run(tmp_path, "resnet50", "f16x3", "default", {"P2P_TEST_N": "20"})           # >= 16 inputs: the large-launch variants of the kernel
+    b = _run(tmp_path, "resnet50", "f16x3", "two_ahead", {"P2P_TEST_N": "20", "P2P_HEADS_TWO_AHEAD": "1"})
+    assert np.array_equal(a["dec"], b["dec"]) and np.array_equal(a["prob"], b["prob"])
