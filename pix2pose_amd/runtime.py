@@ -29,6 +29,13 @@ class Context:
     def synchronize(self):
         _lib.check(_lib.lib().p2p_ctx_synchronize(self._h), "p2p_ctx_synchronize")
 
+    def range_event(self) -> float:
+        """Largest activation magnitude beyond the split-f16 operand range that direct forward calls (Generator.forward_device) stored since
+        the last query; 0.0 = none.  Synchronises the context stream (p2p_ctx_range_event)."""
+        v = C.c_float(0.0)
+        _lib.check(_lib.lib().p2p_ctx_range_event(self._h, C.byref(v)), "p2p_ctx_range_event")
+        return float(v.value)
+
     def profile(self, on: bool):
         """Bracket every implicit-GEMM launch with HIP events on the context stream."""
         _lib.check(_lib.lib().p2p_profile_enable(self._h, 1 if on else 0), "p2p_profile_enable")

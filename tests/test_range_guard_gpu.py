@@ -106,3 +106,23 @@ def test_mixed_batch_with_one_object_falling_back():
     for i, d in enumerate(dets):
         want, _ = est_pose_batch(ctx, [alone[d[1]]], imgs, [(d[0], 0, d[2], d[3])])
         assert key(got[i]) == key(want[0]), i
+
+
+def test_forward_async_reports_through_the_context():
+    """p2p_forward_async cannot return a range error (it only enqueues): p2p_ctx_range_event tells, once, and clears the flag."""
+    import torch
+    from pix2pose_amd.runtime import Context, Generator
+    ctx = Context(0, max_batch=4)
+    x = torch.from_numpy(_x(3)).cuda()
+    y = torch.empty(3, 128, 128, 4, device="cuda")
+    torch.cuda.synchronize()
+    ok = Generator(W.synthetic_weights("paper", 3), "paper", ctx)
+    ok.forward_device(x.data_ptr(), 3, y.data_ptr())
+    assert ctx.range_event() == 0.0
+    bad = Generator(_overflowing("paper"), "paper", ctx)
+    bad.forward_device(x.data_ptr(), 3, y.data_ptr())
+    assert ctx.range_event() > 6e4
+    assert ctx.range_event() == 0.0                 # cleared by the query
+    f32 = Generator(_overflowing("paper"), "paper", ctx, precision="f32")
+    f32.forward_device(x.data_ptr(), 3, y.data_ptr())
+    assert ctx.range_event() == 0.0                 # the fp32 arithmetic has no such limit and is not guarded
