@@ -46,6 +46,7 @@ AE_GFLOP = {"resnet50": 10.70, "paper": 12.58}        # SURVEY.md section 8a-L /
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_F16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_HBM_TBPS = 8.0                                    # MI355X_MICROARCH.md: HBM3E peak
+POWER_WALL_F16X3_TFLOPS = 1497.0                       # v_mfma_f32_32x32x16_f16 out of registers, 12 waves per CU, THIS arithmetic's operand mix: profiles/r04_mfma_power_wall.txt (tools/mfma_f16_wall.hip)
 STREAM_HBM_TBPS = 5.9                                  # what a plain 2-reads-1-write elementwise stream sustains on this chip (tools/bw_probe.py: copy 5.45, add 5.91)
 TH_O, TH_I = [0.2, 0.3, 0.35], 0.2                     # cfg/cfg_bop2020.json:8-9
 
@@ -391,6 +392,10 @@ def main():
              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
              "frac_algorithmic": ach / (PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS),
              "peak_dense_f16_mfma": PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else None,
+             # what the chip sustains when it does NOTHING but these MFMAs on operands distributed like the split's (data-dependent power: all-zero
+             # operands run at 2231): the ceiling any kernel shape is under, measured with tools/mfma_f16_wall.hip
+             "measured_mfma_power_wall_tflops": POWER_WALL_F16X3_TFLOPS if precision == "f16x3" else None,
+             "frac_of_measured_power_wall": (3 * ach / POWER_WALL_F16X3_TFLOPS) if precision == "f16x3" else None,
              "mfma_flops_per_algorithmic_flop": 3 if precision == "f16x3" else 1,
              "note": ("achieved = algorithmic FLOPs (2 x MACs of the layers) / launch time.  frac = utilisation of the f16 matrix pipe: the split-f16 "
                       "arithmetic (fp32-equivalent results) issues 3 MFMA products per algorithmic MAC, so peak = 2500 / 3 and the pipe sustains "
