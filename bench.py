@@ -185,10 +185,11 @@ def main():
     ap.add_argument("--anti-aliasing", action="store_true", help="scikit-image 0.17 - 0.18 resize semantics (Gaussian pre-filter whenever a resize shrinks)")
     ap.add_argument("--bbox-side", default="86,86", help="range of detection box sides in px (default 86 = 128-px crops, the headline workload; "
                     "e.g. 40,300 for general crop sizes -- profiling runs)")
+    ap.add_argument("--batch64", type=int, default=20, help="passes of the configs[1] leg (64-input generator forward only, N=1; 0 = skip)")
     ap.add_argument("--no-legs", action="store_true", help="skip the f32 / host-frame / latency / CPU legs (profiling runs)")
     args = ap.parse_args()
     if args.no_legs:
-        args.f32_steps = args.host_frames = args.latency = args.cpu_sample = args.general = 0
+        args.f32_steps = args.host_frames = args.latency = args.cpu_sample = args.general = args.batch64 = 0
     if args.host_frames < 0:
         args.host_frames = args.steps
     if args.general < 0:
@@ -530,6 +531,36 @@ def main():
                 out["general_crops"]["ransac_iters_selected_le16_le32_le64_le100"] = [int((it <= 16).sum()), int(((it > 16) & (it <= 32)).sum()),
                                                                                        int(((it > 32) & (it <= 64)).sum()), int((it > 64).sum())]
         del gj1, gj2, gfr
+    # -- BASELINE.json configs[1]: batch = 64 synthetic crops, one object model, generator forward ONLY (p2p_forward_async on device buffers,
+    #    HIP events on the context's stream).  Passes of 256 and 768 inputs beside it: a 64-input pass under-fills the short-K layers' launches.
+    if solo and args.batch64 > 0:
+        gen0 = specs[0].generator
+        cst = torch.cuda.ExternalStream(ctx.stream)
+        b64 = {"workload": "BASELINE.json configs[1]: 64 synthetic 128x128 crops, 1 object model, generator forward only", "unit": "inputs/s", "passes": args.batch64}
+        for n_in in (64, 256, 768):
+            if n_in > args.chunk:
+                continue
+            xin = (torch.randint(0, 256, (n_in, 128, 128, 3), device="cuda", generator=torch.Generator("cuda").manual_seed(5)).float() - 128) / 128
+            yout = torch.empty(n_in, 128, 128, 4, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(2):
+                gen0.forward_device(xin.data_ptr(), n_in, yout.data_ptr())
+            ctx.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(cst):
+                e0.record(cst)
+                for _ in range(args.batch64):
+                    gen0.forward_device(xin.data_ptr(), n_in, yout.data_ptr())
+                e1.record(cst)
+            ctx.synchronize()
+            ms = e0.elapsed_time(e1) / args.batch64
+            b64["n%d" % n_in] = {"ms_per_pass": ms, "inputs_per_s": n_in / ms * 1e3, "algo_tflops": n_in * AE_GFLOP[args.backbone] / ms / 1e3}
+            del xin, yout
+        if "n64" in b64:
+            b64["value"] = b64["n64"]["inputs_per_s"]
+            if "n256" in b64:
+                b64["per_input_rate_vs_256"] = b64["n64"]["inputs_per_s"] / b64["n256"]["inputs_per_s"]
+        out["batch64"] = b64
     # -- latency leg: ONE detection through the drop-in shim, masks and image returned like the reference's est_pose
     if solo and args.latency > 0:
         from pix2pose_amd.recognition import pix2pose
@@ -577,8 +608,8 @@ def main():
                                        "status_mismatches": int(status_mismatches),       # expected 0; > 0 voids the delta figures
                                        "note": "GPU path vs the CPU restatement on the cpu_baseline sample: pose delta, and detections whose returned box and "
                                                "inlier fraction (n_inliers / n_init_mask: the RANSAC outcome) are identical; north_star bar 1 mm / 1 deg"}
-        if status_mismatches:                               # a pose on one side only is an infinite delta, not a missing sample
-            out["pose_delta_vs_oracle"]["max_dt_mm"] = out["pose_delta_vs_oracle"]["max_drot_deg"] = float("inf")
+        if status_mismatches:                               # a pose on one side only voids the delta figures (null: `Infinity` is not JSON)
+            out["pose_delta_vs_oracle"]["max_dt_mm"] = out["pose_delta_vs_oracle"]["max_drot_deg"] = None
         out["pose_delta_vs_oracle_max_mm_deg"] = [out["pose_delta_vs_oracle"]["max_dt_mm"], out["pose_delta_vs_oracle"]["max_drot_deg"]]
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define P2P_ABI_VERSION 7
+#define P2P_ABI_VERSION 8
 
 /* The library is built with -fvisibility=hidden: the entry points declared here (P2P_API) are its ONLY dynamic symbols
  * (tests/test_host_cpu.py holds `nm -D` to exactly this list). */
@@ -103,7 +103,9 @@ P2P_API int p2p_model_create(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tens
  * the fp32 mode is (max 2.5e-5 vs 3.3e-5 on the tanh outputs).  Weights are pre-scaled per output channel.
  * OPERAND RANGE of the split: |activation| < 65504 (f16 max).  Batch-normalised layers sit orders of magnitude below; the two
  * linear Dense layers (ae_model.py:199-200) have no BatchNorm behind them.  The range is GUARDED: every layer epilogue tracks the
- * largest magnitude it stores and raises a device-side flag beyond 6e4; the flag travels with the results and
+ * largest magnitude it stores and raises a device-side flag beyond 6e4 -- a NaN counts as beyond (the running maximum and the ReLU of the
+ * epilogues propagate NaN); the caller-supplied input x of p2p_predict / p2p_forward_async is NOT checked (|x| < 65504 is the caller's to
+ * keep: the pipeline's own inputs are (u8 - 128) / 128) -- the flag travels with the results and
  *   p2p_predict / p2p_est_pose_batch / p2p_est_pose_collect return P2P_ERR_RANGE (outputs / poses of that call are not to be used);
  *   p2p_forward_async cannot report -- ask p2p_ctx_range_event() after synchronising.
  * P2P_PREC_AUTO: split-f16 with a strict-fp32 twin of the same weights kept beside it (+ the model's size in HBM).  On a range event the
@@ -182,6 +184,7 @@ typedef struct {
 /* est_pose status: the reference signals failure in-band with -1 sentinels (recognition.py:79,
  * 127,191); the shim maps any status != 0 back to those sentinels. */
 typedef enum {
+    P2P_POSE_RANGE = -2,           /* gathered batches only: a detection of a rank whose batch returned P2P_ERR_RANGE -- it exists, its pose is not to be used */
     P2P_POSE_ABSENT = -1,          /* padding record of a gathered batch (p2p_est_pose_collect_gathered): no detection here */
     P2P_POSE_OK = 0,
     P2P_POSE_CROP_TOO_SMALL = 1,   /* recognition.py:78-79  */
@@ -200,6 +203,10 @@ typedef struct {
     int bbox_t[4];        /* [v1,v2,u1,u2] as returned by the reference (box of the LAST candidate) */
     int n_candidates;     /* stage-2 candidates that were built                                 */
     int ransac_iters;     /* RANSAC iterations run for the selected candidate                   */
+    int64_t mask_stats[3];/* score_type 2 (p2p_est_pose_opts.det_mask given; tools/5_evaluation_bop_basic.py:307-316): {intersection, union,
+                           * valid_mask pixel count} of the detector mask with valid_mask_full -- the same numbers opts.mask_stats receives,
+                           * carried in the record so that a GATHERED record (p2p_est_pose_collect_gathered) is all another rank needs to
+                           * score the detection; zeros otherwise */
 } p2p_pose;
 
 /* Optional knobs; zero-initialise for the reference behaviour. */
@@ -297,15 +304,23 @@ P2P_API int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses);
  *   p2p_comm_unique_id   rank 0 draws the 128-byte id; the host program hands it to the other ranks by whatever it has
  *                        (MPI, a file, torch.distributed, a socket).
  *   p2p_comm_create      every rank: joins the communicator on its context's device (ncclCommInitRank -- collective).
- *   p2p_est_pose_collect_gathered   p2p_est_pose_collect + the gather: the batch's records go DEVICE to DEVICE over the
- *                        communicator on the batch's tail stream (they never visit the host first) and are copied out once.
+ *   p2p_est_pose_collect_gathered   p2p_est_pose_collect + the gather: once the batch's tail has finished, its records go DEVICE to DEVICE over
+ *                        the communicator (they never visit the host first) and are copied out once.
  *                        `poses[n_dets]` = this rank's own results as from collect; `gathered[world][n_max]` = every rank's records in
  *                        its caller's detection order, padded with status = P2P_POSE_ABSENT.  n_max >= the largest batch of any rank
  *                        and equal on all ranks.  Collective: every rank calls it once per step, in the same order.
+ *                        A rank WITHOUT work this step (an empty shard: images run out on different ranks, an object group smaller than
+ *                        the world -- the ragged loop of tools/5_evaluation_bop_basic.py:289-304) calls it with ticket = P2P_TICKET_NONE
+ *                        (poses may be NULL) and contributes n_max padding records; p2p_est_pose_submit itself takes n_dets >= 1.
+ *                        Errors never strand the peers: once ctx / comm / gathered / n_max are sane the all-gather is entered on every
+ *                        path -- an unknown ticket, a batch larger than n_max (its ticket stays in flight for a plain collect) or a failed
+ *                        stage-2 flush contribute padding and are returned AFTER the collective.  A batch that left the split-f16 operand
+ *                        range (P2P_ERR_RANGE on this rank, nothing handed over) travels as P2P_POSE_RANGE records.
  * RCCL is bound at run time (an RCCL already mapped into the process -- PyTorch's wheel carries one -- is reused, else librccl.so.1;
  * P2P_RCCL_LIB overrides): the library loads and runs single-GPU on machines without RCCL; these calls then fail with P2P_ERR_HIP.
  * ---------------------------------------------------------------------------------------- */
 #define P2P_COMM_ID_BYTES 128
+#define P2P_TICKET_NONE (-1)
 typedef struct p2p_comm p2p_comm;
 P2P_API int p2p_comm_unique_id(char* id /* [P2P_COMM_ID_BYTES] */);
 P2P_API int p2p_comm_create(p2p_ctx* ctx, int rank, int world, const char* id /* [P2P_COMM_ID_BYTES] */, p2p_comm** out);
@@ -331,10 +346,11 @@ P2P_API int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double*
  *   5  heads_halo_kernel (merged output heads)     6  igemm_halo8_kernel (layers on the 8x8 grid: conv4, first transposed conv)
  *   7  igemm_halo_s2_kernel (5x5 stride-2 convolutions on larger grids: the paper encoder's conv2 / conv3)
  *   8  igemm_stream_kernel (small launches: one wave per 32x32 tile, same K order and bits as the batched kernels)
+ *   9  resblock_kernel (a ResNet identity bottleneck block -- 1x1, 3x3, 1x1 + residual -- in one launch, intermediates in LDS)
  * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md
  * section 8a-L), not padded work and not the 3 MFMA products per MAC of the split-f16 arithmetic.
  * ---------------------------------------------------------------------------------------- */
-#define P2P_PROFILE_SLOTS 9
+#define P2P_PROFILE_SLOTS 10
 typedef struct {
     int64_t launches;
     double total_ms;

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P2P_LIB", os.path.join(_HERE, "libp2p_mi355.so"))     # P2P_LIB: development override
 
 P2P_OK = 0
-ABI_VERSION = 7            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
+ABI_VERSION = 8            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
 MAX_RANSAC_ITERATIONS = 128
 BACKBONE = {"paper": 0, "resnet50": 1}
 PRECISION = {"f32": 0, "f16x3": 1, "auto": 2}     # p2p_precision; "auto" = split-f16 with an fp32 twin it falls back to on a range event
@@ -19,6 +19,8 @@ ERR_RANGE = -5
 MEM_HOST, MEM_DEVICE = 0, 1
 COMM_ID_BYTES = 128
 POSE_ABSENT = -1
+POSE_RANGE = -2          # gathered record of a rank whose batch left the split-f16 operand range
+TICKET_NONE = -1         # p2p_est_pose_collect_gathered: this rank has no batch this step (empty shard)
 
 
 class P2PError(RuntimeError):
@@ -53,14 +55,15 @@ class Detection(C.Structure):
 class Pose(C.Structure):
     _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("frac_inlier", C.c_double), ("n_inliers", C.c_int),
                 ("n_init_mask", C.c_int), ("status", C.c_int), ("best_slot", C.c_int), ("bbox_t", C.c_int * 4),
-                ("n_candidates", C.c_int), ("ransac_iters", C.c_int)]
+                ("n_candidates", C.c_int), ("ransac_iters", C.c_int), ("mask_stats", C.c_int64 * 3)]
 
 
 import numpy as _np
 
 # numpy views of the struct arrays (same field order / alignment as the ctypes definitions; sizes asserted below)
 POSE_DTYPE = _np.dtype([("R", "<f8", (9,)), ("t", "<f8", (3,)), ("frac_inlier", "<f8"), ("n_inliers", "<i4"), ("n_init_mask", "<i4"),
-                        ("status", "<i4"), ("best_slot", "<i4"), ("bbox_t", "<i4", (4,)), ("n_candidates", "<i4"), ("ransac_iters", "<i4")], align=True)
+                        ("status", "<i4"), ("best_slot", "<i4"), ("bbox_t", "<i4", (4,)), ("n_candidates", "<i4"), ("ransac_iters", "<i4"),
+                        ("mask_stats", "<i8", (3,))], align=True)
 DETECTION_DTYPE = _np.dtype([("image", "<i4"), ("object", "<i4"), ("bbox", "<i4", (4,)), ("camK", "<f8", (9,))], align=True)
 assert POSE_DTYPE.itemsize == C.sizeof(Pose) and DETECTION_DTYPE.itemsize == C.sizeof(Detection)
 
@@ -75,7 +78,7 @@ class EstPoseOpts(C.Structure):
                 ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int), ("mask_prezeroed", C.c_int)]
 
 
-PROFILE_SLOTS = 9     # P2P_PROFILE_SLOTS
+PROFILE_SLOTS = 10    # P2P_PROFILE_SLOTS
 # kernel family of each slot: (label, substring of the rocprofv3 kernel name; %d = precision template argument)
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
                    ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
@@ -85,7 +88,8 @@ PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"
                    ("heads_halo_kernel (merged output heads)", "heads_halo_kernel"),
                    ("igemm_halo8_kernel 128x128 tiles (8x8-grid layers: conv4 through parity planes, first transposed conv)", "igemm_halo8_kernel"),
                    ("igemm_halo_s2_kernel (5x5 stride-2 convolutions on 16x16 and larger grids: the paper encoder)", "igemm_halo_s2_kernel"),
-                   ("igemm_stream_kernel (small launches: one wave per 32x32 output tile, operands streamed to registers)", "igemm_stream_kernel")]
+                   ("igemm_stream_kernel (small launches: one wave per 32x32 output tile, operands streamed to registers)", "igemm_stream_kernel"),
+                   ("resblock_kernel (ResNet identity bottleneck block in one launch: 1x1 -> 3x3 -> 1x1 + residual, intermediates in LDS)", "resblock_kernel")]
 
 
 class KernelStats(C.Structure):

@@ -2,8 +2,10 @@
 // has no multi-GPU call site -- tools/5_evaluation_bop_basic.py:289-304 walks its detections one by one on one GPU).
 //
 // Detections are independent, so every rank runs the whole pipeline on its shard and nothing crosses GPUs on the data path.
-// The only exchange is the (R, t, score) records at the end: 120-byte p2p_pose structs, n_max per rank, gathered DEVICE to DEVICE
-// on the batch's tail stream -- the records never visit the host before the gather -- and copied to the host once, after it.
+// The only exchange is the (R, t, score) records at the end: 144-byte p2p_pose structs, n_max per rank, gathered DEVICE to DEVICE
+// on the communicator's own stream once the batch's tail has finished (the collect has waited for it and taken the operand-range verdict;
+// the NEXT batch's tail, already queued on the tail stream, is not waited for) -- the records never visit the host before the gather --
+// and copied to the host once, after it: an event behind the copy, not a stream synchronisation.
 // 2048 detections on 8 ranks = 30 KB per rank: latency-bound, so ring / tree and bucket sizes are irrelevant.
 //
 // RCCL is bound at run time (dlopen), not at link time: the library must load on machines without RCCL (every single-GPU user), and
@@ -80,34 +82,57 @@ struct Comm {
     int rank = 0, world = 1, device = 0;
     DevBuf send, recv;
     PinnedBuf h_recv;
+    hipStream_t stream = nullptr;      // the gathers run here
+    hipEvent_t landed = nullptr;       // behind the D2H copy of a gather
     ~Comm()
     {
         if (comm && lib) (void)lib->comm_destroy(comm);
         send.release(); recv.release(); h_recv.release();
+        if (landed) hipEventDestroy(landed);
+        if (stream) hipStreamDestroy(stream);
     }
 };
 
-// send[src_index of detection i] = poses[i]  (the batch is processed sorted by object; the gathered records are in the caller's order)
-__global__ void gather_pack_kernel(const DetInfo* __restrict__ dets, const p2p_pose* __restrict__ poses, int n, p2p_pose* __restrict__ send)
+// send[src_index of detection i] = poses[i]  (the batch is processed sorted by object; the gathered records are in the caller's order).
+// force_status != 0: the batch left the split-f16 operand range -- the records travel with that status (P2P_POSE_RANGE) so that the peers see
+// detections whose poses are not to be used instead of ordinary-looking garbage.
+__global__ void gather_pack_kernel(const DetInfo* __restrict__ dets, const p2p_pose* __restrict__ poses, int n, p2p_pose* __restrict__ send, int force_status,
+                                   const unsigned long long* __restrict__ mstat)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) send[dets[i].src_index] = poses[i];
+    if (i >= n) return;
+    p2p_pose r = poses[i];
+    if (force_status) r.status = force_status;
+    if (mstat) {          // score_type-2 sums of the batch (mask_iou_kernel: {inter, |det mask|, |valid mask|}) -> {inter, union, valid}
+        const long long inter = (long long)mstat[3 * i], dc = (long long)mstat[3 * i + 1], vc = (long long)mstat[3 * i + 2];
+        r.mask_stats[0] = inter; r.mask_stats[1] = dc + vc - inter; r.mask_stats[2] = vc;
+    }
+    send[dets[i].src_index] = r;
 }
 
 int comm_world(const Comm& C) { return C.world; }
 
-int comm_gather(Ctx& X, Comm& C, Slot& s, hipStream_t ts, int n_max, p2p_pose* gathered)
+// s == nullptr: this rank has nothing valid to send this step (an empty shard, or a local error the caller reports after the collective):
+// it still joins, with n_max padding records.  `ts` is only used when the communicator has no stream of its own.
+int comm_gather(Ctx& X, Comm& C, Slot* s, bool range_event, hipStream_t ts, int n_max, p2p_pose* gathered)
 {
     int rc;
+    (void)X;
+    if (C.stream) ts = C.stream;
     const size_t rec = sizeof(p2p_pose), per = (size_t)n_max * rec;
     if ((rc = C.send.reserve(per)) || (rc = C.recv.reserve(per * C.world)) || (rc = C.h_recv.reserve(per * C.world))) return rc;
+    if (!C.landed) HIP_TRY(hipEventCreateWithFlags(&C.landed, hipEventDisableTiming));
     HIP_TRY(hipMemsetAsync(C.send.p, 0xFF, per, ts));                    // padding records: status = -1 (P2P_POSE_ABSENT)
-    hipLaunchKernelGGL(gather_pack_kernel, dim3((s.n + 255) / 256), dim3(256), 0, ts, s.det.as<DetInfo>(), s.poses.as<p2p_pose>(), s.n, C.send.as<p2p_pose>());
-    HIP_TRY(hipGetLastError());
+    if (s && s->n > 0) {
+        hipLaunchKernelGGL(gather_pack_kernel, dim3((s->n + 255) / 256), dim3(256), 0, ts, s->det.as<DetInfo>(), s->poses.as<p2p_pose>(), s->n, C.send.as<p2p_pose>(),
+                           range_event ? (int)P2P_POSE_RANGE : 0, s->opt.det_mask ? s->mstat.as<unsigned long long>() : nullptr);
+        HIP_TRY(hipGetLastError());
+    }
     const ncclResult_t r = C.lib->all_gather(C.send.p, C.recv.p, per, ncclChar, C.comm, ts);
     if (r != ncclSuccess) { set_error("ncclAllGather failed: %s", C.lib->error_string(r)); return P2P_ERR_HIP; }
     HIP_TRY(hipMemcpyAsync(C.h_recv.p, C.recv.p, per * C.world, hipMemcpyDeviceToHost, ts));
-    HIP_TRY(hipStreamSynchronize(ts));
+    HIP_TRY(hipEventRecord(C.landed, ts));
+    HIP_TRY(hipEventSynchronize(C.landed));
     memcpy(gathered, C.h_recv.p, per * C.world);
     return P2P_OK;
 }
@@ -145,6 +170,7 @@ int p2p_comm_create(p2p_ctx* ctx, int rank, int world, const char* id, p2p_comm*
     memcpy(u.internal, id, P2P_COMM_ID_BYTES);
     const ncclResult_t r = L->comm_init_rank(&C->comm, world, u, rank);
     if (r != ncclSuccess) { set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, L->error_string(r)); C->comm = nullptr; delete C; return P2P_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking) != hipSuccess) C->stream = nullptr;      // falls back to the batch's tail stream
     *out = reinterpret_cast<p2p_comm*>(C);
     return P2P_OK;
 }

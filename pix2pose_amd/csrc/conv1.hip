@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float u = fmaf(acc[m][q][e], sc[e], sh[e]);
-                        if (act == ACT_RELU) u = fmaxf(u, 0.f);
+                        if (act == ACT_RELU) u = relu_nan(u);
                         else if (act == ACT_LEAKY) u = u > 0.f ? u : u * alpha;
                         v[m][q][e] = u;
                     }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv1_f16x3_kernel(const float* __rest
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float u = fmaf(v[e], sc[e], sh[e]);
-                    if (act == ACT_RELU) u = fmaxf(u, 0.f);
+                    if (act == ACT_RELU) u = relu_nan(u);
                     else if (act == ACT_LEAKY) u = u > 0.f ? u : u * alpha;
                     v[e] = u;
                 }
@@ -273,7 +273,7 @@ hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Con
     // (an output pixel is computed the same way whichever workgroup owns its row)
     const int tpw = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG)) >= 64 ? C1_TILES_PER_WG : (N >= 4 ? 2 : 1);
     const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * tpw));
-    static const bool no_fuse = getenv("P2P_NO_POOL_FUSE") != nullptr;      // development switch (A/B)
+    static const bool no_fuse = dev_env("P2P_NO_POOL_FUSE") != nullptr;      // development switch (A/B)
     if (KH == 7 && pool_out && tpw == C1_TILES_PER_WG && !no_fuse) {
         hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, true>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, pool_out, range_acc);
         return hipGetLastError();

@@ -291,7 +291,7 @@ hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s)
     const bool small = p.N * (p.Hg / (HEADS_TH * HEADS_TILES_BIG)) < 64;
     const int n_wgs = p.N * (p.Hg / (HEADS_TH * (small ? 1 : HEADS_TILES_BIG)));
     const int per_xcd = (n_wgs + 7) / 8;
-    static const bool two_ahead = getenv("P2P_HEADS_TWO_AHEAD") != nullptr && atoi(getenv("P2P_HEADS_TWO_AHEAD")) != 0;      // development switch (A/B; same bits)
+    static const bool two_ahead = dev_env("P2P_HEADS_TWO_AHEAD") != nullptr && atoi(dev_env("P2P_HEADS_TWO_AHEAD")) != 0;      // development switch (A/B; same bits)
     if (small) hipLaunchKernelGGL(heads_halo_kernel<1>, dim3(per_xcd * 8), dim3(256), 0, s, p);
     else if (two_ahead && p.Hg % (HEADS_TH * 2) == 0) {
         const int n2 = p.N * (p.Hg / (HEADS_TH * 2));

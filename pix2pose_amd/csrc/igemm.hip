@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const IgemmParams p)   //
                         for (int e = 0; e < 4; ++e) v[e] += rs[it][e];
                         if (p.act == ACT_RELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
                         } else if (p.act == ACT_LEAKY) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
@@ -428,9 +428,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int kspl
         for (int z = 0; z < ksplit; ++z) s += partial[(size_t)z * total + i];
         const int c = (int)(i % Cout);
         float v = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
-        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        if (act == ACT_RELU) v = relu_nan(v);
         else if (act == ACT_LEAKY) v = v > 0.f ? v : v * alpha;
-        amax = fmaxf(amax, fabsf(v));
+        amax = range_note1(amax, v);
         out[i] = v;
     }
     range_commit(range_acc, amax);
@@ -458,7 +458,7 @@ __global__ void splitk_reduce_rows_kernel(const float* __restrict__ partial, int
         for (int z = 0; z < ksplit; ++z) s += partial[(size_t)z * slab + o];
         const int c = (int)(i % Cout);
         const float v = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
-        amax = fmaxf(amax, fabsf(v));
+        amax = range_note1(amax, v);
         out[o] = v;
     }
     range_commit(range_acc, amax);

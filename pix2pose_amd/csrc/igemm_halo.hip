@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]) + rs[it][e];
                 if (p.act == ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
                 } else if (p.act == ACT_LEAKY) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, WGM == 2 ? 3 : 2) void igemm_halo_kernel(const
 // all four waves along M -- a 16x16 patch, 256x64 tile (with the 8x16 patch a wave had 64x32 and the kernel was bound by
 // its LDS reads: 12 fragment loads per 12 MFMAs instead of 16 per 24) -- or the 8x16 patch with 64x32 wave tiles when the
 // grid is not a multiple of 16 rows.
-static bool tall_patch() { static const bool on = getenv("P2P_HALO_TALL") == nullptr || atoi(getenv("P2P_HALO_TALL")) != 0; return on; }
+static bool tall_patch() { static const bool on = dev_env("P2P_HALO_TALL") == nullptr || atoi(dev_env("P2P_HALO_TALL")) != 0; return on; }
 
 bool igemm_halo_supported(const IgemmParams& p)
 {

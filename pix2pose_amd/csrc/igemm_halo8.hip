@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo8_kernel(const IgemmParams p
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
                 if (p.act == ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
                 } else if (p.act == ACT_LEAKY) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo8_kernel(const IgemmParams p
 // 1: stride-1 layer on an 8x8 grid; 2: the stride-2 5x5 'SAME' convolution from a 16x16 input; 0: not for this kernel
 int igemm_halo8_mode(const IgemmParams& p)
 {
-    static const bool on = getenv("P2P_NO_HALO8") == nullptr;
+    static const bool on = dev_env("P2P_NO_HALO8") == nullptr;
     if (!on || p.prec != PREC_F16X3 || p.mode != EPI_NORMAL || p.ksplit > 1 || p.Hg != G8 || p.Wg != G8 || p.Cout % BN) return 0;
     if (p.seg[1].C != 0 || p.residual || p.seg1_stride) return 0;
     if (p.in_stride == 1 && p.Hin == G8 && p.Win == G8 && p.ntaps >= 4 && p.ntaps <= 9) {

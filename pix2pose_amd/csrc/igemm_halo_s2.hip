@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo_s2_kernel(const IgemmParams
             for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
             if (p.act == ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
             } else if (p.act == ACT_LEAKY) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo_s2_kernel(const IgemmParams
 
 bool igemm_halo_s2_supported(const IgemmParams& p)
 {
-    static const bool on = getenv("P2P_NO_HALO_S2") == nullptr;
+    static const bool on = dev_env("P2P_NO_HALO_S2") == nullptr;
     if (!on || p.prec != PREC_F16X3 || p.mode != EPI_NORMAL || p.ksplit > 1 || p.in_stride != 2 || p.ntaps != 25) return false;
     if (p.Hin != 2 * p.Hg || p.Win != 2 * p.Wg || p.Hg % TY || p.Wg % TX || p.Cout % BN) return false;
     if (p.seg[1].C != 0 || p.residual || p.seg1_stride || p.os != 1 || p.oy || p.ox || p.Hout != p.Hg || p.Wout != p.Wg) return false;

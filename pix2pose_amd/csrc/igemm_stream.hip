@@ -250,9 +250,9 @@ __global__ __launch_bounds__(64) void igemm_stream_kernel(const IgemmParams p, c
             for (int r = 0; r < 16; ++r) {
                 if (ops[r] < 0) continue;
                 float v = fmaf(acc[i][j][r], sc, sh) + rs[r];
-                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                if (p.act == ACT_RELU) v = relu_nan(v);
                 else if (p.act == ACT_LEAKY) v = v > 0.f ? v : v * p.alpha;
-                amax = fmaxf(amax, fabsf(v));
+                amax = range_note1(amax, v);
                 p.out[(size_t)ops[r] * p.out_cstride + p.out_coff + col] = v;
             }
         }

@@ -2,8 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace p2p {
+
+// Route switches between kernels that compute the same bits (P2P_NO_HALO, P2P_STREAM_WGS, P2P_NO_FUSED_BLOCK, ...) exist in DEVELOPMENT builds
+// only: -DP2P_DEV_SWITCHES = pix2pose_amd/libp2p_mi355_dev.so, which the route-equivalence tests and the A/B tools load through P2P_LIB.
+// The shipped library takes no behaviour from the environment (a stray variable cannot silently change its speed).
+#ifdef P2P_DEV_SWITCHES
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum EpiMode { EPI_NORMAL = 0, EPI_HEAD = 1 };
@@ -15,14 +25,27 @@ enum Prec { PREC_F32 = 0, PREC_F16X3 = 1 };   // igemm arithmetic: fp32 MFMA, or
 // a non-negative value order like unsigned integers).  No atomic is issued on the normal path.  Batch-normalised networks sit orders of
 // magnitude below; the two linear Dense layers (ae_model.py:199-200) have no BatchNorm behind them.
 constexpr float RANGE_LIMIT = 6.0e4f;
+// A NaN counts as out of range too (NaN weights or inputs, inf - inf in a residual add): the running maximum is taken with the IEEE-754-2019
+// `maximum` (v_maximum3_f32 on gfx950: NaN-propagating, one instruction for two new values), the epilogues' ReLU likewise (relu_nan: fmaxf
+// would turn a NaN into 0 and hide it from every later layer), and range_commit raises a NaN as +inf.
+// -DP2P_NO_RANGE_GUARD (A/B builds only, tools/ab_round.sh): the guard compiled out, to MEASURE what it costs.
+__device__ __forceinline__ float relu_nan(float v) { return __builtin_elementwise_maximum(v, 0.f); }
+#ifdef P2P_NO_RANGE_GUARD
+template <typename V4> __device__ __forceinline__ float range_note4(float amax, const V4&) { return amax; }
+__device__ __forceinline__ float range_note1(float amax, float) { return amax; }
+__device__ __forceinline__ void range_commit(unsigned*, float) {}
+#else
+__device__ __forceinline__ float range_note1(float amax, float v) { return __builtin_elementwise_maximum(amax, fabsf(v)); }
 template <typename V4> __device__ __forceinline__ float range_note4(float amax, const V4& v)
 {
-    return fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_elementwise_maximum(amax, fabsf(v[0])), fabsf(v[1])),
+                                         __builtin_elementwise_maximum(fabsf(v[2]), fabsf(v[3])));
 }
 __device__ __forceinline__ void range_commit(unsigned* acc, float amax)
 {
-    if (acc && amax > RANGE_LIMIT) atomicMax(acc, __float_as_uint(amax));
+    if (acc && !(amax <= RANGE_LIMIT)) atomicMax(acc, amax == amax ? __float_as_uint(amax) : 0x7F800000u);
 }
+#endif
 
 constexpr int IGEMM_MAX_TAPS = 25;
 constexpr int IGEMM_BK = 32;
@@ -106,6 +129,30 @@ hipError_t launch_igemm_halo8(const IgemmParams& p, hipStream_t s);
 // igemm_halo8.hip, 8x16 patches like igemm_halo.hip): the "paper" encoder's conv2 / conv3.
 bool igemm_halo_s2_supported(const IgemmParams& p);
 hipError_t launch_igemm_halo_s2(const IgemmParams& p, hipStream_t s);
+
+// One ResNet identity bottleneck block (1x1 -> 3x3 -> 1x1 + residual, resnet50_mod.py:40-73) as ONE kernel (resblock.hip): both
+// intermediates stay in LDS, the block input is read (with its 3x3 halo) and the output written once.  PREC_F16X3; the same bits as the
+// three launches it replaces.  Mixed-object batches: samples [grp[g].sample0, grp[g + 1].sample0) use group g's panels.
+struct ResBlockGroup {
+    const float* w2a;      // split-f16 panels of the block's three layers (pack_conv)
+    const float* w2b;
+    const float* w2c;
+    const float* ss;       // folded BatchNorm of the three layers: [scale 2a F1 | shift 2a F1 | scale 2b F1 | shift 2b F1 | scale 2c C | shift 2c C]
+    int sample0;
+    int pad_;
+};
+struct ResBlockParams {
+    const float* x;        // [N, H, W, C] block input (C = 4 F1) -- also the residual
+    float* out;            // [N, H, W, C]
+    int N, H, W;
+    unsigned x_bytes, wa_bytes, wb_bytes, wc_bytes;      // buffer-descriptor ranges
+    unsigned* range_acc;   // operand-range guard (RANGE_LIMIT); may be null
+    int n_groups;          // >= 1
+    ResBlockGroup grp[IGEMM_MAX_GROUPS + 1];
+};
+bool resblock_supported(int F1, int H, int W);
+int resblock_grid(int F1, int N, int H, int W);        // workgroups of the launch
+hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s);
 
 // Small-batch variant (igemm_stream.hip): one wave per 32x32 / 64x32 output tile, operands streamed global -> registers with a deep
 // software pipeline.  Bit-identical to the batched kernel that serves the layer: every output element is the same chain of MFMAs over

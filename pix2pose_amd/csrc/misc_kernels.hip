@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         for (int e = 0; e < 4; ++e) {
             const int co = cg * CPT + c + e;
             float t = fmaf(acc[c + e], scale[co], shift[co]);
-            if (act == ACT_RELU) t = fmaxf(t, 0.f);
+            if (act == ACT_RELU) t = relu_nan(t);
             else if (act == ACT_LEAKY) t = t > 0.f ? t : t * alpha;
             v[e] = t;
         }

@@ -1,6 +1,7 @@
 // Host-side objects behind the opaque handles of include/p2p_mi355.h.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -31,10 +32,11 @@ struct Model {
     int prec = PREC_F32;
     int device = 0;
     std::map<std::string, ConvLayer> L;
+    std::map<std::string, float*> block_ss;   // identity bottleneck blocks (split-f16 models): folded BatchNorm of the block's three layers in one array (resblock.hip)
     // P2P_PREC_AUTO: a split-f16 model with a strict-fp32 twin of the same weights.  The generator runs split-f16 until an operand-range
     // event (kernels.h: RANGE_LIMIT) is seen on a pass of this object; from then on every pass of the object uses the twin.
     Model* twin = nullptr;
-    mutable bool use_twin = false;
+    mutable std::atomic<bool> use_twin{false};      // written through const handles when a range event is seen; a model may be shared between contexts / threads
     const Model* effective() const { return (use_twin && twin) ? twin : this; }
     ~Model();
 };
@@ -71,7 +73,7 @@ struct Ctx {
     float* xyz_stage = nullptr;
     float* prob_stage = nullptr;
     Pipeline* pipe = nullptr;
-    int dev_part = 0;                     // development builds only (P2P_DEV_SWITCHES): run a part of the generator pass
+    int dev_part = 0;                     // timing builds only (P2P_TIMING_SWITCHES): run a part of the generator pass
     // operand-range guard (kernels.h): device words raised by the epilogues of split-f16 passes.  Word 0: direct forward calls
     // (p2p_predict / p2p_forward_async), words 1.. : one per est_pose batch slot.  range_cur = where the passes being enqueued report.
     unsigned* range_words = nullptr;

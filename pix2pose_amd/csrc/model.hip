@@ -125,13 +125,13 @@ static float f16_to_f32(uint16_t h)
 
 // Development switch: P2P_NO_HALO=1 routes every layer through the generic kernels (igemm.hip, the VALU first layer);
 // tests/test_halo_gpu.py compares the two paths.
-static bool specialised_kernels() { static const bool on = getenv("P2P_NO_HALO") == nullptr; return on; }
+static bool specialised_kernels() { static const bool on = dev_env("P2P_NO_HALO") == nullptr; return on; }
 
 // Launches whose batched kernel would run on at most this many workgroups take the streaming kernel (igemm_stream.hip) instead.
 // P2P_STREAM_WGS=0 switches the route off (tests compare the two routes bit for bit).
 static int stream_max_wgs()
 {
-    static const int v = getenv("P2P_STREAM_WGS") ? atoi(getenv("P2P_STREAM_WGS")) : 64;
+    static const int v = dev_env("P2P_STREAM_WGS") ? atoi(dev_env("P2P_STREAM_WGS")) : 64;
     return specialised_kernels() ? v : 0;
 }
 
@@ -475,6 +475,30 @@ static int build_model(const TensorMap& T, Model& M)
     return P2P_ERR_INVALID_ARG;
 }
 
+// Folded BatchNorm of an identity bottleneck block's three layers in ONE device array, the layout resblock.hip reads:
+// [scale 2a | shift 2a | scale 2b | shift 2b | scale 2c | shift 2c] (F1, F1, F1, F1, 4 F1, 4 F1 floats).  Copied device to device
+// from the layers' own arrays, so both routes multiply by the same numbers.
+static int pack_block_ss(Model& M)
+{
+    if (M.backbone != P2P_BACKBONE_RESNET50 || M.prec != PREC_F16X3) return P2P_OK;
+    for (const char* nm : {"res2b", "res2c", "res3b", "res3c", "res3d"}) {
+        const std::string n = nm;
+        const ConvLayer &a = M.L.at(n + "_2a"), &b = M.L.at(n + "_2b"), &c = M.L.at(n + "_2c");
+        const int F1 = a.Cout, C = c.Cout;
+        float* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, (size_t)(4 * F1 + 2 * C) * sizeof(float)));
+        M.block_ss[n] = d;
+        const float* src[6] = {a.scale, a.shift, b.scale, b.shift, c.scale, c.shift};
+        const int len[6] = {F1, F1, F1, F1, C, C};
+        size_t off = 0;
+        for (int k = 0; k < 6; ++k) {
+            HIP_TRY(hipMemcpy(d + off, src[k], (size_t)len[k] * sizeof(float), hipMemcpyDeviceToDevice));
+            off += len[k];
+        }
+    }
+    return P2P_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // activation workspace
 // ------------------------------------------------------------------------------------------
@@ -763,11 +787,65 @@ static int deconv_layer(Ctx& X, const Model& M, const char* name, const float* i
     return P2P_OK;
 }
 
+// Identity blocks of split-f16 models in one kernel (resblock.hip) when the launch is large enough to fill the chip; small launches (one
+// detection at a time) keep the three streaming launches.  The route depends on the batch size, the bits do not (tests/test_resblock_gpu.py).
+// Development builds: P2P_NO_FUSED_BLOCK=1 keeps the three-launch route.
+static bool fused_blocks() { static const bool on = dev_env("P2P_NO_FUSED_BLOCK") == nullptr; return on && specialised_kernels(); }
+
+static int run_resblock(const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H, int f1, float* out)
+{
+    const ConvLayer &a = M.L.at(n + "_2a"), &b = M.L.at(n + "_2b"), &c = M.L.at(n + "_2c");
+    const int C = 4 * f1;
+    ResBlockParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = in; p.out = out; p.N = N; p.H = H; p.W = H;
+    const size_t xb = (size_t)N * H * H * C * sizeof(float);
+    if (xb >= 0xFFFFFFF0ull) { set_error("run_resblock: tensor exceeds the 4 GB buffer-descriptor range (lower max_batch)"); return P2P_ERR_CAPACITY; }
+    p.x_bytes = (unsigned)xb;
+    p.wa_bytes = (unsigned)((size_t)round_up(a.Cout, 128) * a.K * sizeof(float));
+    p.wb_bytes = (unsigned)((size_t)round_up(b.Cout, 128) * b.K * sizeof(float));
+    p.wc_bytes = (unsigned)((size_t)round_up(c.Cout, 128) * c.K * sizeof(float));
+    p.range_acc = X.range_cur;
+    if (X.grp && X.grp->models.size() > 1) {
+        const GroupCtx& G = *X.grp;
+        const int ng = (int)G.models.size();
+        if (ng > IGEMM_MAX_GROUPS) { set_error("run_resblock: %d object groups exceed IGEMM_MAX_GROUPS", ng); return P2P_ERR_CAPACITY; }
+        for (int g = 0; g < ng; ++g) {
+            const Model& Mg = *G.models[g];
+            if (Mg.prec != PREC_F16X3 || !Mg.block_ss.count(n)) { set_error("run_resblock: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
+            p.grp[g] = {Mg.L.at(n + "_2a").w, Mg.L.at(n + "_2b").w, Mg.L.at(n + "_2c").w, Mg.block_ss.at(n), G.start[g], 0};
+        }
+        p.grp[ng] = {nullptr, nullptr, nullptr, nullptr, G.start[ng], 0};
+        p.n_groups = ng;
+    } else {
+        p.grp[0] = {a.w, b.w, c.w, M.block_ss.at(n), 0, 0};
+        p.grp[1] = {nullptr, nullptr, nullptr, nullptr, N, 0};
+        p.n_groups = 1;
+    }
+    hipStream_t st = X.cur->stream;
+    if (X.profiling) {
+        const double px = (double)N * H * H;
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), 9, 2.0 * px * ((double)C * f1 + 9.0 * f1 * f1 + (double)f1 * C),
+                          4.0 * (2.0 * px * C + (double)C * f1 * 2 + 9.0 * f1 * f1)};      // input once (it is also the residual), output once, the three panels
+        if (!ev.a || !ev.b) return P2P_ERR_HIP;
+        HIP_TRY(hipEventRecord(ev.a, st));
+        HIP_TRY(launch_resblock(p, f1, st));
+        HIP_TRY(hipEventRecord(ev.b, st));
+        X.prof_pending.push_back(ev);
+        return P2P_OK;
+    }
+    HIP_TRY(launch_resblock(p, f1, st));
+    return P2P_OK;
+}
+
 static int res_block(const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H,
                      int Cin, int f1, int stride, bool shortcut, float* out)
 {
     int rc;
     const int Ho = H / stride;
+    if (!shortcut && stride == 1 && M.prec == PREC_F16X3 && Cin == 4 * f1 && fused_blocks() && M.block_ss.count(n) && resblock_supported(f1, H, H) &&
+        resblock_grid(f1, N, H, H) > stream_max_wgs())
+        return run_resblock(M, X, n, in, N, H, f1, out);
     float* ta = X.cur->act["t_a"];
     float* tb = X.cur->act["t_b"];
     if ((rc = conv_layer(X, M.L.at(n + "_2a"), in, N, H, H, Cin, stride, ta, ACT_RELU))) return rc;
@@ -793,7 +871,7 @@ static int res_block(const Model& M, Ctx& X, const std::string& n, const float* 
     return conv_layer(X, M.L.at(n + "_2c"), tb, N, Ho, Ho, f1, 1, out, ACT_RELU, res);
 }
 
-#ifdef P2P_DEV_SWITCHES      // A/B builds only (tools/ab_build.sh model.hip -DP2P_DEV_SWITCHES): timing experiments, results are garbage
+#ifdef P2P_TIMING_SWITCHES      // A/B builds only (tools/ab_build.sh model.hip -DP2P_TIMING_SWITCHES): timing experiments, results are garbage
 #define dev_part() (X.dev_part)      // per context, from P2P_DEV_PART at p2p_ctx_create: 1 = ResNet front only, 2 = everything after it only
 #endif
 
@@ -809,7 +887,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
     const float *s1, *s2, *s3;      // skip tensors and their pixel strides / channel offsets
     int s1_stride, s1_off, s1_C, s2_stride, s2_off, s3_stride, s3_off;
     if (M.backbone == P2P_BACKBONE_RESNET50) {
-#ifdef P2P_DEV_SWITCHES
+#ifdef P2P_TIMING_SWITCHES
         if (dev_part() == 2) goto after_front;
 #endif
         if (M.L.at("conv1").prec == PREC_F16X3) {       // matrix-core first layer: one launch, per-sample panel lookup
@@ -838,7 +916,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         if ((rc = res_block(M, X, "res3b", A["o_a"], n, 16, 512, 128, 1, false, A["o_b"]))) return rc;
         if ((rc = res_block(M, X, "res3c", A["o_b"], n, 16, 512, 128, 1, false, A["o_a"]))) return rc;
         if ((rc = res_block(M, X, "res3d", A["o_a"], n, 16, 512, 128, 1, false, A["f3"]))) return rc;
-#ifdef P2P_DEV_SWITCHES
+#ifdef P2P_TIMING_SWITCHES
         if (dev_part() == 1) return P2P_OK;
     after_front:
 #endif
@@ -998,6 +1076,7 @@ int forward_grouped(Ctx& X, const std::vector<const Model*>& models, const std::
 Model::~Model()
 {
     for (auto& kv : L) free_layer(kv.second);
+    for (auto& kv : block_ss) hipFree(kv.second);
     delete twin;
 }
 
@@ -1065,7 +1144,7 @@ int p2p_ctx_create(int device, int max_batch, p2p_ctx** out)
     c->device = device;
     c->max_batch = max_batch;
     hipError_t e;
-#ifdef P2P_DEV_SWITCHES
+#ifdef P2P_TIMING_SWITCHES
     c->dev_part = getenv("P2P_DEV_PART") ? atoi(getenv("P2P_DEV_PART")) : 0;
     if (const char* cus = getenv("P2P_DEV_CUS")) {      // "lo:hi": the context's stream may only use CUs [lo, hi) (mask bits; KFD deals them round-robin over the XCDs)
         int lo = 0, hi = 256;
@@ -1151,6 +1230,7 @@ int p2p_model_create_ex(p2p_ctx* ctx, const p2p_tensor* tensors, int n_tensors, 
     m->prec = precision == P2P_PREC_F32 ? PREC_F32 : PREC_F16X3;
     m->device = c->device;
     int rc = build_model(T, *m);
+    if (!rc) rc = pack_block_ss(*m);
     if (rc) { delete m; return rc; }
     for (auto& kv : m->L) kv.second.name = kv.first;
     if (precision == P2P_PREC_AUTO) {          // the strict-fp32 twin the object falls back to after an operand-range event

@@ -195,6 +195,6 @@ struct Pipeline {
 // RCCL all-gather of a batch's pose records (comm.hip)
 struct Comm;
 int comm_world(const Comm& C);
-int comm_gather(Ctx& X, Comm& C, Slot& s, hipStream_t ts, int n_max, p2p_pose* gathered);
+int comm_gather(Ctx& X, Comm& C, Slot* s, bool range_event, hipStream_t ts, int n_max, p2p_pose* gathered);
 
 }  // namespace p2p

@@ -1125,6 +1125,14 @@ __global__ void aa_back_range_kernel(CandRange* __restrict__ crange, int n_cand,
 // -> 0, or P2P_ERR_RANGE when a generator pass of the batch stored an activation beyond the split-f16 operand range.  The flag is per batch,
 // not per object: every split-f16 object of the batch that was created with P2P_PREC_AUTO switches to its fp32 twin (*switched = how many did);
 // the blocking caller then runs the batch once more -- if the offender was one of them the second run is clean, otherwise it reports again
+// a pass merged over two batches: its range word m goes to both batches' words (bit patterns of non-negative floats order like unsigned integers)
+__global__ void range_fold_kernel(const unsigned* m, unsigned* a, unsigned* b)
+{
+    const unsigned v = *m;
+    if (v > *a) *a = v;
+    if (v > *b) *b = v;
+}
+
 static int range_verdict(const Slot& s, int* switched)
 {
     *switched = 0;
@@ -1169,11 +1177,13 @@ static void finish_batch(const Slot& s, p2p_pose* poses)
         if (opt.det_mask && opt.mask_stats) {
             const long long inter = (long long)hstat[3 * i], dc = (long long)hstat[3 * i + 1], vc = (long long)hstat[3 * i + 2];
             opt.mask_stats[3 * o] = inter; opt.mask_stats[3 * o + 1] = dc + vc - inter; opt.mask_stats[3 * o + 2] = vc;
+            poses[o].mask_stats[0] = inter; poses[o].mask_stats[1] = dc + vc - inter; poses[o].mask_stats[2] = vc;      // the record carries them too
         }
     }
 }
 
-static int forward_parts(Ctx& X, hipStream_t st, const Slot* const* parts, const int* per_det, int n_parts, const float* xin, float* yout)
+static int forward_parts(Ctx& X, hipStream_t st, const Slot* const* parts, const int* per_det, int n_parts, const float* xin, float* yout,
+                         int range_word = -1)
 {
     // (model, count) runs of the concatenated, object-sorted parts
     std::vector<const Model*> ms;
@@ -1189,7 +1199,9 @@ static int forward_parts(Ctx& X, hipStream_t st, const Slot* const* parts, const
             same_backbone = same_backbone && m->backbone == ms[0]->backbone;
         }
     X.cur = &X.lane[0];
-    X.range_cur = X.range_words + parts[0]->range_word;      // operand-range events of this pass are reported with parts[0]'s batch
+    // operand-range events of this pass are reported with parts[0]'s batch -- or, for a pass MERGED over two batches, to a word of its own
+    // that is folded into both batches' words afterwards (an event of the merged pass cannot be attributed to one of them)
+    X.range_cur = X.range_words + (range_word >= 0 ? range_word : parts[0]->range_word);
     bool same_prec = true;
     for (const Model* m : ms) same_prec = same_prec && m->prec == ms[0]->prec;
     if (ms.size() == 1) return forward_async(X, *ms[0], xin, cnt[0], yout);
@@ -1504,7 +1516,7 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
     }
 
     // -- correspondences, PnP-RANSAC, selection
-    static const bool corr_split = getenv("P2P_CORR_SPLIT") == nullptr || atoi(getenv("P2P_CORR_SPLIT")) != 0;      // development switch (A/B)
+    static const bool corr_split = dev_env("P2P_CORR_SPLIT") == nullptr || atoi(dev_env("P2P_CORR_SPLIT")) != 0;      // development switch (A/B)
     if ((n * K <= 16 || SL.max_side > 192) && corr_split) {        // evaluate on CORR_SEG CUs per candidate, then compact (see cand_eval_kernel)
         hipLaunchKernelGGL(cand_eval_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(), d_cr, aa);
         hipLaunchKernelGGL(cand_compact_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(),
@@ -1522,7 +1534,7 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
         HIP_TRY(hipEventRecord(P.corr_ready, st));
         HIP_TRY(hipStreamWaitEvent(ts, P.corr_ready, 0));
     }
-#ifdef P2P_DEV_SWITCHES      // tools/ab_build.sh pipeline.hip -DP2P_DEV_SWITCHES: never in the shipped library (poses are garbage with it)
+#ifdef P2P_TIMING_SWITCHES      // tools/ab_build.sh pipeline.hip -DP2P_TIMING_SWITCHES: never in the shipped library (poses are garbage with it)
     static const bool skip_pnp = getenv("P2P_SKIP_PNP") != nullptr;      // timing experiment: what the PnP tail costs a stream of batches
 #else
     constexpr bool skip_pnp = false;
@@ -1637,10 +1649,14 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         if (PS->same_backbone && SL.same_backbone && m0->backbone == m1->backbone) {
             const Slot* parts[2] = {PS, &SL};
             const int per[2] = {PS->K, 1};
-            if ((rc = forward_parts(X, st, parts, per, 2, PS->x2.as<float>(), PS->y2.as<float>()))) return rc;
+            // the merged pass reports to its own range word (3 + slot), folded into BOTH batches' words behind it: PS's stage-1 events stay PS's,
+            // the newcomer's word starts from the merged pass only
+            const int mw = 3 + (int)(&SL - P.slot);
+            HIP_TRY(hipMemsetAsync(X.range_words + mw, 0, sizeof(unsigned), st));
+            if ((rc = forward_parts(X, st, parts, per, 2, PS->x2.as<float>(), PS->y2.as<float>(), mw))) return rc;
             y1 = PS->y2.as<float>() + (size_t)PS->n * PS->K * 16384 * 4;
-            // the merged pass reported to PS's range word: the newcomer inherits it (over-reports PS's stage-1 events, never misses its own)
-            HIP_TRY(hipMemcpyAsync(SL.range_dev, PS->range_dev, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(range_fold_kernel, dim3(1), dim3(1), 0, st, X.range_words + mw, PS->range_dev, SL.range_dev);
+            HIP_TRY(hipGetLastError());
             if ((rc = enqueue_tail(P, *PS, st, true))) return rc;
         } else {
             if ((rc = flush_stage2(X, P, *PS, st, true))) return rc;
@@ -1681,8 +1697,9 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         HIP_TRY(hipMemcpyAsync(hres.data(), SL.results.p, sizeof(PnpResult) * n * K, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
-    finish_batch(SL, poses);
     {
+        // the verdict BEFORE anything is handed over: the masks / images / sums of a pass that left the operand range never reach the caller's
+        // buffers (with mask_prezeroed the repeated run only rewrites the rows of detections that succeed then)
         int switched = 0;
         if ((rc = range_verdict(SL, &switched))) {
             static thread_local int depth = 0;
@@ -1693,6 +1710,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
             return rc;
         }
     }
+    finish_batch(SL, poses);
     for (int i = 0; i < n; ++i) {
         const int o = SL.perm[i];
         if (opt.dbg_x1) memcpy(opt.dbg_x1 + (size_t)o * 16384 * 3, hx1.data() + (size_t)i * 16384 * 3, 16384 * 3 * 4);
@@ -1727,29 +1745,42 @@ __global__ __launch_bounds__(256) void back_resize_probe_kernel(const double* __
 }
 
 // comm != nullptr: the records of every rank's batch are all-gathered (device to device, on the tail stream, behind this batch's tail)
-// into gathered[world][n_max] before anything is handed to the host
+// into gathered[world][n_max].  The collective is entered on EVERY path once the arguments name a communicator -- a rank that returned
+// early would leave its peers blocked in ncclAllGather for good -- with an all-padding block when this rank has nothing valid to send:
+// no batch this step (ticket == P2P_TICKET_NONE: an empty shard), an unknown ticket, a batch larger than n_max, a failed stage-2 flush.
+// The operand-range verdict is taken BEFORE the records are packed: a batch that left the split-f16 range travels as P2P_POSE_RANGE
+// records, so the peers see that those detections exist and that their poses are not to be used; this rank gets P2P_ERR_RANGE.
 static int collect_est_pose(Ctx& X, int ticket, p2p_pose* poses, Comm* comm = nullptr, int n_max = 0, p2p_pose* gathered = nullptr)
 {
-    if (!X.pipe) { set_error("no batch was submitted"); return P2P_ERR_INVALID_ARG; }
-    for (Slot& s : X.pipe->slot)
-        if (s.ticket == ticket) {
-            if (comm && s.n > n_max) { set_error("p2p_est_pose_collect_gathered: the batch holds %d detections, n_max is %d", s.n, n_max); return P2P_ERR_INVALID_ARG; }
-            if (s.stage2_pending) {            // no later submit picked the stage-2 pass up: run it by itself
-                int rc = flush_stage2(X, *X.pipe, s, X.lane[0].stream, true);
-                if (rc) return rc;
-            }
-            if (comm) {
-                int rc = comm_gather(X, *comm, s, X.pipe->tail_stream, n_max, gathered);
-                if (rc) return rc;
-            }
-            HIP_TRY(hipEventSynchronize(s.done));
-            finish_batch(s, poses);
-            s.ticket = -1;
-            int switched = 0;
-            return range_verdict(s, &switched);       // P2P_ERR_RANGE: the poses are not to be used; with P2P_PREC_AUTO objects a re-submission runs in fp32
-        }
-    set_error("ticket %d is not in flight", ticket);
-    return P2P_ERR_INVALID_ARG;
+    Slot* S = nullptr;
+    int local = P2P_OK;
+    if (!(comm && ticket == P2P_TICKET_NONE)) {
+        if (X.pipe)
+            for (Slot& s : X.pipe->slot)
+                if (s.ticket == ticket && ticket >= 0) S = &s;
+        if (!S) { set_error(X.pipe ? "ticket %d is not in flight" : "no batch was submitted (ticket %d)", ticket); local = P2P_ERR_INVALID_ARG; }
+    }
+    if (local && !comm) return local;
+    if (S && comm && S->n > n_max) {
+        set_error("p2p_est_pose_collect_gathered: the batch holds %d detections, n_max is %d (the ticket stays in flight)", S->n, n_max);
+        local = P2P_ERR_INVALID_ARG;
+    }
+    if (S && !local && S->stage2_pending) local = flush_stage2(X, *X.pipe, *S, X.lane[0].stream, true);      // no later submit picked the stage-2 pass up
+    int verdict = P2P_OK;
+    if (S && !local) {
+        if (hipEventSynchronize(S->done) != hipSuccess) { set_error("hipEventSynchronize(batch done) failed"); local = P2P_ERR_HIP; }
+        else { int switched = 0; verdict = range_verdict(*S, &switched); }
+    }
+    if (comm) {
+        const int rc = comm_gather(X, *comm, (S && !local) ? S : nullptr, verdict != P2P_OK, X.pipe ? X.pipe->tail_stream : X.stream, n_max, gathered);
+        if (rc && !local) local = rc;
+    }
+    if (local) return local;
+    if (!S) return P2P_OK;                       // empty shard: joined the collective, nothing of its own to hand over
+    // P2P_ERR_RANGE: nothing of the pass is handed over (poses, masks, images stay untouched); with P2P_PREC_AUTO objects a re-submission runs in fp32
+    if (verdict == P2P_OK) finish_batch(*S, poses);
+    S->ticket = -1;
+    return verdict;
 }
 
 }  // namespace p2p
@@ -1783,7 +1814,8 @@ int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses)
 
 int p2p_est_pose_collect_gathered(p2p_ctx* ctx, p2p_comm* comm, int ticket, p2p_pose* poses, int n_max, p2p_pose* gathered)
 {
-    if (!ctx || !comm || !poses || !gathered || n_max < 1) { set_error("p2p_est_pose_collect_gathered: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    // (argument errors are local: nothing was enqueued and the caller's peers are its own to unblock; poses may be null for an empty shard)
+    if (!ctx || !comm || !gathered || n_max < 1 || (!poses && ticket != P2P_TICKET_NONE)) { set_error("p2p_est_pose_collect_gathered: bad arguments"); return P2P_ERR_INVALID_ARG; }
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     HIP_TRY(hipSetDevice(c->device));
     return collect_est_pose(*c, ticket, poses, reinterpret_cast<Comm*>(comm), n_max, gathered);

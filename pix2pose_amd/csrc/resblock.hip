@@ -1,0 +1,483 @@
+// One ResNet identity bottleneck block as ONE kernel (gfx950, PREC_F16X3):
+//
+//     t_a = relu(bn(conv1x1(x)))      "2a"   C  -> F1      resnet50_mod.py:57-61
+//     t_b = relu(bn(conv3x3(t_a)))    "2b"   F1 -> F1      resnet50_mod.py:63-66
+//     out = relu(bn(conv1x1(t_b)) + x) "2c"  F1 -> C = 4 F1, residual add, ReLU      resnet50_mod.py:68-73
+//
+// As three launches (igemm.hip / igemm_halo.hip / igemm.hip) every block sends its activations across HBM three times: the 1x1 layers
+// are bandwidth-bound (0.47 of the HBM peak, 12.8 % of a pass's kernel time) and only removing bytes helps them.  Here a workgroup owns a
+// PY x 16 patch of one sample and keeps both intermediates in LDS:
+//
+//   phase A  2a on the (PY + 2) x HPX halo of the patch: the block input streams through LDS in 32-channel slices (split hi/lo by the
+//            loader exactly as igemm.hip does), accumulators in registers; epilogue: BN + ReLU, ZERO for halo pixels outside the image
+//            (the 3x3 convolution pads t_a, not x), split hi/lo, written as the [hi x32 | lo x32] record image igemm_halo.hip stages
+//   phase B  2b from that image: (slice, tap) K order, only the weight tile moves per K-step; epilogue: BN + ReLU, split, second image
+//   phase C  2c from the second image in 128-channel chunks; epilogue through an LDS C tile as in igemm.hip: BN, + x (re-read: it left
+//            L2 long ago at this footprint, the memory-side cache serves it), ReLU, float4 stores of whole 512-byte pixel rows
+//
+// Bits: every output element is the same chain of v_mfma_f32_32x32x16_f16 over the same K-step order as in the three-launch route -- 2a:
+// slices in order; 2b: (slice, tap); 2c: slices in order; (al bh, ah bl, ah bh) inside a step; the same epilogue expressions; the same
+// cvt_pkrtz / round-to-nearest split of the fp32 intermediate -- so the routes agree bit for bit (tests/test_resblock_gpu.py), and a
+// detection's bits do not depend on the batch it travels in (small launches keep the streaming route).  Phases A and B run the MFMA in
+// transposed orientation (weights as the row operand): a lane then owns 4 consecutive channels of one pixel and the split image is
+// written with 8-byte stores; swapping the operand roles changes no bit.
+//
+// Shapes: F1 = 64  (res2: 32x32x256): 8 x 16 patch, 10 x 18 halo (192 GEMM rows, 12 idle), LDS 70.7 KB
+//         F1 = 128 (res3: 16x16x512): 4 x 16 patch, 6 x 16 halo -- the image is one patch wide, so the columns left and right of it are
+//                  padding: lanes whose tap falls there read a zero record instead of a halo column --, LDS 71.8 KB
+// Two workgroups per CU either way (their phases interleave: one's memory-bound phase A under the other's MFMA-bound phase B).
+#include "kernels.h"
+
+namespace p2p {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int REC = 144;        // activation record: [hi f16 x32 | lo f16 x32 | 16 B pad] (igemm_halo.hip)
+constexpr int WREC = 128;       // weight row of a K-step: [hi x32 | lo x32], 16-byte chunk c of row r at c ^ ((r >> 1) & 7)
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// hi = f16(v) toward zero (cvt_pkrtz), lo = f16(v - hi) to nearest: the loaders' split (igemm.hip lstore, igemm_halo.hip hstore)
+__device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo)
+{
+    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    fp16x2 l01, l23;
+    l01[0] = (__fp16)(v[0] - (float)h01[0]); l01[1] = (__fp16)(v[1] - (float)h01[1]);
+    l23[0] = (__fp16)(v[2] - (float)h23[0]); l23[1] = (__fp16)(v[3] - (float)h23[1]);
+    hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+
+template <int F1, int PY, int HPX>
+__global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p)
+{
+    constexpr int C = 4 * F1;
+    constexpr int SA = C / 32;                    // K-steps of 2a
+    constexpr int SB = F1 / 32;                   // channel slices of t_a / t_b
+    constexpr int NCH = C / 128;                  // 128-channel output chunks of 2c
+    constexpr int HX0 = HPX == 18 ? 1 : 0;        // halo columns left of the patch (0: the image is one patch wide)
+    constexpr int HPY = PY + 2, NPA = HPY * HPX, MA = (NPA + 31) / 32;
+    constexpr int PITCH = (HPX * REC + 255) / 256 * 256;      // halo row pitch: a multiple of 16 slots (igemm_halo.hip: LDS layout)
+    constexpr int TSLICE = HPY * PITCH, T_BYTES = SB * TSLICE;
+    constexpr int NPIX = PY * 16, MT = PY / 2;    // patch pixels; their 32-row m-tiles (two patch rows each)
+    constexpr int T2SLICE = NPIX * REC, T2_BYTES = SB * T2SLICE;
+    constexpr int XS_BYTES = MA * 32 * REC;
+    constexpr int WA_BYTES = F1 * WREC, WB_BYTES = F1 * WREC;
+    constexpr int WC_BYTES = 2 * 128 * WREC;      // two K-steps of a 128-row chunk of the 2c panel
+    constexpr int NST = SB / 2;                   // such stages per chunk
+    constexpr int TMC = 2, TNC = MT == 4 ? 2 : 1, WGMC = MT / TMC, WGNC = 4 / WGMC;      // phase-C wave tiling (igemm.hip's)
+    constexpr int CLD = 128 + 4;
+    constexpr int CS_BYTES = TMC * 32 * CLD * 4;
+    constexpr int ZERO_OFF = cmax(cmax(XS_BYTES + WA_BYTES, T_BYTES + WB_BYTES), T2_BYTES + cmax(WC_BYTES, CS_BYTES));
+    constexpr int SMEM = ZERO_OFF + 128;
+    static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
+    static_assert(MA % (F1 == 64 ? 2 : 1) == 0 && (F1 == 64 || F1 == 128) && (PY == 8 || PY == 4), "shapes");
+    __shared__ __attribute__((aligned(256))) char smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+
+    // XCD-aware tile order (block b runs on XCD b % 8): contiguous runs of patches per XCD
+    const int tiles_x = p.W / 16, tiles_y = p.H / PY;
+    int t;
+    {
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int x0 = (t % tiles_x) * 16; t /= tiles_x;
+    const int y0 = (t % tiles_y) * PY;
+    const int n = t / tiles_y;
+
+    int g = 0;                                   // mixed-object batches: groups are runs of samples
+    while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= n) ++g;
+    const float* ss = p.grp[g].ss;               // [s2a F1 | h2a F1 | s2b F1 | h2b F1 | s2c C | h2c C]
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wa = __builtin_amdgcn_make_buffer_rsrc((void*)p.grp[g].w2a, 0, p.wa_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wb = __builtin_amdgcn_make_buffer_rsrc((void*)p.grp[g].w2b, 0, p.wb_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc((void*)p.grp[g].w2c, 0, p.wc_bytes, 0x00020000);
+
+    if (tid < 8) *reinterpret_cast<f32x4*>(smem + ZERO_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight loader (all phases): rows (tid >> 3) + 32 j, 16-byte segment tid & 7, swizzled chunk
+    const int lrow = tid >> 3, lseg = tid & 7;
+    const int w_dst = lrow * WREC + ((lseg ^ ((lrow >> 1) & 7)) << 4);
+    float amax = 0.f;                             // operand-range guard (kernels.h): t_a, t_b and the block output
+
+    // =========================================================================================== phase A: t_a = relu(bn(W2a x)) on the halo
+    f32x16 accA[3];                               // one n-tile (32 channels) x three m-tiles (96 halo pixels) per wave
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[i][r] = 0.f;
+    constexpr int WNA = F1 / 32 >= 4 ? 4 : F1 / 32, WMA = 4 / WNA;       // waves along channels / along halo pixels
+    static_assert(MA == 3 * WMA, "three m-tiles per wave");
+    const int ntA = wave % WNA, mt0A = (wave / WNA) * 3;
+    {
+        char* Xs = smem;
+        char* Was = smem + XS_BYTES;
+        unsigned x_off[MA];
+        int x_dst[MA];
+#pragma unroll
+        for (int j = 0; j < MA; ++j) {
+            // float4 idx = tid + 256 j -> quad idx & 7 of halo pixel perm(idx >> 3): consecutive octets of lanes take pixels hp and hp + 4
+            // (two pixels per 16-lane store group collide unless they are 4 records apart, igemm_halo.hip)
+            const int idx = tid + 256 * j;
+            const int t8 = idx >> 3, q = idx & 7;
+            const int hp = (t8 & ~7) | ((t8 & 1) << 2) | ((t8 >> 1) & 3);
+            const int hy = hp / HPX, hx = hp - hy * HPX;
+            const int iy = y0 - 1 + hy, ix = x0 - HX0 + hx;
+            const bool ok = hp < NPA && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            x_off[j] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * C + q * 4) * 4) : OOB;
+            x_dst[j] = hp * REC + q * 8;
+        }
+        unsigned wa_off[F1 / 32];
+#pragma unroll
+        for (int j = 0; j < F1 / 32; ++j) wa_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)C + (unsigned)lseg * 4u) * 4u;
+        f32x4 rx[MA], rw[F1 / 32];
+        auto gload = [&](int s) {
+#pragma unroll
+            for (int j = 0; j < MA; ++j)
+                rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[j] == OOB ? OOB : x_off[j] + (unsigned)s * 128u, 0, 0));
+#pragma unroll
+            for (int j = 0; j < F1 / 32; ++j) rw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wa, wa_off[j], s * 128, 0));
+        };
+        auto lstore = [&]() {
+#pragma unroll
+            for (int j = 0; j < MA; ++j) {
+                uint2 hi, lo;
+                split4(rx[j], hi, lo);
+                *reinterpret_cast<uint2*>(Xs + x_dst[j]) = hi;
+                *reinterpret_cast<uint2*>(Xs + x_dst[j] + 64) = lo;
+            }
+#pragma unroll
+            for (int j = 0; j < F1 / 32; ++j) *reinterpret_cast<f32x4*>(Was + w_dst + 32 * j * WREC) = rw[j];
+        };
+        gload(0);
+        lstore();
+        __syncthreads();
+        const char* Xf = Xs + (mt0A * 32 + li) * REC + lk * 16;
+        const char* Wf = Was + (ntA * 32 + li) * WREC;
+        int w_sw[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) w_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
+        for (int s = 0; s < SA; ++s) {
+            const bool more = s + 1 < SA;
+            if (more) gload(s + 1);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][0]);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][1]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(Xf + i * 32 * REC + kb * 32);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(Xf + i * 32 * REC + kb * 32 + 64);
+                    accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accA[i], 0, 0, 0);      // (al bh, ah bl, ah bh) with a = activation, b = weight,
+                    accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accA[i], 0, 0, 0);      // operand roles swapped: D[channel][pixel]
+                    accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accA[i], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (more) {
+                lstore();
+                __syncthreads();
+            }
+        }
+    }
+
+    // first weight tile of 2b: requested now, staged beside the t_a image (that region is free in phase A)
+    unsigned wb_off[F1 / 32];
+#pragma unroll
+    for (int j = 0; j < F1 / 32; ++j) wb_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)(9 * F1) + (unsigned)lseg * 4u) * 4u;
+    f32x4 rwb[F1 / 32];
+    auto wbload = [&](int tap, int chunk) {
+        const int koff = (tap * SB + chunk) * 128;                           // the panel's K order is (tap, slice)
+#pragma unroll
+        for (int j = 0; j < F1 / 32; ++j) rwb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wb, wb_off[j], koff, 0));
+    };
+    char* Wbs = smem + T_BYTES;
+    auto wbstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < F1 / 32; ++j) *reinterpret_cast<f32x4*>(Wbs + w_dst + 32 * j * WREC) = rwb[j];
+    };
+    wbload(0, 0);
+
+    // ---- epilogue A: lane = halo pixel mt * 32 + li, channels ntA * 32 + 8 g + 4 lk + {0..3}; the image replaces the staging buffers
+    //      (everyone left the K loop through its last barrier)
+    {
+        char* T = smem + ntA * TSLICE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hp = (mt0A + i) * 32 + li;
+            const int hy = hp / HPX, hx = hp - hy * HPX;
+            const int iy = y0 - 1 + hy, ix = x0 - HX0 + hx;
+            const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            char* dst = T + hy * PITCH + hx * REC + lk * 8;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c = ntA * 32 + 8 * gq + 4 * lk;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + F1 + c);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu_nan(fmaf(accA[i][4 * gq + e], sc[e], sh[e]));
+                amax = range_note4(amax, v);
+                if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};                  // the 3x3 convolution zero-pads t_a
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                if (hp < NPA) {
+                    *reinterpret_cast<uint2*>(dst + gq * 16) = hi;
+                    *reinterpret_cast<uint2*>(dst + gq * 16 + 64) = lo;
+                }
+            }
+        }
+    }
+    wbstore();
+    __syncthreads();
+
+    // =========================================================================================== phase B: t_b = relu(bn(W2b * t_a)), 3x3
+    f32x16 accB[2];                               // one n-tile x two m-tiles (four patch rows) per wave
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accB[i][r] = 0.f;
+    constexpr int WNB = WNA, WMB = 4 / WNB;
+    static_assert(MT == 2 * WMB, "two m-tiles per wave");
+    const int ntB = wave % WNB, mt0B = (wave / WNB) * 2;
+    {
+        // X fragment of m-tile i: patch rows 2 i + (li >> 4), column li & 15; tap (dy, dx) = constant shift (dy + 1) PITCH + (dx + HX0) REC.
+        // HPX == 16: the image is one patch wide -- a lane whose tap column falls outside reads the zero record
+        const int xbase = (li >> 4) * PITCH + (li & 15) * REC + lk * 16;
+        const char* Wf = Wbs + (ntB * 32 + li) * WREC;
+        int w_sw[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) w_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
+        int tap = 0, chunk = 0;
+        constexpr int TOTAL = SB * 9;
+        for (int ks = 0; ks < TOTAL; ++ks) {
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == 9) { ntap = 0; ++nchunk; }
+            const bool more = ks + 1 < TOTAL;
+            if (more) wbload(ntap, nchunk);
+            const int ky = tap / 3, kx = tap - ky * 3;                        // tap t = kh * 3 + kw at (kh - 1, kw - 1)   (pack_conv)
+            const int shift = chunk * TSLICE + ky * PITCH + (kx - 1 + HX0) * REC;
+            int xo[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xo[i] = xbase + shift + (mt0B + i) * 2 * PITCH;
+                if (HPX == 16) {
+                    const int col = (li & 15) + kx - 1;
+                    if ((unsigned)col > 15u) xo[i] = ZERO_OFF + lk * 16;
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][0]);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][1]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32 + 64);
+                    accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accB[i], 0, 0, 0);
+                    accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accB[i], 0, 0, 0);
+                    accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accB[i], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (more) {
+                wbstore();
+                __syncthreads();
+            }
+            tap = ntap; chunk = nchunk;
+        }
+    }
+
+    // weight loader of 2c: a stage = K-steps (2 st, 2 st + 1) of the 128 rows of chunk q: 8 float4 per thread
+    unsigned wc_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wc_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)F1 + (unsigned)lseg * 4u) * 4u;
+    f32x4 rwc[2][4];
+    auto wcload = [&](int q, int st) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rwc[k2][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wc, wc_off[j] + (unsigned)(q * 128 * F1 * 4), (2 * st + k2) * 128, 0));
+    };
+    char* Wcs = smem + T2_BYTES;
+    auto wcstore = [&]() {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(Wcs + k2 * 128 * WREC + w_dst + 32 * j * WREC) = rwc[k2][j];
+    };
+    wcload(0, 0);
+
+    // ---- epilogue B: the t_b image replaces the t_a image (everyone is past the last barrier of the K loop)
+    {
+        char* T2 = smem + ntB * T2SLICE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = T2 + ((mt0B + i) * 32 + li) * REC + lk * 8;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c = ntB * 32 + 8 * gq + 4 * lk;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + 2 * F1 + c);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + 3 * F1 + c);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu_nan(fmaf(accB[i][4 * gq + e], sc[e], sh[e]));
+                amax = range_note4(amax, v);
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<uint2*>(dst + gq * 16) = hi;
+                *reinterpret_cast<uint2*>(dst + gq * 16 + 64) = lo;
+            }
+        }
+    }
+    wcstore();
+    __syncthreads();
+
+    // =========================================================================================== phase C: out = relu(bn(W2c t_b) + x)
+    {
+        const int wm = wave / WGNC, wn = wave % WGNC;
+        const char* Af = smem + (wm * TMC * 32 + li) * REC + lk * 16;
+        const char* Bf = Wcs + (wn * TNC * 32 + li) * WREC;
+        int w_sw[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) w_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
+        // epilogue ownership (igemm.hip): thread = 4 consecutive channels c4 of rows r0 + 8 it of the pass's 64-row C tile
+        float* Cs = reinterpret_cast<float*>(Wcs);
+        const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+        constexpr int NIT = TMC * 32 / 8;
+        for (int q = 0; q < NCH; ++q) {
+            // residual rows of this chunk: requested before the MFMAs.  Row r0 + 8 it of pass h is patch pixel (4 h + (it >> 1), r0 + 8 (it & 1))
+            // (pass 0's rows now; a second pass's rows while pass 0 is stored)
+            f32x4 rs[NIT];
+            const unsigned obase = (unsigned)(((n * p.H + y0) * p.W + x0 + r0) * C + q * 128 + c4);      // elements: tensors are < 2^30 floats
+            const unsigned orow = (unsigned)(p.W * C);
+            auto rsload = [&](int h) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    rs[it] = *reinterpret_cast<const f32x4*>(p.x + (obase + (unsigned)(4 * h + (it >> 1)) * orow + (unsigned)(8 * (it & 1) * C)));
+            };
+            rsload(0);
+            f32x16 acc[TMC][TNC];
+#pragma unroll
+            for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                for (int j = 0; j < TNC; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int st = 0; st < NST; ++st) {
+                const bool more = st + 1 < NST || q + 1 < NCH;
+                if (more) wcload(st + 1 < NST ? q : q + 1, st + 1 < NST ? st + 1 : 0);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        f16x8 ah[TMC], al[TMC], bh[TNC], bl[TNC];
+#pragma unroll
+                        for (int i = 0; i < TMC; ++i) {
+                            ah[i] = *reinterpret_cast<const f16x8*>(Af + (2 * st + k2) * T2SLICE + i * 32 * REC + kb * 32);
+                            al[i] = *reinterpret_cast<const f16x8*>(Af + (2 * st + k2) * T2SLICE + i * 32 * REC + kb * 32 + 64);
+                        }
+#pragma unroll
+                        for (int j = 0; j < TNC; ++j) {
+                            bh[j] = *reinterpret_cast<const f16x8*>(Bf + k2 * 128 * WREC + j * 32 * WREC + w_sw[kb][0]);
+                            bl[j] = *reinterpret_cast<const f16x8*>(Bf + k2 * 128 * WREC + j * 32 * WREC + w_sw[kb][1]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                            for (int j = 0; j < TNC; ++j) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                            }
+                    }
+                __syncthreads();                  // everyone is done reading the weight stage
+                if (st + 1 < NST) {
+                    wcstore();
+                    __syncthreads();
+                }
+            }
+            // epilogue of the chunk through the (now free) weight stage: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + 4 * F1 + q * 128 + c4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + 4 * F1 + C + q * 128 + c4);
+#pragma unroll
+            for (int h = 0; h < WGMC; ++h) {
+                if (wm == h) {
+#pragma unroll
+                    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNC; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD + (wn * TNC + j) * 32 + li] = acc[i][j][r];
+                }
+                __syncthreads();
+                f32x4 o[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + 8 * it) * CLD + c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rs[it][e];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
+                    amax = range_note4(amax, v);
+                    o[it] = v;
+                }
+                if (h + 1 < WGMC) rsload(h + 1);          // the next pass's residual rows fly under this pass's stores
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const f32x4 v = o[it];
+                    *reinterpret_cast<f32x4*>(p.out + (obase + (unsigned)(4 * h + (it >> 1)) * orow + (unsigned)(8 * (it & 1) * C))) = v;
+                }
+                __syncthreads();                  // the C tile is free again (next pass / next chunk's weight stage)
+            }
+            if (q + 1 < NCH) {
+                wcstore();
+                __syncthreads();
+            }
+        }
+    }
+    range_commit(p.range_acc, amax);
+}
+
+}  // namespace
+
+// (F1, H, W) of the ResNet-50 front's identity blocks: res2b/c (64, 32, 32), res3b/c/d (128, 16, 16)
+bool resblock_supported(int F1, int H, int W)
+{
+    return (F1 == 64 && H % 8 == 0 && W % 16 == 0 && W > 16) || (F1 == 128 && H % 4 == 0 && W == 16);
+}
+
+int resblock_grid(int F1, int N, int H, int W) { return N * (H / (F1 == 64 ? 8 : 4)) * (W / 16); }
+
+hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s)
+{
+    if (!resblock_supported(F1, p.H, p.W)) return hipErrorInvalidValue;
+    const int grid = resblock_grid(F1, p.N, p.H, p.W);
+    if (F1 == 64) hipLaunchKernelGGL((resblock_kernel<64, 8, 18>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((resblock_kernel<128, 4, 16>), dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace p2p

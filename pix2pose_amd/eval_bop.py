@@ -69,6 +69,19 @@ def group_targets(targets):
     return out
 
 
+def _resize_generation(cfg: dict) -> int:
+    """cfg key ``skimage`` ("0.14" | "0.15" | "0.16" | "0.17" | "0.18": the scikit-image the reference environment resolves to -- the
+    reference's requirements.txt does not pin it) or the older ``resize_anti_aliasing`` (bool / 0-2).  Neither: generation 0, with a
+    warning that it is the one generation no real library in the build image can check."""
+    from . import runtime
+    if "skimage" in cfg:
+        return runtime.resize_generation(str(cfg["skimage"]))
+    if "resize_anti_aliasing" in cfg:
+        return runtime.resize_generation(cfg["resize_anti_aliasing"])
+    runtime.warn_unpinned_generation("eval_bop cfg (key 'skimage')")
+    return 0
+
+
 # ---------------------------------------------------------------------------------- per-image logic
 def select_detections(rois, obj_ids, obj_id_targets, inst_counts, cand_factor):
     """tools/5_evaluation_bop_basic.py:289-300: skip (-1,-1) rois and non-target objects; stop
@@ -184,11 +197,17 @@ class FramePrefetcher:
 
 # ---------------------------------------------------------------------------------- driver
 def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".", batch_images: int = 32,
-        detect_type: str = "rcnn", est_pose_kwargs=None, shard=None, write_csv: bool = True, inject=None):
+        detect_type: str = "rcnn", est_pose_kwargs=None, shard=None, write_csv: bool = True, inject=None, make_gather=None):
     """Evaluate a pre-dumped detection stream.  Returns the result rows (also written as CSV when
     cfg['path_to_output'] is set).  shard = (rank, world): only every world-th image of the target list, starting at rank;
     every row carries "_order" = (position of its image in the full target list, rank inside the image) so that the shards'
-    rows merge back into the single-process order.  inject (tests): {"key": [N, 2] (image position in the target list, detection
+    rows merge back into the single-process order.
+    make_gather (with shard; a callable taking the runtime Context -> parallel.CabiPoseGather / TorchPoseGather): LOCKSTEP mode.
+    Every rank walks the same number of steps (the longest shard's), and every pooled batch is collected through ONE collective of
+    pose records per step -- p2p_est_pose_collect_gathered over RCCL in the C ABI -- which a rank whose images have run out (or whose
+    chunk holds no detection: the ragged loop of tools/5_evaluation_bop_basic.py:289-323) joins as an empty shard.  The gathered
+    records carry the score_type-2 mask sums, and every rank holds the whole dump, so every rank builds the rows of ALL ranks: the
+    returned rows are then the complete, merged result on every rank.  inject (tests): {"key": [N, 2] (image position in the target list, detection
     index in the image), "inject1": [N,128,128,4], "inject2": [N,K,128,128,4]} -- decoder maps that replace the generator output
     of the listed detections, the way bench.py and the parity tests drive the pipeline with random-weight networks."""
     from . import runtime, weights as W
@@ -207,9 +226,8 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
         specs.append(runtime.ObjectSpec(gen, model_params_to_obj_param(dump["norm_factor"][str(mid)]), th_o[m], th_i))
     by_image = {(im["scene_id"], im["im_id"]): im for im in dump["images"]}
     rows = []
-    tlist = [t + [gi] for gi, t in enumerate(group_targets(dump["targets"]))]
-    if shard is not None:
-        tlist = tlist[shard[0]::shard[1]]
+    full_tlist = [t + [gi] for gi, t in enumerate(group_targets(dump["targets"]))]
+    tlist = full_tlist[shard[0]::shard[1]] if shard is not None else full_tlist
 
     def prepare(chunk):
         frames, dets, det_masks, owners = [], [], [], []
@@ -235,22 +253,30 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
                         raise ValueError("score_type 2 needs detector masks for scene %s image %s" % (scene_id, im_id))
         return frames, dets, det_masks, owners
 
-    def finish(job):
-        chunk, owners, pending, t1, _held = job          # _held: injected maps stay alive until the batch is collected
-        poses = pending.collect()
-        ex = pending.extras
-        dt = time.time() - t1
+    def plan(chunk):
+        """(image index in the chunk, detection index in the image) of the detections prepare() will submit for it, in its order --
+        a function of the dump alone, so every rank can plan every other rank's chunks."""
+        owners = []
+        for ti, (scene_id, im_id, obj_id_targets, inst_counts, _gi) in enumerate(chunk):
+            im = by_image.get((scene_id, im_id))
+            if im is None:
+                continue
+            owners += [(ti, r_id) for r_id in select_detections(im["rois"], im["obj_ids"], obj_id_targets, inst_counts, cand_factor)]
+        return owners
+
+    def rows_of(chunk, owners, recs, dt):
+        """recs[k]: the pose record of owners[k] (ctypes p2p_pose or a row of a _lib.POSE_DTYPE array)."""
         per_image = {}
         for k, (ti, r_id) in enumerate(owners):
-            p = poses[k]
-            if p.status != 0:                                                 # frac_inlier == -1 (:305-306)
+            p = recs[k]
+            if int(p["status"]) != 0:                                         # frac_inlier == -1 (:305-306)
                 continue
             scene_id, im_id = chunk[ti][:2]
             im = by_image[(scene_id, im_id)]
-            ms = (int(ex["mask_stats"][k, 0]), int(ex["mask_stats"][k, 1])) if "mask_stats" in ex else None
-            sc = detection_score(im["scores"][r_id], p.frac_inlier, ms, score_type, detect_type)
+            ms = (int(p["mask_stats"][0]), int(p["mask_stats"][1])) if score_type == 2 and detect_type == "rcnn" else None
+            sc = detection_score(im["scores"][r_id], float(p["frac_inlier"]), ms, score_type, detect_type)
             per_image.setdefault(ti, []).append({"obj_id": im["obj_ids"][r_id], "score": sc,
-                                                 "R": np.array(p.R).reshape(3, 3), "t": np.array(p.t)})
+                                                 "R": np.array(p["R"], np.float64).reshape(3, 3), "t": np.array(p["t"], np.float64)})
         for ti, (scene_id, im_id, obj_id_targets, inst_counts, gi) in enumerate(chunk):
             n_here = sum(1 for o in owners if o[0] == ti)
             new = rank_image_results(per_image.get(ti, []), obj_id_targets, inst_counts, task_type, scene_id, im_id,
@@ -259,6 +285,19 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
                 r["_order"] = (gi, k)
             rows.extend(new)
 
+    def finish(job):
+        chunk, owners, pending, t1, _held, step = job    # _held: injected maps stay alive until the batch is collected
+        from . import _lib
+        if gather is None:
+            pending.collect()
+            rows_of(chunk, owners, np.frombuffer(pending.pose_array, dtype=_lib.POSE_DTYPE, count=max(pending.n, 1)), time.time() - t1)
+            return
+        _own, allp = gather(pending, n_max)               # collective: every rank, every step; pending is None for an empty shard
+        dt = time.time() - t1
+        for r in range(shard[1]):                          # every rank builds every rank's rows of this step from the gathered records
+            ch = chunks_of(r)[step] if step < len(chunks_of(r)) else []
+            rows_of(ch, plan(ch), allp[r * n_max:(r + 1) * n_max], dt)
+
     # detection stream: chunk i+1 is read from disk and enqueued (p2p_est_pose_submit) while chunk i is on the GPU;
     # the score_type-2 mask sums come back through the same asynchronous call
     loader = FramePrefetcher(int(cfg.get("loader_threads", 8)))
@@ -266,16 +305,34 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
     def frame_paths(chunk):
         return [os.path.join(base_dir, by_image[(c[0], c[1])]["rgb"]) for c in chunk if (c[0], c[1]) in by_image]
 
+    gather, n_max, n_steps = None, 0, (len(tlist) + batch_images - 1) // batch_images
+    _chunks = {}
+
+    def chunks_of(r):
+        if r not in _chunks:
+            tl = full_tlist[r::shard[1]]
+            _chunks[r] = [tl[b:b + batch_images] for b in range(0, len(tl), batch_images)]
+        return _chunks[r]
+
+    if make_gather is not None and shard is not None:
+        gather = make_gather(ctx)
+        n_steps = max(len(chunks_of(r)) for r in range(shard[1]))
+        n_max = max([1] + [len(plan(ch)) for r in range(shard[1]) for ch in chunks_of(r)])       # equal on all ranks by construction
     loader.request(frame_paths(tlist[:batch_images]))
     in_flight = []
     n_submitted = 0
     inject_row = {(int(a), int(b)): i for i, (a, b) in enumerate(inject["key"])} if inject is not None else None
-    for b0 in range(0, len(tlist), batch_images):
+    for step in range(n_steps):
+        b0 = step * batch_images
         chunk = tlist[b0:b0 + batch_images]
         t1 = time.time()
         loader.request(frame_paths(tlist[b0 + batch_images:b0 + 2 * batch_images]))      # decoded while this chunk is prepared and runs
         frames, dets, det_masks, owners = prepare(chunk)
         if not dets:
+            if gather is not None:                        # lockstep: an empty shard still joins this step's collective
+                in_flight.append((chunk, owners, None, t1, None, step))
+                if len(in_flight) == 2:
+                    finish(in_flight.pop(0))
             continue
         # est_pose_kwargs: extra arguments of the batch call (tests inject decoder maps); a callable gets (index of the chunk's
         # first detection in stream order, number of detections) and returns them per chunk
@@ -290,13 +347,16 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
             torch.cuda.synchronize(device)
             extra = dict(extra, inject1=held[0].data_ptr(), inject2=held[1].data_ptr(), inject_slots=int(held[1].shape[1]))
         pending = runtime.est_pose_submit(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
-                                          anti_aliasing=bool(cfg.get("resize_anti_aliasing", False)),     # scikit-image >= 0.15 semantics
+                                          anti_aliasing=_resize_generation(cfg),
                                           **extra)
-        in_flight.append((chunk, owners, pending, t1, held))
+        in_flight.append((chunk, owners, pending, t1, held, step))
         if len(in_flight) == 2:
             finish(in_flight.pop(0))
     while in_flight:
         finish(in_flight.pop(0))
+    if gather is not None:
+        rows.sort(key=lambda r: r["_order"])
+        gather.close()
     loader.close()
     out_dir = cfg.get("path_to_output")
     if out_dir and write_csv:
@@ -338,10 +398,21 @@ def run_distributed(cfg: dict, dataset: str, dump: dict, base_dir: str = ".", ba
     torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world)
-    rows = run(cfg, dataset, dump, device=local, base_dir=base_dir, shard=(rank, world), write_csv=False, **kw)
     assert parallel.REC == ROW_REC
-    rec = parallel.gather_poses(rows_to_records(rows), device=torch.device("cuda", local) if backend == "nccl" else None)
-    merged = records_to_rows(rec)
+    # the pose records of every pooled batch travel through ONE collective per step -- inside the C ABI (RCCL all-gather of the device-resident
+    # p2p_pose records, p2p_est_pose_collect_gathered; a rank whose shard is empty at a step joins with P2P_TICKET_NONE) on the "nccl" backend,
+    # through torch.distributed otherwise (gloo dry runs, ranks sharing a device) or when P2P_EVAL_TORCH_GATHER is set; every rank then holds
+    # the merged rows.  P2P_EVAL_FINAL_GATHER=1 keeps the old scheme: independent shards + one all-gather of the result rows at the end.
+    if os.environ.get("P2P_EVAL_FINAL_GATHER"):
+        rows = run(cfg, dataset, dump, device=local, base_dir=base_dir, shard=(rank, world), write_csv=False, **kw)
+        rec = parallel.gather_poses(rows_to_records(rows), device=torch.device("cuda", local) if backend == "nccl" else None)
+        merged = records_to_rows(rec)
+    else:
+        if backend == "nccl" and not os.environ.get("P2P_EVAL_TORCH_GATHER"):
+            make_gather = parallel.CabiPoseGather
+        else:
+            make_gather = lambda ctx: parallel.TorchPoseGather(torch.device("cuda", local) if backend == "nccl" else None)      # noqa: E731
+        merged = run(cfg, dataset, dump, device=local, base_dir=base_dir, shard=(rank, world), write_csv=False, make_gather=make_gather, **kw)
     out_dir = cfg.get("path_to_output")
     if out_dir and rank == 0:
         os.makedirs(out_dir, exist_ok=True)
@@ -370,13 +441,14 @@ def main(argv):
         with np.load(os.environ["P2P_EVAL_INJECT"]) as z:
             inject = {k: z[k] for k in ("key", "inject1", "inject2")}
     detect_type = cfg.get("detection_pipeline", "rcnn")          # tools/5_evaluation_bop_basic.py:36 ('rcnn' | 'retinanet': no masks)
+    bi = int(cfg.get("batch_images", 32))             # images pooled into one device batch (this build's own key)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         rows = run_distributed(cfg, dataset, dump, base_dir=base_dir, same_device=bool(os.environ.get("P2P_EVAL_SAME_DEVICE")), inject=inject,
-                               detect_type=detect_type)
+                               detect_type=detect_type, batch_images=bi)
         if int(os.environ["RANK"]) != 0:
             return 0
     else:
-        rows = run(cfg, dataset, dump, device=device, base_dir=base_dir, inject=inject, detect_type=detect_type)
+        rows = run(cfg, dataset, dump, device=device, base_dir=base_dir, inject=inject, detect_type=detect_type, batch_images=bi)
     print("Saving %d results to %s" % (len(rows), os.path.join(cfg.get("path_to_output", "."), output_name(dataset))))
     return 0
 

@@ -105,6 +105,58 @@ def create_comm(ctx):
     return Comm(ctx, rank, world, box[0])
 
 
+class CabiPoseGather:
+    """Per-step exchange of a detection stream's pose records through the C ABI: p2p_est_pose_collect_gathered (RCCL all-gather of the
+    device-resident p2p_pose records over xGMI).  ``gather(pending, n_max)`` is collective: every rank calls it once per step, a rank
+    without a batch passes ``pending = None`` (P2P_TICKET_NONE).  -> (own poses or [], numpy view [world * n_max] of _lib.POSE_DTYPE)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.comm = ctx, create_comm(ctx)
+        self.world, self.impl = self.comm.world, "C ABI ncclAllGather (%s)" % self.comm.library()
+
+    def __call__(self, pending, n_max: int):
+        from . import _lib
+        from .runtime import collect_gathered_empty
+        if pending is None:
+            own, allp = [], collect_gathered_empty(self.ctx, self.comm, n_max)
+        else:
+            own, allp = pending.collect_gathered(self.comm, n_max)
+        return own, np.frombuffer(allp, dtype=_lib.POSE_DTYPE, count=self.world * n_max)
+
+    def close(self):
+        self.comm.close()
+
+
+class TorchPoseGather:
+    """The same exchange through torch.distributed (gloo dry runs, several ranks on one device -- RCCL refuses that --, hosts without
+    RCCL): the raw record bytes of each rank's collected batch, padded to n_max with status = POSE_ABSENT, in one all_gather."""
+
+    def __init__(self, device=None):
+        import torch.distributed as dist
+        self.device, self.world = device, dist.get_world_size()
+        self.impl = "torch.distributed all_gather_into_tensor (%s)" % dist.get_backend()
+
+    def __call__(self, pending, n_max: int):
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        own = pending.collect() if pending is not None else []
+        if len(own) > n_max:
+            raise ValueError("the batch holds %d detections, n_max is %d" % (len(own), n_max))
+        buf = np.zeros(n_max, _lib.POSE_DTYPE)
+        buf["status"] = _lib.POSE_ABSENT
+        if own:
+            buf[:len(own)] = np.frombuffer(pending.pose_array, dtype=_lib.POSE_DTYPE, count=len(own))
+        dev = self.device if self.device is not None else torch.device("cpu")
+        send = torch.from_numpy(buf.view(np.uint8).copy()).to(dev)
+        out = torch.empty(self.world * send.numel(), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, send)
+        return own, np.frombuffer(out.cpu().numpy().tobytes(), dtype=_lib.POSE_DTYPE, count=self.world * n_max)
+
+    def close(self):
+        pass
+
+
 def gathered_to_records(all_poses, world: int, n_max: int, ids_per_rank: int | None = None) -> np.ndarray:
     """The world * n_max p2p_pose records p2p_est_pose_collect_gathered returns -> [n, REC] records sorted by id
     (id = rank * ids_per_rank + position in the rank's batch), padding records dropped."""

@@ -67,10 +67,16 @@ class pix2pose():
         # skimage.transform.resize semantics: False = scikit-image <= 0.14 (no anti-aliasing), True = 0.17 - 0.18 (Gaussian
         # pre-filter when down-scaling); the reference does not pin the version
         # skimage="0.14" / "0.18" names the generation outright ("0.18" is pinned bit for bit to the real scikit-image 0.18.3)
+        # "0.15" / "0.16": anti-aliasing also on the bool keep mask of recognition.py:103 (what the reference's own python-3.5 image resolves to).
+        # Nothing named: generation 0 with a one-time warning that it is the unpinned one.
         gen = kwargs.get("skimage")
-        if gen is not None and str(gen) not in ("0.14", "0.17", "0.18"):
-            raise ValueError("skimage must be '0.14' or '0.18' (0.15 / 0.16 and >= 0.19 are not modelled), got %r" % (gen,))
-        self.anti_aliasing = bool(kwargs.get("anti_aliasing", False)) if gen is None else str(gen) != "0.14"
+        if gen is not None:
+            self.anti_aliasing = runtime.resize_generation(str(gen))
+        elif "anti_aliasing" in kwargs:
+            self.anti_aliasing = runtime.resize_generation(kwargs["anti_aliasing"])
+        else:
+            self.anti_aliasing = 0
+            runtime.warn_unpinned_generation("pix2pose(...)")
         # precision="f16x3" (default), "f32", or "auto" (split-f16 with an fp32 twin the object falls back to on a range event)
         self.generator_train = runtime.Generator(weights, backbone, ctx, precision=kwargs.get("precision", "f16x3"))
         self._inject = None                    # TEST / BENCH ONLY: (inject1_ptr, inject2_ptr, slots) device maps that replace the decoder outputs

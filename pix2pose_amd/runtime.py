@@ -185,6 +185,41 @@ def _image_struct(img):
     return s, a
 
 
+# skimage.transform.resize GENERATION (p2p_est_pose_opts.resize_anti_aliasing; include/p2p_mi355.h has the full account).  The reference calls
+# resize six times per detection and does not pin scikit-image, so the caller names the library its reference environment resolves to.
+RESIZE_GENERATIONS = {"0.14": 0, "0.15": 2, "0.16": 2, "0.17": 1, "0.18": 1}
+_warned_unpinned = False
+
+
+def resize_generation(spec) -> int:
+    """None / False / 0 / "0.14" -> 0 (scikit-image <= 0.14: no anti-aliasing; NOT pinned to a real library);
+    True / 1 / "0.17" / "0.18" -> 1 (pinned bit for bit to the real 0.18.3); 2 / "0.15" / "0.16" -> 2 (anti-aliasing on for every input
+    including the bool keep mask; its Gaussian filter pinned to the real scipy, its warp restated)."""
+    if spec is None or spec is False:
+        return 0
+    if spec is True:
+        return 1
+    if isinstance(spec, str):
+        if spec not in RESIZE_GENERATIONS:
+            raise ValueError("skimage must be one of %s (>= 0.19 rejects the reference's bool mask resize), got %r" % (sorted(RESIZE_GENERATIONS), spec))
+        return RESIZE_GENERATIONS[spec]
+    g = int(spec)
+    if g not in (0, 1, 2):
+        raise ValueError("resize generation must be 0, 1 or 2, got %r" % (spec,))
+    return g
+
+
+def warn_unpinned_generation(who: str):
+    """The default generation (scikit-image <= 0.14) cannot be checked against any real library in the build image: say so, once."""
+    global _warned_unpinned
+    if not _warned_unpinned:
+        _warned_unpinned = True
+        import warnings
+        warnings.warn("%s: no scikit-image generation was named -- using the <= 0.14 resize semantics, which are restated from the published "
+                      "behaviour and NOT pinned to a real library; name the version the reference environment resolves to (skimage='0.18' is "
+                      "pinned bit for bit to scikit-image 0.18.3, '0.15' / '0.16' has its filter pinned) to silence this" % who, stacklevel=3)
+
+
 def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks, det_masks, ransac_iterations,
              reprojection_error, confidence, anti_aliasing=False):
     """Build the C arrays of one batch call.  -> (objs, imgs, dets, opts, extras, keep-alive list)"""
@@ -207,7 +242,7 @@ def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_m
     opts = _lib.EstPoseOpts()
     opts.ransac_iterations, opts.reprojection_error, opts.confidence = ransac_iterations, reprojection_error, confidence
     opts.inject1, opts.inject2, opts.inject_slots = inject1, inject2, inject_slots
-    opts.resize_anti_aliasing = 1 if anti_aliasing else 0
+    opts.resize_anti_aliasing = resize_generation(anti_aliasing)
     extras = {}
     if want_masks and n:
         def hw(i):
@@ -331,6 +366,16 @@ class PendingBatch:
         self._keep = None
         self.pose_array = poses
         return [poses[i] for i in range(self.n)], allp
+
+
+def collect_gathered_empty(ctx: Context, comm: "Comm", n_max: int):
+    """This rank has NO batch this step (an empty shard: its images ran out, or none of its detections survived the candidate limits)
+    but its peers do: join their p2p_est_pose_collect_gathered with ticket = P2P_TICKET_NONE, contributing n_max padding records.
+    Collective.  -> ctypes array of world * n_max records as from PendingBatch.collect_gathered."""
+    allp = (_lib.Pose * (comm.world * n_max))()
+    _lib.check(_lib.lib().p2p_est_pose_collect_gathered(ctx.handle, comm.handle, _lib.TICKET_NONE, None, n_max, allp),
+               "p2p_est_pose_collect_gathered(empty shard)")
+    return allp
 
 
 def est_pose_submit(ctx: Context, objects, images, detections, *, inject1=None, inject2=None, inject_slots=0,

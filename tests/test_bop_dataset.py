@@ -277,6 +277,16 @@ def test_bop_directory_stream_one_and_two_ranks(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     two = _read_csv(csv_fn)
     assert len(one) >= 10 and one == two
+    # ragged shards: three ranks, two images per step -> 3 / 3 / 2 images = 2 / 2 / 1 steps: rank 2 has NO batch at the second step and
+    # joins that step's collective as an empty shard (the per-step exchange of pose records; over RCCL it is the C ABI's
+    # p2p_est_pose_collect_gathered with P2P_TICKET_NONE, here -- three ranks on one device -- torch.distributed carries the same records)
+    os.rename(csv_fn, csv_fn + ".2")
+    json.dump(dict(cfg, batch_images=2), open(os.path.join(root, "cfg3.json"), "w"))
+    args3 = ["0", os.path.join(root, "cfg3.json"), "ycbv", os.path.join(root, "detections.json")]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", "-m", "pix2pose_amd.eval_bop"] + args3, capture_output=True, text=True, cwd=ROOT, env=env2, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert _read_csv(csv_fn) == one
     # ... and they are the rows of the in-process run (same text after the float round trip)
     dump = B.build_dump(cfg, "ycbv", dets)
     with np.load(os.path.join(root, "inject.npz")) as z:

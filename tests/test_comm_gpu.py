@@ -47,6 +47,47 @@ def test_collect_gathered_equals_collect_in_caller_order():
     comm.close()
 
 
+def test_empty_shard_and_errors_still_enter_the_collective():
+    """A rank without a batch joins with P2P_TICKET_NONE (n_max padding records); an unknown ticket is reported AFTER the collective (its
+    peers are not left blocked in ncclAllGather -- with one rank: the call returns instead of hanging and the communicator stays usable);
+    the score_type-2 mask sums travel inside the gathered records."""
+    import torch
+    from pix2pose_amd import _lib
+    from pix2pose_amd.runtime import Comm, Context, Generator, ObjectSpec, collect_gathered_empty, est_pose_submit
+    ctx = Context(0, max_batch=64)
+    comm = Comm(ctx, 0, 1, Comm.unique_id())
+    n_max = 8
+    allp = collect_gathered_empty(ctx, comm, n_max)                    # before any batch was ever submitted on this context
+    assert all(allp[i].status == _lib.POSE_ABSENT for i in range(n_max))
+    spec = ObjectSpec(Generator(W.synthetic_weights("paper", 2), "paper", ctx), S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2)
+    sc = S.make_scene(5, seed=77)
+    H, Wd = sc["images"].shape[1:3]
+    masks = np.zeros((5, H, Wd), np.uint8)
+    for i, d in enumerate(sc["dets"]):
+        b = d[2]
+        masks[i, b[0] + 8:b[2] - 6, b[1] + 5:b[3] - 9] = 1
+    j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
+    torch.cuda.synchronize()
+    kw = dict(inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3, det_masks=list(masks))
+    pend = est_pose_submit(ctx, [spec], list(sc["images"]), sc["dets"], **kw)
+    own, allp = pend.collect_gathered(comm, n_max)
+    assert [p.status for p in own] == [0] * 5 and all(allp[i].status == _lib.POSE_ABSENT for i in range(5, n_max))
+    for i in range(5):
+        assert list(allp[i].mask_stats) == pend.extras["mask_stats"][i].tolist() == list(own[i].mask_stats)
+        assert allp[i].mask_stats[0] > 0 and allp[i].mask_stats[1] >= allp[i].mask_stats[0]
+    L = _lib.lib()
+    poses = (_lib.Pose * n_max)()
+    out = (_lib.Pose * n_max)()
+    assert L.p2p_est_pose_collect_gathered(ctx.handle, comm.handle, 12345, poses, n_max, out) == -1      # unknown ticket: error after the gather
+    assert all(out[i].status == _lib.POSE_ABSENT for i in range(n_max))                                  # ... which ran, with padding only
+    assert b"12345" in L.p2p_last_error()
+    allp = collect_gathered_empty(ctx, comm, n_max)                    # an empty step between two real ones
+    assert all(allp[i].status == _lib.POSE_ABSENT for i in range(n_max))
+    own2, allp2 = est_pose_submit(ctx, [spec], list(sc["images"]), sc["dets"], **kw).collect_gathered(comm, n_max)
+    assert [_key(p) for p in own2] == [_key(p) for p in own]
+    comm.close()
+
+
 def test_comm_argument_validation():
     from pix2pose_amd import _lib
     from pix2pose_amd.runtime import Comm, Context

@@ -1,13 +1,16 @@
 """The specialised F16X3 kernels (halo-tiled igemm, heads, first layer) against the generic implicit-GEMM
 path they replace: same layers, same split-f16 arithmetic, different tiling and summation order, so the
 network outputs agree to fp32 summation noise.  The generic path is selected per process with
-P2P_NO_HALO=1 (a development switch read once by the library), hence the subprocesses."""
+P2P_NO_HALO=1 (a route switch that exists in the development twin of the library only, read once per process: pix2pose_amd/build.py
+dev_switches), hence the subprocesses; the other side of every comparison is the SHIPPED library."""
 import os
 import subprocess
 import sys
 
 import numpy as np
 import pytest
+
+from pix2pose_amd.build import dev_switches
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +42,7 @@ def _run(tmp_path, backbone, precision, tag, env_extra):
 @pytest.mark.parametrize("backbone", ["resnet50", "paper"])
 def test_specialised_kernels_match_generic_path(tmp_path, backbone):
     a = _run(tmp_path, backbone, "f16x3", "halo", {})
-    b = _run(tmp_path, backbone, "f16x3", "generic", {"P2P_NO_HALO": "1"})
+    b = _run(tmp_path, backbone, "f16x3", "generic", dev_switches(P2P_NO_HALO=1))
     assert np.isfinite(a["dec"]).all() and np.isfinite(a["prob"]).all()
     big = 3                                     # the x40 sample: every pre-activation, and so every rounding difference, is 40x larger
     rest = [0, 1, 2, 4]
@@ -62,5 +65,5 @@ def test_heads_two_ahead_schedule_is_bit_identical(tmp_path):
     """heads_halo_kernel<2> (P2P_HEADS_TWO_AHEAD=1: 8-row workgroups fetching two stages ahead) computes an output pixel with the same chain
     of MFMAs as the default 16-row schedule: identical bits."""
     a = _run(tmp_path, "resnet50", "f16x3", "default", {"P2P_TEST_N": "20"})           # >= 16 inputs: the large-launch variants of the kernel
-    b = _run(tmp_path, "resnet50", "f16x3", "two_ahead", {"P2P_TEST_N": "20", "P2P_HEADS_TWO_AHEAD": "1"})
+    b = _run(tmp_path, "resnet50", "f16x3", "two_ahead", dev_switches(P2P_TEST_N=20, P2P_HEADS_TWO_AHEAD=1))
     assert np.array_equal(a["dec"], b["dec"]) and np.array_equal(a["prob"], b["prob"])

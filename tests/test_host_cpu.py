@@ -134,7 +134,8 @@ from pix2pose_amd import _lib
 from pix2pose_amd.parallel import gather_poses, poses_to_records, shard_detections
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-dets = [(0, i %% 3, [0, 0, 1, 1], None) for i in range(11)]
+N = int(os.environ.get("P2P_TEST_DETS", "11"))
+dets = [(0, i %% 3, [0, 0, 1, 1], None) for i in range(N)]
 order, bounds = shard_detections(dets, world)
 mine = order[bounds[rank]:bounds[rank + 1]]
 poses = []
@@ -150,9 +151,9 @@ h2 = gather_poses_async(poses_to_records(poses, ids=mine))
 rec = h1.result()
 assert (h2.result() == rec).all()
 assert (gather_poses(poses_to_records(poses, ids=mine)) == rec).all()
-assert rec.shape == (11, 20), rec.shape
-assert rec[:, 0].tolist() == list(range(11))
-for i in range(11):
+assert rec.shape == (N, 20), rec.shape
+assert rec[:, 0].tolist() == list(range(N))
+for i in range(N):
     assert rec[i, 3] == 100 + i and rec[i, 2] == i / 7.0
     assert rec[i, 6:15].tolist() == [i + k / 16.0 for k in range(9)]      # float64 records: bit exact
     assert rec[i, 15:18].tolist() == [-i - k / 3.0 for k in range(3)]
@@ -170,6 +171,20 @@ def test_pose_gather_world_size_2_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_pose_gather_world_size_8_with_empty_shards_gloo(tmp_path):
+    """Eight ranks, five detections: three ranks own an EMPTY shard and still take part in every gather (padding to the largest shard,
+    padded rows dropped) -- the shape of BASELINE.json configs[3] / [4] whenever an object group or the tail of an image stream is smaller
+    than the node (tools/5_evaluation_bop_basic.py:289-304 makes the batches ragged)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_GLOO_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", P2P_TEST_DETS="5", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 8
 
 
 def test_binding_refuses_a_stale_library(monkeypatch):

@@ -1,8 +1,8 @@
 """The small-launch route (igemm_stream.hip: one wave per 32x32 output tile, operands streamed to registers) against the batched
 kernels it stands in for.  The claim is stronger than a tolerance: every output element is the same chain of MFMAs over the same
 K-step order whichever kernel computes it, so the generator output of a crop is BIT-IDENTICAL alone (streaming route), inside a
-large batch (batched kernels), and with the streaming route switched off (P2P_STREAM_WGS=0, read once per process -- hence the
-subprocess).  This is what lets the reference's one-roi-at-a-time caller (tools/5_evaluation_bop_basic.py:289-304) and a pooled
+large batch (batched kernels), and with the streaming route switched off (P2P_STREAM_WGS=0: a route switch of the library's development
+twin, read once per process -- hence the subprocess; pix2pose_amd/build.py dev_switches).  This is what lets the reference's one-roi-at-a-time caller (tools/5_evaluation_bop_basic.py:289-304) and a pooled
 batch agree to the last bit."""
 import os
 import subprocess
@@ -11,6 +11,7 @@ import sys
 import numpy as np
 import pytest
 
+from pix2pose_amd.build import dev_switches
 from pix2pose_amd import weights as W
 
 pytestmark = pytest.mark.gpu
@@ -44,7 +45,7 @@ def _run(tmp_path, backbone, tag, env_extra):
 @pytest.mark.parametrize("backbone", ["resnet50", "paper"])
 def test_streaming_route_is_bit_identical_to_batched_kernels(tmp_path, backbone):
     a = _run(tmp_path, backbone, "stream", {})
-    b = _run(tmp_path, backbone, "batched", {"P2P_STREAM_WGS": "0"})
+    b = _run(tmp_path, backbone, "batched", dev_switches(P2P_STREAM_WGS=0))
     for k in a.files:
         assert np.isfinite(a[k]).all()
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)

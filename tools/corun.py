@@ -1,4 +1,4 @@
-"""Timing experiment (A/B build with -DP2P_DEV_SWITCHES): does the memory-bound ResNet front of one pass run 'for free' on a slice of the
+"""Timing experiment (A/B build with -DP2P_TIMING_SWITCHES): does the memory-bound ResNet front of one pass run 'for free' on a slice of the
 CUs while the MFMA-bound (power-limited) rest of another pass runs on the others?
     P2P_LIB=tools/ab/libp2p_ab.so python tools/corun.py [n_inputs] [front_cus]"""
 import os

@@ -37,6 +37,17 @@ def main(path, batch=256):
     if "maxpool" not in ks[1][0]:              # first layer and max-pool in one kernel (conv1.hip, large batches)
         layers = [("conv1+pool", LAYERS[0][1])] + LAYERS[2:]
         KF["conv1+pool"] = 49 + 131 + 66       # input, the skip's 32 channels, the pooled tensor
+    if any("resblock_kernel" in r[0] for r in ks[:len(layers)]):      # identity bottleneck blocks as one launch each (resblock.hip)
+        fused, out = ("res2b", "res2c", "res3b", "res3c", "res3d"), []
+        for nm, mmac in layers:
+            b = nm.split("_")[0]
+            if b in fused:
+                if nm.endswith("_2a"):
+                    out.append((b + " (fused)", sum(m for n2, m in layers if n2.split("_")[0] == b)))
+                    KF[b + " (fused)"] = 2 * (262 if b.startswith("res2") else 131)      # block input read once, output written once
+                continue
+            out.append((nm, mmac))
+        layers = out
     ks = ks[:len(layers)]
     tot = 0
     for (nm, mmac), r in zip(layers, ks):
@@ -44,7 +55,7 @@ def main(path, batch=256):
         tot += us
         gf = 2 * mmac * batch / 1e3
         tb = KF.get(nm, 0) * 1e3 * 4 * batch / (us * 1e-6) / 1e12 if us else 0
-        print("%-14s %-28s %9.1f us %9.1f GFLOP %7.1f TFLOP/s %6.2f TB/s" % (nm, r[0].replace("void p2p::", "").replace("p2p::", "").replace("(anonymous namespace)::", "")[:28],
+        print("%-16s %-28s %9.1f us %9.1f GFLOP %7.1f TFLOP/s %6.2f TB/s" % (nm, r[0].replace("void p2p::", "").replace("p2p::", "").replace("(anonymous namespace)::", "")[:28],
                                                                          us, gf, gf / us * 1e3 if us else 0, tb))
     print("total %.1f us -> %.0f inputs/s" % (tot, batch / tot * 1e6))
 

@@ -30,7 +30,7 @@ cd $GRAFT_REPO_ROOT
 python tools/pmc_traffic.py gpurun_out/pmc_fetch2/x_results.db gpurun_out/pmc_write2/x_results.db profiles/'"$R"'_traffic.json > /dev/null   # bench.py reads it
 python tools/single_det.py 200 > gpurun_out/single_det.log 2>&1
 python tools/time_small.py resnet50 50 > gpurun_out/small_passes.log 2>&1
-P2P_STREAM_WGS=0 python tools/time_small.py resnet50 50 1,3,8 >> gpurun_out/small_passes.log 2>&1
+P2P_LIB=$GRAFT_REPO_ROOT/pix2pose_amd/libp2p_mi355_dev.so P2P_STREAM_WGS=0 python tools/time_small.py resnet50 50 1,3,8 >> gpurun_out/small_passes.log 2>&1
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --objects 30 --no-legs > gpurun_out/bench_objects30.json 2>> gpurun_out/bench_final.err
 python bench.py --steps 5 --warmup 2 --precision f32 --no-legs > gpurun_out/bench_f32.json 2>> gpurun_out/bench_final.err
