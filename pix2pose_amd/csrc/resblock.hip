@@ -54,7 +54,9 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
 
-template <int F1, int PY, int HPX>
+// DA / DB: K-steps of global loads in flight in phases A / B (register rings).  A K-step of these phases is 12 - 18 MFMAs per wave -- a few
+// hundred cycles, a fraction of a loaded memory round trip -- so with the usual one-step-ahead prefetch every step waited for its operands.
+template <int F1, int PY, int HPX, int DA, int DB, int KA, bool PRIV, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p)
 {
     constexpr int C = 4 * F1;
@@ -68,17 +70,22 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     constexpr int NPIX = PY * 16, MT = PY / 2;    // patch pixels; their 32-row m-tiles (two patch rows each)
     constexpr int T2SLICE = NPIX * REC, T2_BYTES = SB * T2SLICE;
     constexpr int XS_BYTES = MA * 32 * REC;
-    constexpr int WA_BYTES = F1 * WREC, WB_BYTES = F1 * WREC;
+    constexpr int WA_BYTES = F1 * WREC;
+    // KA: K-steps per staged stage of phase A.  PRIV: phase B with wave-private weight tiles (every wave stages its OWN copy of its n-tile's 32
+    // rows: no workgroup barrier in the K loop) instead of one shared tile per K-step between two barriers.
+    constexpr int WB_BYTES = PRIV ? 4 * 32 * WREC : F1 * WREC;
     constexpr int WC_BYTES = 2 * 128 * WREC;      // two K-steps of a 128-row chunk of the 2c panel
     constexpr int NST = SB / 2;                   // such stages per chunk
     constexpr int TMC = 2, TNC = MT == 4 ? 2 : 1, WGMC = MT / TMC, WGNC = 4 / WGMC;      // phase-C wave tiling (igemm.hip's)
     constexpr int CLD = 128 + 4;
     constexpr int CS_BYTES = TMC * 32 * CLD * 4;
-    constexpr int ZERO_OFF = cmax(cmax(XS_BYTES + WA_BYTES, T_BYTES + WB_BYTES), T2_BYTES + cmax(WC_BYTES, CS_BYTES));
-    constexpr int SMEM = ZERO_OFF + 128;
+    constexpr int ZERO_OFF = cmax(cmax(KA * (XS_BYTES + WA_BYTES), T_BYTES + WB_BYTES), T2_BYTES + cmax(WC_BYTES, CS_BYTES));
+    constexpr int SS_OFF = ZERO_OFF + 128, SS_FLOATS = 4 * F1 + 2 * C;      // the folded BatchNorm vectors: read by every epilogue, kept in LDS
+    constexpr int SMEM = SS_OFF + SS_FLOATS * 4;
     static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
     static_assert(MA % (F1 == 64 ? 2 : 1) == 0 && (F1 == 64 || F1 == 128) && (PY == 8 || PY == 4), "shapes");
     __shared__ __attribute__((aligned(256))) char smem[SMEM];
+    static_assert(SS_FLOATS % 4 == 0, "float4 copies");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -99,7 +106,11 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
 
     int g = 0;                                   // mixed-object batches: groups are runs of samples
     while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= n) ++g;
-    const float* ss = p.grp[g].ss;               // [s2a F1 | h2a F1 | s2b F1 | h2b F1 | s2c C | h2c C]
+    // [s2a F1 | h2a F1 | s2b F1 | h2b F1 | s2c C | h2c C]: fetched once (a global load per use put a memory round trip in front of every
+    // group of four channels in the epilogues)
+    const float* ss = reinterpret_cast<const float*>(smem + SS_OFF);
+    for (int i = tid * 4; i < SS_FLOATS; i += 1024)
+        *reinterpret_cast<f32x4*>(smem + SS_OFF + i * 4) = *reinterpret_cast<const f32x4*>(p.grp[g].ss + i);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wa = __builtin_amdgcn_make_buffer_rsrc((void*)p.grp[g].w2a, 0, p.wa_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wb = __builtin_amdgcn_make_buffer_rsrc((void*)p.grp[g].w2b, 0, p.wb_bytes, 0x00020000);
@@ -122,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     static_assert(MA == 3 * WMA, "three m-tiles per wave");
     const int ntA = wave % WNA, mt0A = (wave / WNA) * 3;
     {
-        char* Xs = smem;
-        char* Was = smem + XS_BYTES;
+        char* Xs = smem;                           // [KA][MA * 32 records]
+        char* Was = smem + KA * XS_BYTES;          // [KA][F1 rows]
         unsigned x_off[MA];
         int x_dst[MA];
 #pragma unroll
@@ -142,27 +153,38 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
         unsigned wa_off[F1 / 32];
 #pragma unroll
         for (int j = 0; j < F1 / 32; ++j) wa_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)C + (unsigned)lseg * 4u) * 4u;
-        f32x4 rx[MA], rw[F1 / 32];
-        auto gload = [&](int s) {
+        constexpr int NSTG = SA / KA;              // stages of KA K-steps
+        static_assert(SA % KA == 0 && NSTG % DA == 0, "ring depth divides the stages");
+        f32x4 rx[DA][KA][MA], rw[DA][KA][F1 / 32];      // ring slot d holds stages congruent to d (mod DA); all indices are static after unrolling
+        auto gload = [&](int stg, auto& qx, auto& qw) {
 #pragma unroll
-            for (int j = 0; j < MA; ++j)
-                rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[j] == OOB ? OOB : x_off[j] + (unsigned)s * 128u, 0, 0));
+            for (int k2 = 0; k2 < KA; ++k2) {
+                const int s = stg * KA + k2;
 #pragma unroll
-            for (int j = 0; j < F1 / 32; ++j) rw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wa, wa_off[j], s * 128, 0));
-        };
-        auto lstore = [&]() {
+                for (int j = 0; j < MA; ++j)
+                    qx[k2][j] = (ABL & 4) ? f32x4{1.f, 2.f, 3.f, 4.f}
+                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[j] == OOB ? OOB : x_off[j] + (unsigned)s * 128u, 0, 0));
 #pragma unroll
-            for (int j = 0; j < MA; ++j) {
-                uint2 hi, lo;
-                split4(rx[j], hi, lo);
-                *reinterpret_cast<uint2*>(Xs + x_dst[j]) = hi;
-                *reinterpret_cast<uint2*>(Xs + x_dst[j] + 64) = lo;
+                for (int j = 0; j < F1 / 32; ++j) qw[k2][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wa, wa_off[j], s * 128, 0));
             }
-#pragma unroll
-            for (int j = 0; j < F1 / 32; ++j) *reinterpret_cast<f32x4*>(Was + w_dst + 32 * j * WREC) = rw[j];
         };
-        gload(0);
-        lstore();
+        auto lstore = [&](const auto& qx, const auto& qw) {
+#pragma unroll
+            for (int k2 = 0; k2 < KA; ++k2) {
+#pragma unroll
+                for (int j = 0; j < MA; ++j) {
+                    uint2 hi, lo;
+                    split4(qx[k2][j], hi, lo);
+                    *reinterpret_cast<uint2*>(Xs + k2 * XS_BYTES + x_dst[j]) = hi;
+                    *reinterpret_cast<uint2*>(Xs + k2 * XS_BYTES + x_dst[j] + 64) = lo;
+                }
+#pragma unroll
+                for (int j = 0; j < F1 / 32; ++j) *reinterpret_cast<f32x4*>(Was + k2 * WA_BYTES + w_dst + 32 * j * WREC) = qw[k2][j];
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DA; ++d) gload(d, rx[d], rw[d]);
+        lstore(rx[0], rw[0]);
         __syncthreads();
         const char* Xf = Xs + (mt0A * 32 + li) * REC + lk * 16;
         const char* Wf = Was + (ntA * 32 + li) * WREC;
@@ -171,46 +193,71 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) w_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
-        for (int s = 0; s < SA; ++s) {
-            const bool more = s + 1 < SA;
-            if (more) gload(s + 1);
+        for (int g0 = 0; g0 < NSTG; g0 += DA) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][0]);
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][1]);
+            for (int d = 0; d < DA; ++d) {
+                const int stg = g0 + d;                                       // the staged stage; its ring slot d is free again
+                if (stg + DA < NSTG) gload(stg + DA, rx[d], rw[d]);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(Xf + i * 32 * REC + kb * 32);
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(Xf + i * 32 * REC + kb * 32 + 64);
-                    accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accA[i], 0, 0, 0);      // (al bh, ah bl, ah bh) with a = activation, b = weight,
-                    accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accA[i], 0, 0, 0);      // operand roles swapped: D[channel][pixel]
-                    accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accA[i], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-            if (more) {
-                lstore();
+                for (int k2 = 0; k2 < KA; ++k2)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const f16x8 wh = *reinterpret_cast<const f16x8*>(Wf + k2 * WA_BYTES + w_sw[kb][0]);
+                        const f16x8 wl = *reinterpret_cast<const f16x8*>(Wf + k2 * WA_BYTES + w_sw[kb][1]);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const f16x8 xh = *reinterpret_cast<const f16x8*>(Xf + k2 * XS_BYTES + i * 32 * REC + kb * 32);
+                            const f16x8 xl = *reinterpret_cast<const f16x8*>(Xf + k2 * XS_BYTES + i * 32 * REC + kb * 32 + 64);
+                            if (ABL & 32) { accA[i][0] += (float)wh[0] + (float)wl[0] + (float)xh[0] + (float)xl[0]; continue; }
+                            accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accA[i], 0, 0, 0);      // (al bh, ah bl, ah bh) with a = activation, b = weight,
+                            accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accA[i], 0, 0, 0);      // operand roles swapped: D[channel][pixel]
+                            accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accA[i], 0, 0, 0);
+                        }
+                    }
                 __syncthreads();
+                if (stg + 1 < NSTG) {
+                    lstore(rx[(d + 1) % DA], rw[(d + 1) % DA]);
+                    __syncthreads();
+                }
             }
         }
     }
 
-    // first weight tile of 2b: requested now, staged beside the t_a image (that region is free in phase A)
-    unsigned wb_off[F1 / 32];
+    // 2b weights.  PRIV: every wave streams its OWN n-tile's 32 rows (two lanes per 128-byte row) through a private 4 KB staging tile, so the
+    // K loop of phase B has no workgroup barrier (LDS operations of one wave execute in order, the t_a image is read-only; waves that share an
+    // n-tile -- F1 = 64: two m-halves -- fetch it twice).  Otherwise: one shared F1-row tile per K-step, two barriers per step.
+    constexpr int WNB = F1 / 32 >= 4 ? 4 : F1 / 32, WMB = 4 / WNB;
+    const int ntB = wave % WNB, mt0B = (wave / WNB) * 2;
+    constexpr int TOTAL = SB * 9;
+    static_assert(TOTAL % DB == 0, "ring depth divides the K-steps");
+    constexpr int NWB = PRIV ? 4 : F1 / 32;       // float4 per thread and K-step
+    unsigned wb_off[NWB];
+    int wb_dst[NWB];
 #pragma unroll
-    for (int j = 0; j < F1 / 32; ++j) wb_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)(9 * F1) + (unsigned)lseg * 4u) * 4u;
-    f32x4 rwb[F1 / 32];
-    auto wbload = [&](int tap, int chunk) {
-        const int koff = (tap * SB + chunk) * 128;                           // the panel's K order is (tap, slice)
+    for (int j = 0; j < NWB; ++j) {
+        if (PRIV) {
+            wb_off[j] = ((unsigned)(ntB * 32 + (lane >> 1)) * (unsigned)(9 * F1) + (unsigned)(lane & 1) * 16u) * 4u + 16u * j;
+            wb_dst[j] = (lane >> 1) * WREC + ((((lane & 1) * 4 + j) ^ ((lane >> 2) & 7)) << 4);
+        } else {
+            wb_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)(9 * F1) + (unsigned)lseg * 4u) * 4u;
+            wb_dst[j] = w_dst + 32 * j * WREC;
+        }
+    }
+    f32x4 rwb[DB][NWB];
+    auto wbload = [&](int ks, auto& qw) {
+        const int chunk = ks / 9, tap = ks - chunk * 9;                       // K order (slice, tap); the panel's is (tap, slice)
+        const int koff = (tap * SB + chunk) * 128;
 #pragma unroll
-        for (int j = 0; j < F1 / 32; ++j) rwb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wb, wb_off[j], koff, 0));
+        for (int j = 0; j < NWB; ++j)
+            qw[j] = (ABL & 8) ? f32x4{1.f, 2.f, 3.f, 4.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wb, wb_off[j], koff, 0));
     };
-    char* Wbs = smem + T_BYTES;
-    auto wbstore = [&]() {
+    char* Wbs = smem + T_BYTES + (PRIV ? wave * (32 * WREC) : 0);
+    auto wbstore = [&](const auto& qw) {
 #pragma unroll
-        for (int j = 0; j < F1 / 32; ++j) *reinterpret_cast<f32x4*>(Wbs + w_dst + 32 * j * WREC) = rwb[j];
+        for (int j = 0; j < NWB; ++j) *reinterpret_cast<f32x4*>(Wbs + wb_dst[j]) = qw[j];
     };
-    wbload(0, 0);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) wbload(d, rwb[d]);
 
     // ---- epilogue A: lane = halo pixel mt * 32 + li, channels ntA * 32 + 8 g + 4 lk + {0..3}; the image replaces the staging buffers
     //      (everyone left the K loop through its last barrier)
@@ -242,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             }
         }
     }
-    wbstore();
-    __syncthreads();
+    wbstore(rwb[0]);
+    __syncthreads();                              // the t_a image is complete
 
     // =========================================================================================== phase B: t_b = relu(bn(W2b * t_a)), 3x3
     f32x16 accB[2];                               // one n-tile x two m-tiles (four patch rows) per wave
@@ -251,58 +298,67 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB[i][r] = 0.f;
-    constexpr int WNB = WNA, WMB = 4 / WNB;
     static_assert(MT == 2 * WMB, "two m-tiles per wave");
-    const int ntB = wave % WNB, mt0B = (wave / WNB) * 2;
     {
         // X fragment of m-tile i: patch rows 2 i + (li >> 4), column li & 15; tap (dy, dx) = constant shift (dy + 1) PITCH + (dx + HX0) REC.
         // HPX == 16: the image is one patch wide -- a lane whose tap column falls outside reads the zero record
         const int xbase = (li >> 4) * PITCH + (li & 15) * REC + lk * 16;
-        const char* Wf = Wbs + (ntB * 32 + li) * WREC;
+        const char* Wf = Wbs + ((PRIV ? 0 : ntB * 32) + li) * WREC;
         int w_sw[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) w_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
-        int tap = 0, chunk = 0;
-        constexpr int TOTAL = SB * 9;
-        for (int ks = 0; ks < TOTAL; ++ks) {
-            int ntap = tap + 1, nchunk = chunk;
-            if (ntap == 9) { ntap = 0; ++nchunk; }
-            const bool more = ks + 1 < TOTAL;
-            if (more) wbload(ntap, nchunk);
-            const int ky = tap / 3, kx = tap - ky * 3;                        // tap t = kh * 3 + kw at (kh - 1, kw - 1)   (pack_conv)
-            const int shift = chunk * TSLICE + ky * PITCH + (kx - 1 + HX0) * REC;
-            int xo[2];
+        for (int k0 = 0; k0 < TOTAL; k0 += DB) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                xo[i] = xbase + shift + (mt0B + i) * 2 * PITCH;
-                if (HPX == 16) {
-                    const int col = (li & 15) + kx - 1;
-                    if ((unsigned)col > 15u) xo[i] = ZERO_OFF + lk * 16;
-                }
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][0]);
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][1]);
+            for (int d = 0; d < DB; ++d) {
+                const int ks = k0 + d;
+                const int chunk = ks / 9, tap = ks - chunk * 9;
+                if (ks + DB < TOTAL) wbload(ks + DB, rwb[d]);
+                const int ky = tap / 3, kx = tap - ky * 3;                    // tap t = kh * 3 + kw at (kh - 1, kw - 1)   (pack_conv)
+                const int shift = chunk * TSLICE + ky * PITCH + (kx - 1 + HX0) * REC;
+                int xo[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32);
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32 + 64);
-                    accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accB[i], 0, 0, 0);
-                    accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accB[i], 0, 0, 0);
-                    accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accB[i], 0, 0, 0);
+                    xo[i] = xbase + shift + (mt0B + i) * 2 * PITCH;
+                    if (HPX == 16) {
+                        const int col = (li & 15) + kx - 1;
+                        if ((unsigned)col > 15u) xo[i] = ZERO_OFF + lk * 16;
+                    }
+                }
+                f16x8 wh[2], wl[2], xh[2][2], xl[2][2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    wh[kb] = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][0]);
+                    wl[kb] = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][1]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        xh[kb][i] = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32);
+                        xl[kb][i] = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32 + 64);
+                    }
+                }
+                // PRIV: the private tile's fragments are in flight (LDS serves a wave in order): the next K-step's tile may follow them
+                if (PRIV && ks + 1 < TOTAL) wbstore(rwb[(d + 1) % DB]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (ABL & 16) { accB[i][0] += (float)wh[kb][0] + (float)wl[kb][0] + (float)xh[kb][i][0] + (float)xl[kb][i][0]; continue; }
+                        accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kb], xl[kb][i], accB[i], 0, 0, 0);
+                        accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kb], xh[kb][i], accB[i], 0, 0, 0);
+                        accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kb], xh[kb][i], accB[i], 0, 0, 0);
+                    }
+                if (!PRIV) {
+                    __syncthreads();              // everyone is done reading the shared weight tile
+                    if (ks + 1 < TOTAL) {
+                        wbstore(rwb[(d + 1) % DB]);
+                        __syncthreads();
+                    }
                 }
             }
-            __syncthreads();
-            if (more) {
-                wbstore();
-                __syncthreads();
-            }
-            tap = ntap; chunk = nchunk;
         }
     }
+    if (PRIV) __syncthreads();                    // every wave is done with the t_a image (the t_b image and the 2c stage replace it)
 
     // weight loader of 2c: a stage = K-steps (2 st, 2 st + 1) of the 128 rows of chunk q: 8 float4 per thread
     unsigned wc_off[4];
@@ -373,7 +429,8 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             auto rsload = [&](int h) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
-                    rs[it] = *reinterpret_cast<const f32x4*>(p.x + (obase + (unsigned)(4 * h + (it >> 1)) * orow + (unsigned)(8 * (it & 1) * C)));
+                    rs[it] = (ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                       : *reinterpret_cast<const f32x4*>(p.x + (obase + (unsigned)(4 * h + (it >> 1)) * orow + (unsigned)(8 * (it & 1) * C)));
             };
             rsload(0);
             f32x16 acc[TMC][TNC];
@@ -448,7 +505,8 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const f32x4 v = o[it];
-                    *reinterpret_cast<f32x4*>(p.out + (obase + (unsigned)(4 * h + (it >> 1)) * orow + (unsigned)(8 * (it & 1) * C))) = v;
+                    if (!(ABL & 2) || v[0] == 12345.678f)
+                        *reinterpret_cast<f32x4*>(p.out + (obase + (unsigned)(4 * h + (it >> 1)) * orow + (unsigned)(8 * (it & 1) * C))) = v;
                 }
                 __syncthreads();                  // the C tile is free again (next pass / next chunk's weight stage)
             }
@@ -475,8 +533,38 @@ hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s)
 {
     if (!resblock_supported(F1, p.H, p.W)) return hipErrorInvalidValue;
     const int grid = resblock_grid(F1, p.N, p.H, p.W);
-    if (F1 == 64) hipLaunchKernelGGL((resblock_kernel<64, 8, 18>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((resblock_kernel<128, 4, 16>), dim3(grid), dim3(256), 0, s, p);
+    // Development builds: P2P_RB_VARIANT = KA (1 | 2) + 4 * PRIV picks among bit-identical forms of phases A / B, P2P_RB_ABL a TIMING ablation of the
+    // default form (results are garbage): 1 no residual loads, 2 no output stores, 4 no input loads, 8 no 2b weight loads, 16 / 32 no MFMAs in phase
+    // B / A.  The shipped library holds the default form only.
+#define P2P_RB_LAUNCH(KA_, DA_, PRIV_, ABL_)                                                                                              \
+    do {                                                                                                                                  \
+        if (F1 == 64) hipLaunchKernelGGL((resblock_kernel<64, 8, 18, DA_, 3, KA_, PRIV_, ABL_>), dim3(grid), dim3(256), 0, s, p);      \
+        else hipLaunchKernelGGL((resblock_kernel<128, 4, 16, DA_, 4, KA_, PRIV_, ABL_>), dim3(grid), dim3(256), 0, s, p);              \
+    } while (0)
+#ifdef P2P_DEV_SWITCHES
+    static const int variant = dev_env("P2P_RB_VARIANT") ? atoi(dev_env("P2P_RB_VARIANT")) : 1;
+    static const int abl = dev_env("P2P_RB_ABL") ? atoi(dev_env("P2P_RB_ABL")) : 0;
+    switch (abl) {
+    case 1: P2P_RB_LAUNCH(1, 4, false, 1); return hipGetLastError();
+    case 2: P2P_RB_LAUNCH(1, 4, false, 2); return hipGetLastError();
+    case 3: P2P_RB_LAUNCH(1, 4, false, 3); return hipGetLastError();
+    case 4: P2P_RB_LAUNCH(1, 4, false, 4); return hipGetLastError();
+    case 7: P2P_RB_LAUNCH(1, 4, false, 7); return hipGetLastError();
+    case 8: P2P_RB_LAUNCH(1, 4, false, 8); return hipGetLastError();
+    case 16: P2P_RB_LAUNCH(1, 4, false, 16); return hipGetLastError();
+    case 32: P2P_RB_LAUNCH(1, 4, false, 32); return hipGetLastError();
+    case 48: P2P_RB_LAUNCH(1, 4, false, 48); return hipGetLastError();
+    default: break;
+    }
+    switch (variant) {
+    case 2: P2P_RB_LAUNCH(2, 2, false, 0); return hipGetLastError();
+    case 5: P2P_RB_LAUNCH(1, 4, true, 0); return hipGetLastError();
+    case 6: P2P_RB_LAUNCH(2, 2, true, 0); return hipGetLastError();
+    default: break;
+    }
+#endif
+    P2P_RB_LAUNCH(1, 4, false, 0);
+#undef P2P_RB_LAUNCH
     return hipGetLastError();
 }
 

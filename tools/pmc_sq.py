@@ -8,13 +8,18 @@ import sys
 
 
 def main(paths):
+    match = None
+    if "--match" in paths:              # only kernels whose name contains this substring
+        i = paths.index("--match")
+        match = paths[i + 1]
+        paths = paths[:i] + paths[i + 2:]
     agg = {}
     for path in paths:
         db = sqlite3.connect(path)
         for name, counter, n, total, dur in db.execute("select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection group by kernel_name, counter_name"):
             agg.setdefault(name, {})[counter] = (n, total)
             agg[name]["_duration_ns_" + counter] = (n, dur)
-    keys = sorted(agg, key=lambda k: -agg[k].get("SQ_BUSY_CYCLES", (0, 0))[1])
+    keys = sorted((k for k in agg if match is None or match in k), key=lambda k: -agg[k].get("SQ_BUSY_CYCLES", (0, 0))[1])
     print("# rocprofv3 --pmc, bench.py --blocking --steps 1 --warmup 1 (two warm-up + timed + two profiling steps); values per launch, summed over the chip")
     for k in keys[:8]:
         c = {n: v[1] / max(v[0], 1) for n, v in agg[k].items()}
