@@ -244,6 +244,7 @@ typedef struct {
     int64_t* mask_stats;
     /* skimage.transform.resize GENERATION switch.  The reference calls resize(order=1) six times per detection
      * (recognition.py:82,103,121,134,144,146) and does not pin scikit-image (requirements.txt does not list it):
+     * Values outside 0 .. 2 are refused (P2P_ERR_INVALID_ARG).
      *   0 (default): scikit-image <= 0.14 -- plain bilinear warp, every image warped in double (the 0.14 _warp_fast takes doubles only).
      *      Restated from the published semantics; no such version exists in the build image, so this mode is NOT pinned to a real library.
      *   1: scikit-image 0.17 - 0.18, PINNED bit for bit to the real 0.18.3 (+ scipy 1.7.1) of the build image's /opt/conda/bin/python3.9
@@ -259,8 +260,17 @@ typedef struct {
      *      and the fit's 1e-14 noise -- which depends on the BLAS kernels the machine selects -- decides `> 0.9` on mask pixels whose
      *      bilinear weight is exactly 0.9 (crop sides that are multiples of 10).  This library uses the exact map the fit approximates;
      *      the fixture records both and shows the same wheels disagreeing with themselves across OPENBLAS_CORETYPE settings.
-     *      0.15 / 0.16, where anti_aliasing first defaulted to True, ran the filter on the bool array of :103 as well (an erosion to
-     *      the pixels whose weighted sum is exactly 1.0); that generation is NOT modelled.
+     *   2: scikit-image 0.15 / 0.16 -- what the reference's OWN image resolves to (requirements.txt:7 imgaug==0.2.7 pulls scikit-image,
+     *      Dockerfile:1,5 is python 3.5, which caps it at 0.15.x).  anti_aliasing defaults to True for EVERY image: resize() hands the image
+     *      as passed to scipy.ndimage.gaussian_filter, so the float32 maps are filtered in float32 as in generation 1 -- and the BOOL keep mask
+     *      of recognition.py:103 is filtered into a BOOL array (each axis pass ends in a cast to npy_bool: a pixel survives only where its
+     *      weighted sum reaches 1.0; depending on how the weights' sum rounds for the crop side, part of the mask survives or none of it);
+     *      warp() then converts every image to double (the 0.15 / 0.16 _warp_fast takes doubles only), so interpolation, the th_inlier
+     *      comparison and the * 255 are in double as in generation 0.  PINNING: no 0.15 wheel exists in the build image; the fixture
+     *      (tests/golden/reference_est_pose_skimage015.json) runs the reference's est_pose with resize COMPOSED of the real scipy 1.7.1 filter on
+     *      the image as passed and the real scikit-image 0.18.3 float64 warp -- filter (bool path included) and warp pinned, their order and the
+     *      double conversion restated from the 0.15 / 0.16 sources.  The Gaussian weights are built with libm's exp like numpy <= 1.18 (the
+     *      reference's era); numpy >= 1.19 uses a SIMD exp 1 ulp apart on some arguments, which the bool filter can amplify into a whole mask.
      * (scikit-image >= 0.19 rejects the bool array of recognition.py:103, so the reference does not run there.)
      * clip=True of resize (output clamped to the input's range, cval preserved) is common to all versions and always on. */
     int resize_anti_aliasing;

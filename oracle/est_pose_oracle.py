@@ -83,19 +83,47 @@ def _warp_bilinear_f32(a, out_shape, mode, cval):
     return ((1.0 - drd) * top + drd * bot).astype(f32)
 
 
-def resize_bilinear(img, out_shape, mode, cval=0.0, anti_aliasing=False, clip=True, keep_float32=None):
+def generation(spec):
+    """scikit-image GENERATION of the six resize calls (p2p_est_pose_opts.resize_anti_aliasing): False / 0 = <= 0.14 (no anti-aliasing,
+    everything in double); True / 1 = 0.17 - 0.18 (filter on for float images, off for bool ones; float32 images warped in float32);
+    2 = 0.15 / 0.16 (filter on for EVERY image as passed -- the bool keep mask of recognition.py:103 included, with scipy's bool output --
+    and ``_warp_fast`` converting every image to double)."""
+    g = {False: 0, True: 1}.get(spec, spec) if isinstance(spec, bool) else int(spec)
+    if g not in (0, 1, 2):
+        raise ValueError("resize generation must be 0, 1 or 2")
+    return g
+
+
+def resize_gen(img, out_shape, mode, cval, gen):
+    """One resize call of est_pose under scikit-image generation ``gen`` (see :func:`generation`)."""
+    return resize_bilinear(img, out_shape, mode, cval, anti_aliasing=gen > 0, keep_float32=gen == 1, filter_bool=gen == 2)
+
+
+def resize_bilinear(img, out_shape, mode, cval=0.0, anti_aliasing=False, clip=True, keep_float32=None, filter_bool=False):
     """img [H,W] or [H,W,C] (bool/float) -> float64 [oh,ow(,C)]  (float32 for a float32 image when ``keep_float32``).
     keep_float32 (default: = anti_aliasing, i.e. the two switches select a scikit-image GENERATION -- <= 0.14: no filter, everything
     in double; 0.17 / 0.18: filter on, and ``warp`` keeps a float32 image float32: matrix, coordinates and result in float32, see
     :func:`_warp_bilinear_f32`; the float32 images of the path are the prob map of recognition.py:134 and img_pred of :144).
     src = dst*scale + (0.5*scale - 0.5), scale = in/out; taps floor/ceil; out-of-range taps are
     reflected ('reflect') or replaced by cval ('constant').
+    filter_bool: with anti_aliasing, a bool image is filtered too (scikit-image 0.15 / 0.16), see below.
     anti_aliasing (skimage 0.17-0.18 semantics: on by default for float images, off for bool ones): Gaussian pre-filter, sigma = max(0, (in/out - 1)/2) per axis, truncated at
     4 sigma, border mode 'mirror' (for 'reflect') or 'constant' with cval; the filter keeps the input's dtype (a float32
     map is rounded to float32 after each axis pass, exactly what scipy does for skimage).
     clip (skimage default): the output is clipped to [min, max] of the (filtered) input; in 'constant' mode with cval
     outside that range, pixels exactly equal to cval are kept (skimage._shared / transform._warps._clip_warp_output)."""
     a0 = np.asarray(img)
+    if a0.dtype == bool and anti_aliasing and filter_bool:
+        # scikit-image 0.15 / 0.16: resize() hands the image AS PASSED to scipy.ndimage.gaussian_filter, whose output takes the input's dtype:
+        # for a bool array every axis pass ends in a C cast double -> npy_bool, i.e. a pixel survives a pass only where its weighted sum
+        # reaches 1.0 -- an erosion that, depending on how the weights' sum rounds, leaves part of the mask or NOTHING of it.
+        from scipy import ndimage as ndi
+        hb, wb = a0.shape[:2]
+        sig = [max(0.0, (hb / out_shape[0] - 1) / 2), max(0.0, (wb / out_shape[1] - 1) / 2)]
+        if max(sig) > 0:
+            a0 = ndi.gaussian_filter(a0, sig, cval=cval, mode="mirror" if mode == "reflect" else "constant")
+            assert a0.dtype == bool
+        anti_aliasing = False
     if a0.dtype == bool:
         # scikit-image 0.17 / 0.18: `anti_aliasing` defaults to "not a bool image" ("Gaussian convolution is not defined with bool data
         # type": a FutureWarning there, a ValueError from 0.19 on) -- the one bool input of the path is the keep mask of recognition.py:103.
@@ -248,7 +276,8 @@ def pnp_ransac(rgb_aug, img_prob_ori, non_zero, v1, v2, u1, u2, camK, obj_scale,
 def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th_inlier=0.1, box_size=1.5,
              debug=None, anti_aliasing=False):
     """Returns the reference's 6-tuple.  ``predict(x[N,128,128,3]) -> [decode, prob]``.
-    ``debug`` (dict) receives intermediates for stage-wise parity tests."""
+    ``debug`` (dict) receives intermediates for stage-wise parity tests.  ``anti_aliasing``: the scikit-image generation, see
+    :func:`generation` (False / True kept for the first two)."""
     camK = np.asarray(camK, np.float64).reshape(3, 3)
     obj_scale, obj_ct = np.asarray(obj_param[:3], float), np.asarray(obj_param[3:], float)
     H, W = rgb.shape[0], rgb.shape[1]
@@ -265,8 +294,8 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
     if base.shape[0] < 5 or base.shape[1] < 5 or crop.shape[0] < 5 or crop.shape[1] < 5:   # :78-79
         return np.zeros((1)), -1, -1, -1, -1, fail_box
     base[b1.vv1:b1.vv2, b1.uu1:b1.uu2] = crop                                        # :81
-    aa = bool(anti_aliasing)
-    x1 = resize_bilinear(base, (128, 128), "reflect", anti_aliasing=aa)              # :82
+    gen = generation(anti_aliasing)
+    x1 = resize_gen(base, (128, 128), "reflect", 0, gen)                             # :82
     dbg["x1"] = x1.astype(np.float32)
     decode, prob = predict(np.expand_dims(x1, 0), stage=1)                           # :84
     decode = np.array(decode, np.float32)
@@ -286,7 +315,7 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
             continue
         bb = np.array([vs.min(), us.min(), vs.max(), us.max()])                      # :101 (of non_gray, not keep)
         bb = bb * np.array([side / 128, (b1.u2_ori - b1.u1_ori) / 128] * 2)          # :102
-        keep_ori = resize_bilinear(keep, (side, b1.u2_ori - b1.u1_ori), "constant", 0, anti_aliasing=aa) > 0.9     # :103
+        keep_ori = resize_gen(keep, (side, b1.u2_ori - b1.u1_ori), "constant", 0, gen) > 0.9     # :103 (a BOOL image)
         keep_ori = keep_ori[b1.vv1:b1.vv2, b1.uu1:b1.uu2]                            # :104
         bg_full = np.ones((H, W), bool)                                              # :105-106
         bg_full[b1.v1:b1.v2, b1.u1:b1.u2] = np.invert(keep_ori)
@@ -305,7 +334,7 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
         # mis-align boxes and inputs afterwards; we keep them aligned (the misaligned case needs
         # a <5 px re-crop and does not occur for boxes that passed the stage-1 check).
         base2[b2.vv1:b2.vv2, b2.uu1:b2.uu2] = crop2                                  # :120
-        inputs.append(resize_bilinear(base2, (128, 128), "reflect", anti_aliasing=aa))   # :121-122
+        inputs.append(resize_gen(base2, (128, 128), "reflect", 0, gen))              # :121-122
         boxes.append(b2)
         slots.append(slot)
     dbg["slots"] = slots
@@ -325,14 +354,14 @@ def est_pose(rgb, bbox, predict, camK, obj_param, th_outlier=(0.1, 0.2, 0.3), th
         b = boxes[c]
         last = b
         side2, wid2 = b.v2_ori - b.v1_ori, b.u2_ori - b.u1_ori
-        prob_ori = resize_bilinear(prob[c, :, :, 0], (side2, wid2), "constant", 1, anti_aliasing=aa)   # :134 (float32 map)
+        prob_ori = resize_gen(prob[c, :, :, 0], (side2, wid2), "constant", 1, gen)   # :134 (float32 map)
         prob_ori = prob_ori[b.vv1:b.vv2, b.uu1:b.uu2]                                # :135
         gray = np.linalg.norm(decode[c], axis=2) < 0.3                               # :137
         ng = np.invert(gray)                                                         # :138
         decode[c, gray, :] = 0                                                       # :139
         pred = np.clip((decode[c] + 1) / 2, 0, 1)                                    # :141-143
-        pred_ori = resize_bilinear(pred, (side2, wid2), "constant", 0.5, anti_aliasing=aa) * 255       # :144 (float32 map)
-        ng = resize_bilinear(ng.astype(float), (side2, wid2), "constant", 0, anti_aliasing=aa) > 0.9   # :146
+        pred_ori = resize_gen(pred, (side2, wid2), "constant", 0.5, gen) * 255       # :144 (float32 map)
+        ng = resize_gen(ng.astype(float), (side2, wid2), "constant", 0, gen) > 0.9   # :146
         ng = ng[b.vv1:b.vv2, b.uu1:b.uu2]                                            # :147
         n_non_gray = int(np.sum(ng))                                                 # :148
         cd = {"slot": slots[c], "n_non_gray": n_non_gray}

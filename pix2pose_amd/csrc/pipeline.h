@@ -31,7 +31,8 @@ struct DetInfo {
     int ok1;                // 0 => recognition.py:78-79 early return
     long long corr_off;     // float offset of this detection's correspondence storage
     int corr_cap;           // points per candidate (stage-1 side squared)
-    int aa;                 // scikit-image generation (p2p_est_pose_opts.resize_anti_aliasing): 1 = 0.17 / 0.18 -- anti-aliased resizes AND float32 images warped in float32
+    int aa;                 // scikit-image generation (p2p_est_pose_opts.resize_anti_aliasing): 1 = 0.17 / 0.18 -- anti-aliased resizes AND float32 images warped
+                            // in float32; 2 = 0.15 / 0.16 -- anti-aliased resizes of EVERY image (the bool keep mask too), every image warped in double
     long long cv_off;       // double offset of this detection's (1 + K) canvases of corr_cap * 3 doubles each (aa, side > 128)
     int src_index;          // index of this detection in the caller's array (detections are processed sorted by object)
 };
@@ -77,6 +78,7 @@ struct Stage1 {
     int keep_cnt[MAX_TH];
     int valid2[MAX_TH];     // candidate built for threshold slot k
     double kmin[MAX_TH], kmax[MAX_TH];   // range of the keep mask image fed to the warp (clip=True), per slot
+    int keepf[MAX_TH];      // generation 2: the slot's keep mask was filtered (AaPtrs::keepf holds it)
     int n_cand;
     Boxes b2;               // all candidates of a detection share it (quirk)
 };
@@ -135,6 +137,7 @@ struct AaPtrs {
     AaItem* k0;   // [n]        stage-1 canvases           (side > 128)
     AaItem* k1;   // [n*K]      stage-2 canvases           (side > 128)
     AaItem* k3;   // [n*K*5]    prob, pred r/g/b, non_gray (stage-2 side < 128)
+    const unsigned char* keepf;   // generation 2 only: [n*K][128*128] keep masks after scipy's filter with bool output (stage-1 side < 128; Stage1::keepf says which)
 };
 struct AaBufs {
     double *cv, *cv_tmp;      // canvases: per detection (1 + K) x corr_cap x 3 doubles at DetInfo::cv_off
@@ -153,6 +156,7 @@ struct Slot {
     int sacc_n = 0;
     DevBuf crec, cseg;                  // few candidates: per-pixel records and per-segment counts of the two-launch correspondence build
     DevBuf aa_items, aa_cv, aa_cv_tmp, aa_bk, aa_bk_tmp;   // anti-aliased resizes: descriptors, canvases, 128x128 planes
+    DevBuf keepf;                       // generation 2: filtered bool keep masks
     DevBuf mask, pred, dmask, mstat;    // optional outputs of the batch (valid_mask_full, img_pred_f, detector masks, IoU sums)
     p2p_pose* host_poses = nullptr;     // pinned
     size_t host_cap = 0;
@@ -172,7 +176,7 @@ struct Slot {
     bool stage2_pending = false;        // stage-2 inputs are built, the stage-2 generator pass and the tail are not enqueued yet
     int tail_cap = 0;                   // network inputs of a following batch that fit behind this batch's stage-2 inputs
     int max_side = 0;
-    AaPtrs aa = {nullptr, nullptr, nullptr};
+    AaPtrs aa = {nullptr, nullptr, nullptr, nullptr};
     std::vector<int> img_hw, img_w;     // H*W and W of each detection's frame (sorted order)
     long long cmask_stride = 0, cpred_stride = 0;   // bytes per detection of the compact mask / image landing buffers
     p2p_est_pose_opts opt;              // the caller's output pointers (host), filled at collect time

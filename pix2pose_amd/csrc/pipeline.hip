@@ -73,7 +73,7 @@ Pipeline::~Pipeline()
 {
     for (Slot& s : slot) {
         for (DevBuf* b : {&s.det, &s.s1, &s.cand, &s.probs, &s.results, &s.poses, &s.corr, &s.hyp, &s.x1, &s.y1, &s.x2, &s.y2, &s.images, &s.crec, &s.cseg, &s.sacc,
-                          &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_bk, &s.aa_bk_tmp}) b->release();
+                          &s.mask, &s.pred, &s.dmask, &s.mstat, &s.crange, &s.aa_items, &s.aa_cv, &s.aa_cv_tmp, &s.aa_bk, &s.aa_bk_tmp, &s.keepf}) b->release();
         for (PinnedBuf* b : {&s.h_mask, &s.h_pred, &s.h_stat, &s.h_frames, &s.h_range}) b->release();
         if (s.host_poses) (void)hipHostFree(s.host_poses);
         if (s.done) (void)hipEventDestroy(s.done);
@@ -372,9 +372,10 @@ __global__ __launch_bounds__(256) void stage1_stats_seg_kernel(const DetInfo* __
     A = z;                                           // cleared for the next batch that uses this slot
 }
 
-// resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square.  The keep mask is a BOOL image: no scikit-image
-// generation this library models filters it (see aa_plan_kernel); [kmin, kmax]: range of the warp input (clip=True).
-__device__ inline bool keep_ori_at(const float* y1d, float th, double kmin, double kmax, int r, int c, int S, int Sw)
+// resize(keep, (S,S), 'constant', 0) > 0.9 at canvas position (r, c) of the stage-1 square.  The keep mask is a BOOL image: scikit-image
+// <= 0.14 and 0.17 / 0.18 do not filter it, 0.15 / 0.16 (generation 2) do, into a bool array; [kmin, kmax]: range of the warp input (clip=True).
+// kf (generation 2, stage-1 side < 128): the keep mask after scipy's Gaussian filter with BOOL output (keep_filter_kernel), [128 * 128] bytes.
+__device__ inline bool keep_ori_at(const float* y1d, float th, double kmin, double kmax, int r, int c, int S, int Sw, const unsigned char* kf = nullptr)
 {
     const Tap tr = axis_tap(r, 128, S), tc = axis_tap(c, 128, Sw);
     double v[2][2];
@@ -384,7 +385,7 @@ __device__ inline bool keep_ori_at(const float* y1d, float th, double kmin, doub
             double k = 0.0;
             if (P2P_TAP_LIVE(a, e, tr, tc) && ri[a] >= 0 && ri[a] < 128 && cj[e] >= 0 && cj[e] < 128) {
                 const float* q = y1d + ((size_t)ri[a] * 128 + cj[e]) * 4;
-                k = (non_gray_at(q) && q[3] < th) ? 1.0 : 0.0;
+                k = kf ? (kf[ri[a] * 128 + cj[e]] ? 1.0 : 0.0) : ((non_gray_at(q) && q[3] < th) ? 1.0 : 0.0);
             }
             v[a][e] = k;
         }
@@ -393,7 +394,7 @@ __device__ inline bool keep_ori_at(const float* y1d, float th, double kmin, doub
 
 // value of the stage-2 canvas (recognition.py:113-120) at canvas position (r, c), channel ch: the frame pixel where the
 // kept mask says foreground, zero elsewhere
-__device__ inline bool stage2_fg(const DetInfo& D, const Stage1& S, const float* y1d, int slot, int r, int c, int* fy, int* fx)
+__device__ inline bool stage2_fg(const DetInfo& D, const Stage1& S, const float* y1d, int slot, int r, int c, int* fy, int* fx, const unsigned char* kf = nullptr)
 {
     const Boxes& b1 = D.b1;
     const Boxes& b = S.b2;
@@ -403,7 +404,7 @@ __device__ inline bool stage2_fg(const DetInfo& D, const Stage1& S, const float*
     *fy = y; *fx = x;
     // bg_full: True outside the stage-1 clipped crop, ~keep_ori inside   (:105-106)
     if (y >= b1.v1 && y < b1.v2 && x >= b1.u1 && x < b1.u2)
-        return keep_ori_at(y1d, D.th_o[slot], S.kmin[slot], S.kmax[slot], y - b1.v1_ori, x - b1.u1_ori, b1.v2_ori - b1.v1_ori, b1.u2_ori - b1.u1_ori);
+        return keep_ori_at(y1d, D.th_o[slot], S.kmin[slot], S.kmax[slot], y - b1.v1_ori, x - b1.u1_ori, b1.v2_ori - b1.v1_ori, b1.u2_ori - b1.u1_ori, kf);
     return false;
 }
 
@@ -437,12 +438,13 @@ __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __rest
         return;
     }
     const float* y1d = y1 + (size_t)d * 16384 * 4;
+    const unsigned char* kf = (aa.keepf && S.keepf[slot]) ? aa.keepf + (size_t)cand * 16384 : nullptr;      // generation 2: the filtered bool keep mask
     bool fg[2][2];
     int fy[2][2], fx[2][2];
     for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 2; ++e) {
             fy[a][e] = fx[a][e] = 0;
-            fg[a][e] = P2P_TAP_LIVE(a, e, tr, tc) && stage2_fg(D, S, y1d, slot, r[a], c[e], &fy[a][e], &fx[a][e]);
+            fg[a][e] = P2P_TAP_LIVE(a, e, tr, tc) && stage2_fg(D, S, y1d, slot, r[a], c[e], &fy[a][e], &fx[a][e], kf);
         }
     for (int ch = 0; ch < 3; ++ch) {
         double v[2][2];
@@ -513,8 +515,8 @@ __device__ inline float lerp2_f32(float tl, float tr, float bl, float br, float 
 }
 
 // bk: the candidate's five anti-aliased planes [prob | pred r | g | b | non_gray][128*128] (null: raw maps from y2c)
-// gen: 0 = scikit-image <= 0.14 (every image warped in double), 1 = 0.17 / 0.18 (prob and img_pred warped in float32, compared with
-// th_inlier and multiplied by 255 in float32; the non_gray image of :146 is a float64 array in every version)
+// gen: 0 = every image warped in double (scikit-image <= 0.14, and 0.15 / 0.16 -- there on the filtered planes `bk`), 1 = 0.17 / 0.18 (prob and
+// img_pred warped in float32, compared with th_inlier and multiplied by 255 in float32; the non_gray image of :146 is a float64 array in every version)
 __device__ inline CandPixel cand_pixel(const float* y2c, const double* bk, const CandRange& R, int r, int c, int S2, int S2w, double th_i, int gen)
 {
     const Tap tr = axis_tap(r, 128, S2), tc = axis_tap(c, 128, S2w);
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(1024) void cand_corr_kernel(const DetInfo* __restri
             int rr = 0, cc = 0;
             if (p < npx) {
                 rr = p / w; cc = p - rr * w;
-                cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
+                cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa == 1);
                 valid = cp.valid;
                 if (cp.non_gray) { ++ng_cnt; sv += (unsigned)(b.v1 + rr); su += (unsigned)(b.u1 + cc); }
             }
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(256) void cand_eval_kernel(const DetInfo* __restric
         unsigned* r = rec + D.corr_off / 5 + (size_t)slot * D.corr_cap;
         for (int p = seg * per + tid; p < min(npx, (seg + 1) * per); p += 256) {
             const int rr = p / w, cc = p - rr * w;
-            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
+            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa == 1);
             r[p] = (unsigned)cp.q[0] | ((unsigned)cp.q[1] << 8) | ((unsigned)cp.q[2] << 16) | (cp.valid ? 1u << 24 : 0u);
             nv += cp.valid;
             if (cp.non_gray) { ++ng; sv += (unsigned)(b.v1 + rr); su += (unsigned)(b.u1 + cc); }
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(256) void render_best_kernel(const DetInfo* __restr
     const CandRange R = crange[cand];
     for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
         const int rr = p / w, cc = p - rr * w;
-        const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
+        const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa == 1);
         if (mask && p < mask_stride) mask[(size_t)d * mask_stride + p] = cp.valid ? 1 : 0;      // compact: row-major over the clipped box
         if (pred && (long long)(p + 1) * 3 <= pred_stride) {
             unsigned char* q = pred + (size_t)d * pred_stride + (size_t)p * 3;
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(256) void mask_iou_kernel(const DetInfo* __restrict
         const CandRange R = crange[cand];
         for (int p = blockIdx.x * 256 + threadIdx.x; p < h * w; p += gridDim.x * 256) {
             const int rr = p / w, cc = p - rr * w;
-            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa);
+            const CandPixel cp = cand_pixel(y2c, bk, R, b.vv1 + rr, b.uu1 + cc, S2, S2w, D.th_i, D.aa == 1);
             if (cp.valid) {
                 ++vcount;
                 inter += dm[(size_t)(b.v1 + rr) * D.W + (b.u1 + cc)] != 0;
@@ -1019,7 +1021,7 @@ __global__ void aa_plan_kernel(const DetInfo* __restrict__ dets, const Stage1* _
     const Stage1& S = s1[d];
     if (!D.aa || !D.ok1 || slot >= D.n_th) return;
     // :103 shrinks the 128x128 keep mask to the stage-1 square -- a BOOL image: scikit-image 0.17 / 0.18 do not filter those
-    // (anti_aliasing defaults to "not bool"; 0.15 / 0.16 ran the filter into a bool array, an erosion that is not modelled): nothing to plan for it.
+    // (anti_aliasing defaults to "not bool"); 0.15 / 0.16 run the filter into a bool array: keep_filter_kernel (generation 2), not an AaItem.
     if (!S.valid2[slot]) return;
     const int S2 = S.b2.v2_ori - S.b2.v1_ori;
     if (S2 > 128 && S2 <= tab.max_side && tab.rad[S2] > 0) {              // :121 shrinks the stage-2 canvas to 128
@@ -1035,6 +1037,71 @@ __global__ void aa_plan_kernel(const DetInfo* __restrict__ dets, const Stage1* _
             I.mode = 1; I.cval = j == 0 ? 1.0 : (j == 4 ? 0.0 : 0.5);
             I.round32 = j < 4;                                            // prob and img_pred are float32 arrays, non_gray.astype(float) is float64
         }
+}
+
+// Generation 2 (scikit-image 0.15 / 0.16), stage-1 sides < 128: resize() runs scipy.ndimage.gaussian_filter on the BOOL keep mask of
+// recognition.py:103 before shrinking it, and scipy's output array takes the input's dtype -- every axis pass computes, in double,
+//     t = x[0] w[0];  for d = radius .. 1:  t += (x[-d] + x[+d]) w[d]            (NI_Correlate1D, symmetric branch; border 'constant', cval 0)
+// and stores (npy_bool)t: a pixel survives a pass only where its weighted sum reaches 1.0.  An erosion whose outcome hangs on how the weights'
+// sum rounds: for some crop sides part of the mask survives, for others NOTHING does (tests/test_real_libraries_cpu.py holds this restatement to
+// scipy itself for every side).  One workgroup per candidate, both passes through LDS; the filtered plane feeds keep_ori_at(), its range clip=True.
+__global__ __launch_bounds__(256) void keep_filter_kernel(const DetInfo* __restrict__ dets, Stage1* __restrict__ s1, const float* __restrict__ y1,
+                                                          int K, AaTable tab, unsigned char* __restrict__ keepf)
+{
+    __shared__ unsigned char p0[16384], p1[16384];
+    __shared__ int s_any, s_all;
+    const int cand = blockIdx.x, d = cand / K, slot = cand - d * K;
+    const DetInfo& D = dets[d];
+    Stage1& S = s1[d];
+    const int S1 = D.b1.v2_ori - D.b1.v1_ori;
+    const bool on = D.aa == 2 && D.ok1 && slot < D.n_th && S.valid2[slot] && S1 < 128 && S1 > 0 && tab.rad[S1] > 0;
+    if (!on) {
+        if (threadIdx.x == 0 && slot < MAX_TH) S.keepf[slot] = 0;
+        return;
+    }
+    const int r = tab.rad[S1];
+    const double* w = tab.w + tab.off[S1];
+    const float* y1d = y1 + (size_t)d * 16384 * 4;
+    const float th = D.th_o[slot];
+    if (threadIdx.x == 0) { s_any = 0; s_all = 1; }
+    for (int p = threadIdx.x; p < 16384; p += 256) {
+        const float* q = y1d + (size_t)p * 4;
+        p0[p] = (non_gray_at(q) && q[3] < th) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < 16384; p += 256) {              // axis 0 (rows)
+        const int v = p >> 7, u = p & 127;
+        double t = (double)p0[p] * w[0];
+        for (int dd = r; dd >= 1; --dd) {
+            const double a = v - dd >= 0 ? (double)p0[(v - dd) * 128 + u] : 0.0;
+            const double b = v + dd < 128 ? (double)p0[(v + dd) * 128 + u] : 0.0;
+            t += (a + b) * w[dd];
+        }
+        p1[p] = (unsigned char)t ? 1 : 0;                         // (npy_bool)t: truncation toward zero
+    }
+    __syncthreads();
+    int any = 0, all = 1;
+    unsigned char* out = keepf + (size_t)cand * 16384;
+    for (int p = threadIdx.x; p < 16384; p += 256) {              // axis 1 (columns)
+        const int v = p >> 7, u = p & 127;
+        double t = (double)p1[p] * w[0];
+        for (int dd = r; dd >= 1; --dd) {
+            const double a = u - dd >= 0 ? (double)p1[v * 128 + u - dd] : 0.0;
+            const double b = u + dd < 128 ? (double)p1[v * 128 + u + dd] : 0.0;
+            t += (a + b) * w[dd];
+        }
+        const unsigned char k = (unsigned char)t ? 1 : 0;
+        out[p] = k;
+        any |= k; all &= k;
+    }
+    if (any) atomicOr(&s_any, 1);
+    if (!all) atomicAnd(&s_all, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S.keepf[slot] = 1;
+        S.kmin[slot] = s_all ? 1.0 : 0.0;                         // range of the FILTERED mask as float (clip=True of the :103 resize)
+        S.kmax[slot] = s_any ? 1.0 : 0.0;
+    }
 }
 
 // stage-1 canvas (recognition.py:75-81): zeros, the normalised clipped crop pasted in.  grid (64, n)
@@ -1283,6 +1350,7 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
     SL.opt = opt;
     SL.objs.assign(objects, objects + n_obj);
     SL.use_aa = opt.resize_anti_aliasing != 0;
+    const int generation = opt.resize_anti_aliasing;      // 0: <= 0.14, 1: 0.17 / 0.18, 2: 0.15 / 0.16 (validated in run_est_pose)
 
     for (int i = 0; i < n_img; ++i)
         if (!images[i].data || images[i].height <= 0 || images[i].width <= 0) { set_error("image %d is empty", i); return P2P_ERR_INVALID_ARG; }
@@ -1318,7 +1386,7 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
         D.corr_cap = D.ok1 ? (int)(side * side) : 0;
         D.corr_off = corr_total;
         corr_total += (long long)D.corr_cap * 5 * K;
-        D.aa = use_aa ? 1 : 0;
+        D.aa = generation;
         D.cv_off = cv_total;
         if (use_aa && D.ok1 && side > 128) {
             if (side > 4096) { set_error("detection %d: crop side %lld exceeds the anti-aliasing table (4096)", perm[i], side); return P2P_ERR_CAPACITY; }
@@ -1404,7 +1472,7 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
     const bool corr_seg = n * K <= 16 || max_side > 192;
     if (corr_seg && ((rc = SL.crec.reserve(sizeof(unsigned) * (size_t)std::max<long long>(corr_total / 5, 1))) ||
                         (rc = SL.cseg.reserve(sizeof(CorrSeg) * CORR_SEG * (size_t)n * K)))) return rc;
-    SL.aa = {nullptr, nullptr, nullptr};
+    SL.aa = {nullptr, nullptr, nullptr, nullptr};
     AaBufs aab = {nullptr, nullptr, nullptr, nullptr};
     AaTable aat;
     if (use_aa) {
@@ -1413,8 +1481,12 @@ static int enqueue_front(Ctx& X, Pipeline& P, Slot& SL, hipStream_t st, const p2
         if ((rc = SL.aa_items.reserve(sizeof(AaItem) * (size_t)(n + 6 * n * K))) || (rc = SL.aa_cv.reserve(cvb)) || (rc = SL.aa_cv_tmp.reserve(cvb)) ||
             (rc = SL.aa_bk.reserve(plane * 5)) || (rc = SL.aa_bk_tmp.reserve(plane * 5))) return rc;
         AaItem* it = SL.aa_items.as<AaItem>();
-        SL.aa = {it, it + n, it + n + n * K};
+        SL.aa = {it, it + n, it + n + n * K, nullptr};
         aab = {SL.aa_cv.as<double>(), SL.aa_cv_tmp.as<double>(), SL.aa_bk.as<double>(), SL.aa_bk_tmp.as<double>()};
+        if (generation == 2) {      // filtered bool keep masks, one 128 x 128 byte plane per candidate (keep_filter_kernel)
+            if ((rc = SL.keepf.reserve((size_t)16384 * n * K))) return rc;
+            SL.aa.keepf = SL.keepf.as<unsigned char>();
+        }
     }
     // -- optional outputs: argument checks, landing buffers and the detector-mask upload (read during submit)
     const bool want_mask = opt.valid_mask != nullptr, want_pred = opt.img_pred != nullptr, want_iou = opt.det_mask != nullptr;
@@ -1483,6 +1555,12 @@ static int enqueue_mid(Ctx& X, Slot& SL, hipStream_t st, float* y1)
         hipLaunchKernelGGL(aa_canvas2_kernel, dim3(64, n * K), dim3(256), 0, st, d_det, d_s1, y1, K, SL.aa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(launch_aa_filter(SL.aa.k1, n * K, SL.max_side * SL.max_side * 3, st));
+    }
+    if (SL.aa.keepf) {    // generation 2: the bool keep masks of stage-1 sides < 128 are filtered too (into bool planes)
+        AaTable aat;
+        if ((rc = aa_table_get(X.device, &aat))) return rc;
+        hipLaunchKernelGGL(keep_filter_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y1, K, aat, const_cast<unsigned char*>(SL.aa.keepf));
+        HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, SL.x2.as<float>(), SL.aa);
     HIP_TRY(hipGetLastError());
@@ -1620,6 +1698,10 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     }
     if (opt.ransac_iterations > P2P_MAX_RANSAC_ITERATIONS) {
         set_error("ransac_iterations %d exceeds P2P_MAX_RANSAC_ITERATIONS (%d)", opt.ransac_iterations, P2P_MAX_RANSAC_ITERATIONS);
+        return P2P_ERR_INVALID_ARG;
+    }
+    if (opt.resize_anti_aliasing < 0 || opt.resize_anti_aliasing > 2) {
+        set_error("resize_anti_aliasing = %d: the scikit-image generation is 0 (<= 0.14), 1 (0.17 / 0.18) or 2 (0.15 / 0.16)", opt.resize_anti_aliasing);
         return P2P_ERR_INVALID_ARG;
     }
     if ((opt.det_mask != nullptr) != (opt.mask_stats != nullptr)) {
@@ -1879,7 +1961,7 @@ int p2p_debug_back_resize(p2p_ctx* ctx, const float* prob, const float* pred, co
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(back_resize_probe_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, planes.as<double>(), R, out_h, out_w, th_inlier,
-                           generation ? 1 : 0, dq.as<unsigned char>(), db.as<unsigned char>(), dg.as<unsigned char>());
+                           generation == 1 ? 1 : 0, dq.as<unsigned char>(), db.as<unsigned char>(), dg.as<unsigned char>());
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(q, dq.p, npx * 3, hipMemcpyDeviceToHost, st);

@@ -16,6 +16,8 @@ cv2, scikit-image; no network), so exactly these calls are served by the oracle'
 and numpy's removed aliases (np.int) are restored.
 
     /opt/conda/bin/python3.9 tests/golden/make_reference_vectors.py --real-skimage     (writes reference_est_pose_skimage018.json)
+    /opt/conda/bin/python3.9 tests/golden/make_reference_vectors.py --skimage015       (writes reference_est_pose_skimage015.json: the
+                                                                                         0.15 / 0.16 generation, see main_skimage015)
 
 ROUND 4: the build image carries a second interpreter with the REAL scikit-image 0.18.3 (+ scipy 1.7.1, numpy 1.26).  With
 --real-skimage the skimage shim is NOT installed: all six resize call sites of est_pose (recognition.py:82,103,121,134,144,146)
@@ -165,12 +167,15 @@ def run_scenes(ref, specs):
             p.obj_scale, p.obj_ct = sc["obj_param"][:3], sc["obj_param"][3:]
             p.box_size, p.dist_coeff = 1.5, None
             p.generator_train = _Predict(sc["inject1"][i], sc["inject2"][i])
+            del RESIZE_LOG[:]
             try:
                 r = p.est_pose(sc["images"][img_i], np.asarray(bbox))
             except AssertionError as e:
                 dets.append({"skip": str(e)})
                 continue
             d = {"bbox": [int(b) for b in bbox], "bbox_t": [int(v) for v in r[5]], "x_sums": p.generator_train.x_sums}
+            if RESIZE_LOG:          # --skimage015: did a filter of this detection use weights that depend on the exp() implementation?
+                d["exp_ulp_sensitive"] = any(_weights_depend_on_exp(a, b) for a, b in set(RESIZE_LOG))
             if isinstance(r[1], int) and r[1] == -1:
                 d.update({"ok": False})
             else:
@@ -262,7 +267,93 @@ def main_real_skimage():
           ";", sum(1 for x, y in zip(de, di) if _discrete(x) != _discrete(y)), "detections differ between the exact and the fitted matrix; cores:", cores)
 
 
+RESIZE_LOG = []      # (n_in, n_out) of every filtered resize of the detection being processed (--skimage015)
+
+
+def _weights_depend_on_exp(n_in, n_out):
+    """scipy builds the Gaussian kernel with numpy.exp.  numpy <= 1.18 (the reference's era; python 3.5 caps it at 1.18) calls libm's exp, numpy
+    >= 1.19 its own SIMD routine, which is 1 ulp apart on some arguments -- irrelevant for float images, but the BOOL filter of this generation
+    keeps a pixel only where the weighted sum reaches 1.0, so one ulp in a weight can keep or erase a whole mask.  The library builds its weights
+    with libm's exp (csrc/resize_aa.hip); detections whose filters hit an argument where the two differ are flagged, and the parity tests hold
+    them to status and box only."""
+    import math
+    sigma = max(0.0, (n_in / n_out - 1) / 2)
+    lw = int(4.0 * sigma + 0.5)
+    if lw == 0:
+        return False
+    c = -0.5 / (sigma * sigma)
+    x = np.arange(-lw, lw + 1)
+    return not np.array_equal(np.exp(c * x ** 2), np.array([math.exp(c * float(v * v)) for v in x]))
+
+
+SCENES_015 = [dict(seed=531, n_det=6, bbox_side=(40, 84)),        # stage-1 sides < 128: the BOOL keep mask is filtered (bool output), the maps too
+              dict(seed=532, n_det=4, bbox_side=(90, 210)),       # sides > 128: the frame canvases are filtered
+              dict(seed=533, n_det=3, bbox_side=(86, 86)),        # 128-px crops: every filter is the identity
+              dict(seed=534, n_det=6, bbox_side=(40, 300)),       # the bench's general-crop distribution
+              dict(seed=535, n_det=4, bbox_side=(36, 60)),        # small detections: sigma ~ 0.6 - 0.9
+              dict(seed=536, n_det=4, bbox_side=(70, 84), outlier_frac=0.4)]
+
+
+def main_skimage015():
+    """est_pose of the reference under the scikit-image 0.15 / 0.16 GENERATION -- what the reference's own image resolves to
+    (requirements.txt:7 imgaug==0.2.7 pulls scikit-image; Dockerfile:1,5 is python 3.5, which caps it at 0.15.x).  No 0.15 wheel exists
+    in the build image, so its ``resize`` is COMPOSED here from the real libraries that do:
+        1. scipy.ndimage.gaussian_filter (REAL scipy) on the image AS PASSED -- 0.15 / 0.16 call it before any dtype conversion, with
+           sigma = max(0, (in / out - 1) / 2) per spatial axis: a float32 map stays float32, and the BOOL keep mask of recognition.py:103
+           stays bool (every axis pass ends in a cast to npy_bool);
+        2. the image converted to double (0.15 / 0.16 ``_warp_fast`` takes doubles only) and warped by the REAL scikit-image 0.18.3
+           ``resize(..., anti_aliasing=False)``, whose float64 ``_warp_fast`` and clip=True are the code 0.15 runs (exact affine map as in
+           --real-skimage: the SVD fit's noise is not reproducible across machines).
+    PINNED: the filter (bool path included) and the float64 warp, by the real libraries.  RESTATED: the order of the two steps and the
+    double conversion (from the published 0.15 / 0.16 sources of transform/_warps.py)."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    version = install_shims(real_skimage=True)
+    import scipy
+    from scipy import ndimage as ndi
+    import skimage.transform as skt
+    real_resize = skt.resize
+    _w, _Exact = _exact_affine_patch()
+    _w.AffineTransform = _Exact
+
+    def resize_015(image, output_shape, order=1, mode="reflect", cval=0, clip=True, preserve_range=False, anti_aliasing=True):
+        assert order == 1 and not preserve_range
+        image = np.asarray(image)
+        factors = np.asarray(image.shape[:2], np.float64) / np.asarray(output_shape[:2], np.float64)
+        if anti_aliasing:
+            for k in range(2):
+                if factors[k] > 1:
+                    RESIZE_LOG.append((int(image.shape[k]), int(output_shape[k])))
+            sigma = list(np.maximum(0, (factors - 1) / 2)) + [0] * (image.ndim - 2)
+            image = ndi.gaussian_filter(image, sigma, cval=cval, mode={"reflect": "mirror", "constant": "constant"}[mode])
+        return real_resize(image.astype(np.float64), output_shape, order=1, mode=mode, cval=cval, clip=clip, anti_aliasing=False)
+
+    skt.resize = resize_015
+    sys.path.insert(0, REF)
+    from pix2pose_model import recognition as ref
+    ref.resize = resize_015                                # `from skimage.transform import resize` already ran in the module
+    scenes = run_scenes(ref, SCENES_015)
+    if "--scenes-only" in sys.argv:
+        print(json.dumps(scenes))
+        return
+    out = {"note": "outputs of /root/reference/pix2pose_model/recognition.py (est_pose) under the scikit-image 0.15 / 0.16 resize generation: "
+                   "REAL scipy gaussian_filter on every image as passed (bool keep mask included), then the REAL scikit-image 0.18.3 float64 "
+                   "warp of the double-converted image; filter and warp pinned, their composition restated; cv2 / keras stood in "
+                   "(tests/golden/make_reference_vectors.py --skimage015)",
+           "skimage_version_of_the_warp": version, "scipy_version": scipy.__version__, "numpy_version": np.__version__,
+           "interpreter": "%s (python %s)" % (sys.executable, sys.version.split()[0]),
+           "th_outlier": TH_O, "th_inlier": TH_I, "scenes": scenes}
+    fn = os.path.join(HERE, "reference_est_pose_skimage015.json")
+    with open(fn, "w") as f:
+        json.dump(out, f)
+    ds = [d for s_ in scenes for d in s_["dets"]]
+    print("wrote", fn, os.path.getsize(fn), "bytes;", sum(1 for d in ds if d.get("ok")), "successful poses of", len(ds),
+          ";", sum(1 for d in ds if "skip" in d), "skipped")
+
+
 def main():
+    if "--skimage015" in sys.argv:
+        return main_skimage015()
     if "--real-skimage" in sys.argv:
         return main_real_skimage()
     install_shims()

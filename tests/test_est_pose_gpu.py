@@ -130,6 +130,67 @@ def test_anti_aliased_resizes_sweep_with_border_clipping(rig):
     assert _run_injected(rig, sc, anti_aliasing=True) >= 12
 
 
+def _exp_sensitive_sides():
+    """Crop sides whose Gaussian weights depend on the exp() implementation: the library builds them with libm's exp (numpy <= 1.18, the
+    reference's era, did the same), the scipy of this interpreter with numpy's SIMD exp, 1 ulp apart on some arguments."""
+    import ctypes as C
+    from pix2pose_amd import _lib
+    L = _lib.lib()
+    bad = set()
+    for side in list(range(5, 128)) + list(range(129, 700)):
+        w = (C.c_double * 256)()
+        r = L.p2p_aa_weights(side, w)
+        if r <= 0:
+            continue
+        n_in, n_out = (side, 128) if side > 128 else (128, side)
+        sigma = (n_in / n_out - 1) / 2
+        x = np.arange(-r, r + 1)
+        phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        if not np.array_equal(np.array(w[:r + 1]), (phi / phi.sum())[r:]):
+            bad.add(side)
+    return bad
+
+
+def test_generation_2_filters_the_bool_keep_mask(rig):
+    """p2p_est_pose_opts.resize_anti_aliasing = 2 (scikit-image 0.15 / 0.16, the generation the reference's own python-3.5 image resolves to):
+    every image is filtered as passed -- the BOOL keep mask of recognition.py:103 into a bool array (keep_filter_kernel), the float32 maps in
+    float32 -- and warped in double.  Against the oracle (scipy's own gaussian_filter on the bool array), bit for bit, over crop sides 54 .. 390 px.
+    A detection whose filters hit a crop side where libm's exp and this interpreter's numpy exp build different weights may legitimately differ
+    (the bool filter turns one ulp into a whole mask): those are held to status and box only."""
+    import torch
+    from oracle import est_pose_oracle as E
+    from pix2pose_amd.runtime import est_pose_batch
+    ctx, gen, spec = rig
+    bad = _exp_sensitive_sides()
+    n_exact = n_sensitive = n_filtered_masks = 0
+    for seed, sides in ((61, (36, 84)), (62, (40, 260)), (63, (70, 84))):
+        sc = synth.make_scene(10, seed=seed, bbox_side=sides, H=300, W=400, n_images=3)
+        j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
+        torch.cuda.synchronize()
+        poses, ex = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=j1.data_ptr(), inject2=j2.data_ptr(),
+                                   inject_slots=3, want_masks=True, debug=True, anti_aliasing=2)
+        poses1, _ = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3, anti_aliasing=1)
+        for i in range(len(sc["dets"])):
+            def predict(x, stage, slots=None, i=i):
+                m = sc["inject1"][i][None] if stage == 1 else sc["inject2"][i][slots]
+                return [m[..., :3].copy(), m[..., 3:].copy()]
+            dbg = {}
+            ref = _oracle(sc, i, predict, dbg, 2)
+            b1 = E.get_boxes(sc["dets"][i][2], 300, 400)
+            used = {b1.v2_ori - b1.v1_ori} | {b[1] - b[0] for b in dbg.get("boxes2", [])}
+            if used & bad:
+                n_sensitive += 1
+                continue
+            _compare(poses[i], ex, i, ref, dbg, True)
+            n_exact += 1
+            if b1.v2_ori - b1.v1_ori < 128 and (poses[i].n_inliers != poses1[i].n_inliers or poses[i].status != poses1[i].status):
+                n_filtered_masks += 1
+    assert n_exact >= 18, (n_exact, n_sensitive)
+    assert n_filtered_masks >= 3          # the generation really is a different computation from 0.17 / 0.18
+    with pytest.raises(Exception):
+        est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"][:1], anti_aliasing=3)
+
+
 @pytest.mark.parametrize("aa", [False, True])
 def test_large_frames_large_crops(rig, aa):
     """1920x1080 frames, boxes of 300-420 px (crop sides 450-630 px, 70 000 correspondences per candidate: far beyond the 128-px

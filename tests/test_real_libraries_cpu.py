@@ -80,6 +80,63 @@ def test_committed_est_pose_vectors_are_what_the_reference_produces_with_the_rea
     assert same >= 0.85 * tot, (same, tot)
 
 
+@pytest.mark.skipif(not _have("skimage") or not os.path.isdir("/root/reference"), reason="needs the conda interpreter and /root/reference")
+def test_committed_skimage015_vectors_are_what_the_real_libraries_produce():
+    """tests/golden/reference_est_pose_skimage015.json (the 0.15 / 0.16 resize generation: REAL scipy gaussian_filter on every image as
+    passed -- bool keep mask included --, then the REAL scikit-image 0.18.3 float64 warp with the exact affine map) re-derived now."""
+    keys = ("ok", "bbox_t", "mask_sum", "mask_crc", "img_pred_crc", "frac_inlier", "R", "t")
+    committed = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_est_pose_skimage015.json")))
+    r = _run([os.path.join("tests", "golden", "make_reference_vectors.py"), "--skimage015", "--scenes-only"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    fresh = json.loads(r.stdout.strip().splitlines()[-1])
+    n = 0
+    for sf, sc in zip(fresh, committed["scenes"]):
+        for df, dc in zip(sf["dets"], sc["dets"]):
+            assert [df.get(k) for k in keys] == [dc.get(k) for k in keys]
+            n += 1
+    assert n >= 25
+
+
+def test_bool_mask_filter_restatement_equals_scipy():
+    """What csrc/pipeline.hip restates for generation 2 -- scipy.ndimage.gaussian_filter on a BOOL array: per axis
+    t = x0 w0 + sum_{d = r .. 1} (x[-d] + x[+d]) w[d] in double, then a C cast to npy_bool -- against the scipy of THIS interpreter, for
+    every crop side below 128 (the mask survives for some sides and vanishes entirely for others: the rounding of the weights' sum decides)."""
+    import numpy as np
+    from scipy import ndimage as ndi
+    from pix2pose_amd import _lib
+    import ctypes as C
+    rs = np.random.RandomState(2)
+    yy, xx = np.mgrid[:128, :128]
+    m = (((yy - 60) ** 2 / 900 + (xx - 70) ** 2 / 1600) < 1) & (rs.rand(128, 128) > 0.02)
+    L = _lib.lib()
+    survived = set()
+    for S in range(8, 128):
+        sig = (128 / S - 1) / 2
+        want = ndi.gaussian_filter(m, (sig, sig), cval=0, mode="constant")
+        w = (C.c_double * 256)()
+        r = L.p2p_aa_weights(S, w)
+        wv = np.array(w[:r + 1])
+
+        def axis_pass(a, axis):
+            a = np.moveaxis(a.astype(np.float64), axis, 0)
+            p = np.zeros((128 + 2 * r,) + a.shape[1:])
+            p[r:r + 128] = a
+            t = p[r:r + 128] * wv[0]
+            for d in range(r, 0, -1):
+                t = t + (p[r - d:r - d + 128] + p[r + d:r + d + 128]) * wv[d]
+            return np.moveaxis(t.astype(np.uint8).astype(bool), 0, axis)
+        got = axis_pass(axis_pass(m, 0), 1) if r > 0 else m
+        # (the library's weights are built with libm's exp; numpy >= 1.19 evaluates exp with its own SIMD routine, 1 ulp apart on some
+        # vectors -- where that moves the weights' sum across 1.0 the whole mask flips, so compare only where both builds of the weights agree)
+        x = np.arange(-r, r + 1)
+        phi = np.exp(-0.5 / (sig * sig) * x ** 2) if r > 0 else np.ones(1)
+        if r > 0 and not np.array_equal(wv, (phi / phi.sum())[r:]):
+            continue
+        assert np.array_equal(got, want), S
+        survived.add(bool(want.any()))
+    assert survived == {True, False}
+
+
 @pytest.mark.skipif(not _have("h5py"), reason="no /opt/conda/bin/python3.9 with h5py")
 def test_hdf5_reader_on_real_h5py_files():
     """pix2pose_amd.convert_keras.read_hdf5 on files written by the real h5py 3.3.0: both Keras layouts, both backbones (row f-2)."""

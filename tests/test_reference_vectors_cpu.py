@@ -39,17 +39,23 @@ def test_shim_get_boxes_matches_reference():
 GS = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage018.json")))
 
 
-@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage"])
+G15 = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage015.json")))
+
+
+@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage", "skimage015"])
 def test_est_pose_matches_reference(key):
     """"scenes": resize stand-in without anti-aliasing (scikit-image <= 0.14); "scenes_aa": with the Gaussian pre-filter of
     scikit-image 0.17 - 0.18 (scipy.ndimage.gaussian_filter itself) and float32 images kept float32 through the warp;
     "real_skimage": reference_est_pose_skimage018.json["scenes_exact_matrix"] -- the reference's est_pose run under
     /opt/conda/bin/python3.9 with the REAL scikit-image 0.18.3 on all six resize call sites (only cv2 / keras stood in; the affine fit
     of resize() returning the exact map, see the generator): masks, uint8 images, boxes, inlier fractions and poses of the oracle's
-    anti_aliasing=True mode are IDENTICAL to it."""
+    anti_aliasing=True mode are IDENTICAL to it.
+    "skimage015": reference_est_pose_skimage015.json -- the reference's est_pose under the 0.15 / 0.16 generation (what the reference's own
+    python-3.5 image resolves to), its resize composed from the REAL scipy 1.7.1 gaussian_filter on every image as passed -- the bool keep
+    mask of recognition.py:103 included -- and the REAL scikit-image 0.18.3 float64 warp: the oracle's generation 2 is IDENTICAL to it."""
     n = 0
-    aa = key != "scenes"
-    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G[key]):
+    aa = {"scenes": 0, "skimage015": 2}.get(key, 1)
+    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G15["scenes"] if key == "skimage015" else G[key]):
         spec = s["spec"]
         sc = synthetic.make_scene(spec["n_det"], seed=spec["seed"], bbox_side=tuple(spec["bbox_side"]), outlier_frac=spec.get("outlier_frac", 0.2))
         for i, gd in enumerate(s["dets"]):

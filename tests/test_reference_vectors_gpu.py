@@ -15,35 +15,42 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 G = json.load(open(os.path.join(HERE, "golden", "reference_est_pose.json")))
 GS = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage018.json")))
+G15 = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage015.json")))
 
 
 def _crc(a):
     return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
 
 
-@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage"])
+@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage", "skimage015"])
 def test_est_pose_pipeline_matches_reference_vectors(key):
     """"scenes_aa": p2p_est_pose_opts.resize_anti_aliasing = 1 against the reference run with an anti-aliasing resize
     (scikit-image 0.17 - 0.18 semantics; the Gaussian filter there was scipy.ndimage's own).
     "real_skimage": the same option against the reference's est_pose run with the REAL scikit-image 0.18.3 on all six resize call sites
     (tests/golden/reference_est_pose_skimage018.json["scenes_exact_matrix"], generated under /opt/conda/bin/python3.9): masks and uint8
-    images bit for bit."""
+    images bit for bit.
+    "skimage015": resize_anti_aliasing = 2 against the reference's est_pose under the scikit-image 0.15 / 0.16 generation (REAL scipy filter on
+    every image as passed, the bool keep mask included; REAL 0.18.3 float64 warp; tests/golden/reference_est_pose_skimage015.json)."""
     import torch
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
     ctx = Context(0, max_batch=16)
     gen = Generator(W.synthetic_weights("paper", 1), "paper", ctx)
     spec = ObjectSpec(gen, synthetic.OBJ_PARAM, G["th_outlier"], G["th_inlier"])
-    n = 0
-    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G[key]):
+    n = n_sens = 0
+    sk_gen = {"scenes": 0, "skimage015": 2}.get(key, 1)
+    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G15["scenes"] if key == "skimage015" else G[key]):
         sp = s["spec"]
         sc = synthetic.make_scene(sp["n_det"], seed=sp["seed"], bbox_side=tuple(sp["bbox_side"]), outlier_frac=sp.get("outlier_frac", 0.2))
         j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
         torch.cuda.synchronize()
         poses, ex = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=j1.data_ptr(), inject2=j2.data_ptr(),
-                                   inject_slots=3, want_masks=True, debug=True, anti_aliasing=key != "scenes")
+                                   inject_slots=3, want_masks=True, debug=True, anti_aliasing=sk_gen)
         H, Wd = sc["images"].shape[1:3]
         for i, gd in enumerate(s["dets"]):
             p = poses[i]
+            if gd.get("exp_ulp_sensitive"):      # a filter of this detection used weights that differ between libm's exp (the library, numpy <= 1.18)
+                n_sens += 1                      # and the fixture's numpy 1.26 exp: the bool filter of generation 2 may turn that ulp into a mask
+                continue
             assert (p.status == 0) == gd["ok"]
             assert list(p.bbox_t) == gd["bbox_t"]
             assert abs(float(ex["x1"][i].astype(np.float64).sum()) - gd["x_sums"][0]) < 1e-2      # stage-1 network input (float32 sums)
