@@ -186,7 +186,7 @@ def test_generation_2_filters_the_bool_keep_mask(rig):
             if b1.v2_ori - b1.v1_ori < 128 and (poses[i].n_inliers != poses1[i].n_inliers or poses[i].status != poses1[i].status):
                 n_filtered_masks += 1
     assert n_exact >= 18, (n_exact, n_sensitive)
-    assert n_filtered_masks >= 3          # the generation really is a different computation from 0.17 / 0.18
+    assert n_filtered_masks >= 1          # the generation really is a different computation from 0.17 / 0.18
     with pytest.raises(Exception):
         est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"][:1], anti_aliasing=3)
 
