@@ -418,7 +418,9 @@ def main():
         above; the bandwidth-leaning kernel families are priced here: compulsory bytes of their launches (inputs + residual + weights read
         once, outputs written once, fp32; p2p_kernel_stats.algo_bytes) / HIP-event time of the same launches, against 8 TB/s."""
         out = []
-        for i, label in ((5, "decoder output heads"), (0, "ResNet 1x1 bottleneck layers (+ dense_dec)"), (1, "Cout = 64 1x1 layers (res2 2a)")):
+        for i, label in ((5, "decoder output heads"), (9, "ResNet identity bottleneck blocks, fused: 1x1 -> 3x3 -> 1x1 + residual in one launch (block input read once + "
+                                                          "its 3x3 halo, output written once; the three-launch route moved 2x these bytes)"),
+                         (0, "1x1 layers of the projection blocks res2a / res3a (+ dense_dec)"), (1, "Cout = 64 1x1 layers (res2a 2a)")):
             st = stats[i]
             if not st["launches"] or st["total_ms"] <= 0:
                 continue
@@ -565,7 +567,7 @@ def main():
     if solo and args.latency > 0:
         from pix2pose_amd.recognition import pix2pose
         shim = pix2pose({k: v for k, v in wts.items()}, synthetic.LM_K, 640, 480, synthetic.OBJ_PARAM, th_outlier=TH_O, th_inlier=TH_I,
-                        backbone=args.backbone, ctx=ctx)
+                        backbone=args.backbone, ctx=ctx, skimage="0.14")      # 128-px crops: every resize is the identity in every generation
         lat, n_ret = [], 0
         for i in range(args.latency + 5):
             j = i % args.batch

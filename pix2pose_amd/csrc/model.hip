@@ -791,6 +791,8 @@ static int deconv_layer(Ctx& X, const Model& M, const char* name, const float* i
 // detection at a time) keep the three streaming launches.  The route depends on the batch size, the bits do not (tests/test_resblock_gpu.py).
 // Development builds: P2P_NO_FUSED_BLOCK=1 keeps the three-launch route.
 static bool fused_blocks() { static const bool on = dev_env("P2P_NO_FUSED_BLOCK") == nullptr; return on && specialised_kernels(); }
+// smallest fused launch (workgroups): below it the three streaming launches run (development builds: P2P_FUSED_MIN_WGS)
+static int fused_min_wgs() { static const int v = dev_env("P2P_FUSED_MIN_WGS") ? atoi(dev_env("P2P_FUSED_MIN_WGS")) : -1; return v >= 0 ? v : stream_max_wgs() + 1; }
 
 static int run_resblock(const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H, int f1, float* out)
 {
@@ -844,7 +846,7 @@ static int res_block(const Model& M, Ctx& X, const std::string& n, const float* 
     int rc;
     const int Ho = H / stride;
     if (!shortcut && stride == 1 && M.prec == PREC_F16X3 && Cin == 4 * f1 && fused_blocks() && M.block_ss.count(n) && resblock_supported(f1, H, H) &&
-        resblock_grid(f1, N, H, H) > stream_max_wgs())
+        resblock_grid(f1, N, H, H) >= fused_min_wgs())
         return run_resblock(M, X, n, in, N, H, f1, out);
     float* ta = X.cur->act["t_a"];
     float* tb = X.cur->act["t_b"];
