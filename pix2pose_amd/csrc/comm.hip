@@ -2,7 +2,7 @@
 // has no multi-GPU call site -- tools/5_evaluation_bop_basic.py:289-304 walks its detections one by one on one GPU).
 //
 // Detections are independent, so every rank runs the whole pipeline on its shard and nothing crosses GPUs on the data path.
-// The only exchange is the (R, t, score) records at the end: 144-byte p2p_pose structs, n_max per rank, gathered DEVICE to DEVICE
+// The only exchange is the (R, t, score) records at the end: 168-byte p2p_pose structs (they carry the score_type-2 mask sums), n_max per rank, gathered DEVICE to DEVICE
 // on the communicator's own stream once the batch's tail has finished (the collect has waited for it and taken the operand-range verdict;
 // the NEXT batch's tail, already queued on the tail stream, is not waited for) -- the records never visit the host before the gather --
 // and copied to the host once, after it: an event behind the copy, not a stream synchronisation.

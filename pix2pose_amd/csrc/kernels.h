@@ -153,6 +153,7 @@ struct ResBlockParams {
 bool resblock_supported(int F1, int H, int W);
 int resblock_grid(int F1, int N, int H, int W);        // workgroups of the launch
 hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s);
+hipError_t launch_resproj(const ResBlockParams& p, int F1, hipStream_t s);      // the projection blocks res2a / res3a (H, W = output grid)
 
 // Small-batch variant (igemm_stream.hip): one wave per 32x32 / 64x32 output tile, operands streamed global -> registers with a deep
 // software pipeline.  Bit-identical to the batched kernel that serves the layer: every output element is the same chain of MFMAs over

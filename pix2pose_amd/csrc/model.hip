@@ -481,9 +481,11 @@ static int build_model(const TensorMap& T, Model& M)
 static int pack_block_ss(Model& M)
 {
     if (M.backbone != P2P_BACKBONE_RESNET50 || M.prec != PREC_F16X3) return P2P_OK;
-    for (const char* nm : {"res2b", "res2c", "res3b", "res3c", "res3d"}) {
+    for (const char* nm : {"res2a", "res2b", "res2c", "res3a", "res3b", "res3c", "res3d"}) {
         const std::string n = nm;
-        const ConvLayer &a = M.L.at(n + "_2a"), &b = M.L.at(n + "_2b"), &c = M.L.at(n + "_2c");
+        if (!M.L.count(n + "_2c") && !M.L.count(n + "_2c1")) continue;
+        // (projection blocks: the last convolution is the merged [2c | shortcut] layer, pack_merged_shortcut)
+        const ConvLayer &a = M.L.at(n + "_2a"), &b = M.L.at(n + "_2b"), &c = M.L.count(n + "_2c") ? M.L.at(n + "_2c") : M.L.at(n + "_2c1");
         const int F1 = a.Cout, C = c.Cout;
         float* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, (size_t)(4 * F1 + 2 * C) * sizeof(float)));
@@ -840,11 +842,64 @@ static int run_resblock(const Model& M, Ctx& X, const std::string& n, const floa
     return P2P_OK;
 }
 
+// The projection blocks res2a / res3a in the same kernel (resblock.hip, PROJ): H = input grid, Ho = H / stride the output grid.
+static int run_resproj(const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H, int Cin, int f1, int stride, float* out)
+{
+    const ConvLayer &a = M.L.at(n + "_2a"), &b = M.L.at(n + "_2b"), &c = M.L.at(n + "_2c1");
+    const int C = 4 * f1, Ho = H / stride;
+    ResBlockParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = in; p.out = out; p.N = N; p.H = Ho; p.W = Ho;
+    const size_t xb = (size_t)N * H * H * Cin * sizeof(float), ob = (size_t)N * Ho * Ho * C * sizeof(float);
+    if (xb >= 0xFFFFFFF0ull || ob >= 0xFFFFFFF0ull) { set_error("run_resproj: tensor exceeds the 4 GB buffer-descriptor range (lower max_batch)"); return P2P_ERR_CAPACITY; }
+    p.x_bytes = (unsigned)xb;
+    p.wa_bytes = (unsigned)((size_t)round_up(a.Cout, 128) * a.K * sizeof(float));
+    p.wb_bytes = (unsigned)((size_t)round_up(b.Cout, 128) * b.K * sizeof(float));
+    p.wc_bytes = (unsigned)((size_t)round_up(c.Cout, 128) * c.K * sizeof(float));
+    p.range_acc = X.range_cur;
+    if (X.grp && X.grp->models.size() > 1) {
+        const GroupCtx& G = *X.grp;
+        const int ng = (int)G.models.size();
+        if (ng > IGEMM_MAX_GROUPS) { set_error("run_resproj: %d object groups exceed IGEMM_MAX_GROUPS", ng); return P2P_ERR_CAPACITY; }
+        for (int g = 0; g < ng; ++g) {
+            const Model& Mg = *G.models[g];
+            if (Mg.prec != PREC_F16X3 || !Mg.block_ss.count(n)) { set_error("run_resproj: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
+            p.grp[g] = {Mg.L.at(n + "_2a").w, Mg.L.at(n + "_2b").w, Mg.L.at(n + "_2c1").w, Mg.block_ss.at(n), G.start[g], 0};
+        }
+        p.grp[ng] = {nullptr, nullptr, nullptr, nullptr, G.start[ng], 0};
+        p.n_groups = ng;
+    } else {
+        p.grp[0] = {a.w, b.w, c.w, M.block_ss.at(n), 0, 0};
+        p.grp[1] = {nullptr, nullptr, nullptr, nullptr, N, 0};
+        p.n_groups = 1;
+    }
+    hipStream_t st = X.cur->stream;
+    if (X.profiling) {
+        const double px = (double)N * Ho * Ho;
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), 9, 2.0 * px * ((double)Cin * f1 + 9.0 * f1 * f1 + (double)(f1 + Cin) * C),
+                          4.0 * (px * Cin + px * C + (double)Cin * f1 + 9.0 * f1 * f1 + (double)(f1 + Cin) * C)};      // the sampled input pixels once, the output once, the panels
+        if (!ev.a || !ev.b) return P2P_ERR_HIP;
+        HIP_TRY(hipEventRecord(ev.a, st));
+        HIP_TRY(launch_resproj(p, f1, st));
+        HIP_TRY(hipEventRecord(ev.b, st));
+        X.prof_pending.push_back(ev);
+        return P2P_OK;
+    }
+    HIP_TRY(launch_resproj(p, f1, st));
+    return P2P_OK;
+}
+
+static bool fused_proj_blocks() { static const bool on = dev_env("P2P_NO_FUSED_PROJ") == nullptr; return on; }      // development builds: res2a / res3a on three launches
+
 static int res_block(const Model& M, Ctx& X, const std::string& n, const float* in, int N, int H,
                      int Cin, int f1, int stride, bool shortcut, float* out)
 {
     int rc;
     const int Ho = H / stride;
+    if (shortcut && M.prec == PREC_F16X3 && M.L.count(n + "_2c1") && fused_blocks() && fused_proj_blocks() && M.block_ss.count(n) &&
+        ((f1 == 64 && Cin == 64 && stride == 1) || (f1 == 128 && Cin == 256 && stride == 2)) && resblock_supported(f1, Ho, Ho) &&
+        resblock_grid(f1, N, Ho, Ho) >= fused_min_wgs())
+        return run_resproj(M, X, n, in, N, H, Cin, f1, stride, out);
     if (!shortcut && stride == 1 && M.prec == PREC_F16X3 && Cin == 4 * f1 && fused_blocks() && M.block_ss.count(n) && resblock_supported(f1, H, H) &&
         resblock_grid(f1, N, H, H) >= fused_min_wgs())
         return run_resblock(M, X, n, in, N, H, f1, out);

@@ -56,11 +56,16 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo)
 
 // DA / DB: K-steps of global loads in flight in phases A / B (register rings).  A K-step of these phases is 12 - 18 MFMAs per wave -- a few
 // hundred cycles, a fraction of a loaded memory round trip -- so with the usual one-step-ahead prefetch every step waited for its operands.
-template <int F1, int PY, int HPX, int DA, int DB, int KA, bool PRIV, int ABL = 0>
+// PROJ: the projection blocks res2a / res3a (resnet50_mod.py:76-118): the block input has CIN channels on a grid STRIDE times finer than the output
+// (the 1x1 layers of a stride-2 block sample its even pixels), and the block's last 1x1 convolution carries the projection shortcut as a second K
+// segment [t_b (F1) | x (CIN)] (model.hip: pack_merged_shortcut) instead of a residual add.
+template <int F1, int PY, int HPX, int DA, int DB, int KA, bool PRIV, int ABL = 0, int CIN = 4 * F1, int STRIDE = 1, bool PROJ = false>
 __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p)
 {
-    constexpr int C = 4 * F1;
-    constexpr int SA = C / 32;                    // K-steps of 2a
+    constexpr int C = 4 * F1;                     // output channels
+    constexpr int SA = CIN / 32;                  // K-steps of 2a
+    constexpr int SX = CIN / 32;                  // PROJ: K-steps of the shortcut segment of the last convolution
+    static_assert(PROJ || (CIN == C && STRIDE == 1), "identity blocks keep their shape");
     constexpr int SB = F1 / 32;                   // channel slices of t_a / t_b
     constexpr int NCH = C / 128;                  // 128-channel output chunks of 2c
     constexpr int HX0 = HPX == 18 ? 1 : 0;        // halo columns left of the patch (0: the image is one patch wide)
@@ -79,7 +84,9 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     constexpr int TMC = 2, TNC = MT == 4 ? 2 : 1, WGMC = MT / TMC, WGNC = 4 / WGMC;      // phase-C wave tiling (igemm.hip's)
     constexpr int CLD = 128 + 4;
     constexpr int CS_BYTES = TMC * 32 * CLD * 4;
-    constexpr int ZERO_OFF = cmax(cmax(KA * (XS_BYTES + WA_BYTES), T_BYTES + WB_BYTES), T2_BYTES + cmax(WC_BYTES, CS_BYTES));
+    constexpr int XC_BYTES = NPIX * REC;          // PROJ: a 32-channel slice of the block input at the patch's own pixels, staged per K-step
+    constexpr int ZERO_OFF = cmax(cmax(KA * (XS_BYTES + WA_BYTES), T_BYTES + WB_BYTES),
+                                  T2_BYTES + cmax(PROJ ? 128 * WREC + XC_BYTES : WC_BYTES, CS_BYTES));
     constexpr int SS_OFF = ZERO_OFF + 128, SS_FLOATS = 4 * F1 + 2 * C;      // the folded BatchNorm vectors: read by every epilogue, kept in LDS
     constexpr int SMEM = SS_OFF + SS_FLOATS * 4;
     static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
@@ -147,12 +154,12 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             const int hy = hp / HPX, hx = hp - hy * HPX;
             const int iy = y0 - 1 + hy, ix = x0 - HX0 + hx;
             const bool ok = hp < NPA && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            x_off[j] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * C + q * 4) * 4) : OOB;
+            x_off[j] = ok ? (unsigned)((((n * p.H * STRIDE + iy * STRIDE) * (p.W * STRIDE) + ix * STRIDE) * CIN + q * 4) * 4) : OOB;
             x_dst[j] = hp * REC + q * 8;
         }
         unsigned wa_off[F1 / 32];
 #pragma unroll
-        for (int j = 0; j < F1 / 32; ++j) wa_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)C + (unsigned)lseg * 4u) * 4u;
+        for (int j = 0; j < F1 / 32; ++j) wa_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)CIN + (unsigned)lseg * 4u) * 4u;
         constexpr int NSTG = SA / KA;              // stages of KA K-steps
         static_assert(SA % KA == 0 && NSTG % DA == 0, "ring depth divides the stages");
         f32x4 rx[DA][KA][MA], rw[DA][KA][F1 / 32];      // ring slot d holds stages congruent to d (mod DA); all indices are static after unrolling
@@ -360,22 +367,24 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     }
     if (PRIV) __syncthreads();                    // every wave is done with the t_a image (the t_b image and the 2c stage replace it)
 
-    // weight loader of 2c: a stage = K-steps (2 st, 2 st + 1) of the 128 rows of chunk q: 8 float4 per thread
+    // weight loader of the last convolution.  Identity blocks: a stage = K-steps (2 st, 2 st + 1) of the 128 rows of chunk q: 8 float4 per thread.
+    // Projection blocks: a stage = ONE K-step of chunk q (its K runs over [t_b | x]: row stride F1 + CIN), and the x slice of the K-step beside it.
+    constexpr int K2C = PROJ ? F1 + CIN : F1;
     unsigned wc_off[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wc_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)F1 + (unsigned)lseg * 4u) * 4u;
+    for (int j = 0; j < 4; ++j) wc_off[j] = ((unsigned)(lrow + 32 * j) * (unsigned)K2C + (unsigned)lseg * 4u) * 4u;
     f32x4 rwc[2][4];
     auto wcload = [&](int q, int st) {
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+        for (int k2 = 0; k2 < (PROJ ? 1 : 2); ++k2)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                rwc[k2][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wc, wc_off[j] + (unsigned)(q * 128 * F1 * 4), (2 * st + k2) * 128, 0));
+                rwc[k2][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wc, wc_off[j] + (unsigned)(q * 128 * K2C * 4), ((PROJ ? st : 2 * st) + k2) * 128, 0));
     };
     char* Wcs = smem + T2_BYTES;
     auto wcstore = [&]() {
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+        for (int k2 = 0; k2 < (PROJ ? 1 : 2); ++k2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(Wcs + k2 * 128 * WREC + w_dst + 32 * j * WREC) = rwc[k2][j];
     };
@@ -406,6 +415,135 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     wcstore();
     __syncthreads();
 
+    if constexpr (PROJ) {
+    // =========================================================================================== phase C (projection): out = relu(bn([W2c | W1] [t_b ; x]))
+    // K-outer, chunk-inner: every 128-channel output chunk keeps its accumulators, so a K-step's activation fragments (from the t_b image, or from
+    // the x slice staged for it) are read once for all chunks; per (K-step, chunk) only the 16 KB weight tile moves.  K order per output element:
+    // t_b slices, then x slices -- igemm.hip's order over the two segments.
+        constexpr int KC = SB + SX, NSTAGE = KC * NCH;
+        const int wm = wave / WGNC, wn = wave % WGNC;
+        char* Xcs = Wcs + 128 * WREC;
+        const char* Bf = Wcs + (wn * TNC * 32 + li) * WREC;
+        int w_sw[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) w_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
+        // x loader: float4 idx = tid + 256 j -> quad idx & 7 of patch pixel perm(idx >> 3) (the store pattern of the halo loaders)
+        constexpr int XP = NPIX * 8 / 256;
+        unsigned xc_off[XP];
+        int xc_dst[XP];
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            const int idx = tid + 256 * j;
+            const int t8 = idx >> 3, q = idx & 7;
+            const int px = (t8 & ~7) | ((t8 & 1) << 2) | ((t8 >> 1) & 3);
+            xc_off[j] = (unsigned)((((n * p.H * STRIDE + (y0 + (px >> 4)) * STRIDE) * (p.W * STRIDE) + (x0 + (px & 15)) * STRIDE) * CIN + q * 4) * 4);
+            xc_dst[j] = px * REC + q * 8;
+        }
+        f32x4 rxc[XP];
+        auto xcload = [&](int sx) {
+#pragma unroll
+            for (int j = 0; j < XP; ++j) rxc[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xc_off[j] + (unsigned)sx * 128u, 0, 0));
+        };
+        auto xcstore = [&]() {
+#pragma unroll
+            for (int j = 0; j < XP; ++j) {
+                uint2 hi, lo;
+                split4(rxc[j], hi, lo);
+                *reinterpret_cast<uint2*>(Xcs + xc_dst[j]) = hi;
+                *reinterpret_cast<uint2*>(Xcs + xc_dst[j] + 64) = lo;
+            }
+        };
+        f32x16 acc[NCH][TMC][TNC];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+#pragma unroll
+            for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                for (int j = 0; j < TNC; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+        // (stage 0's weight tile was stored with the t_b image; its activations come from that image)
+#pragma unroll 1
+        for (int ks = 0; ks < KC; ++ks) {
+            const char* Af = (ks < SB ? smem + ks * T2SLICE : Xcs) + (wm * TMC * 32 + li) * REC + lk * 16;
+            f16x8 ah[2][TMC], al[2][TMC];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < TMC; ++i) {
+                    ah[kb][i] = *reinterpret_cast<const f16x8*>(Af + i * 32 * REC + kb * 32);
+                    al[kb][i] = *reinterpret_cast<const f16x8*>(Af + i * 32 * REC + kb * 32 + 64);
+                }
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int stage = ks * NCH + q;
+                const bool more = stage + 1 < NSTAGE;
+                const bool next_ks = q + 1 == NCH;                       // the next stage starts K-step ks + 1
+                if (more) {
+                    wcload(next_ks ? 0 : q + 1, next_ks ? ks + 1 : ks);
+                    if (next_ks && ks + 1 >= SB) xcload(ks + 1 - SB);
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    f16x8 bh[TNC], bl[TNC];
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j) {
+                        bh[j] = *reinterpret_cast<const f16x8*>(Bf + j * 32 * WREC + w_sw[kb][0]);
+                        bl[j] = *reinterpret_cast<const f16x8*>(Bf + j * 32 * WREC + w_sw[kb][1]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNC; ++j) {
+                            acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb][i], bh[j], acc[q][i][j], 0, 0, 0);
+                            acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bl[j], acc[q][i][j], 0, 0, 0);
+                            acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bh[j], acc[q][i][j], 0, 0, 0);
+                        }
+                }
+                __syncthreads();                  // everyone is done with the weight tile (and, at the end of a K-step, with its x slice)
+                if (more) {
+                    wcstore();
+                    if (next_ks && ks + 1 >= SB) xcstore();
+                    __syncthreads();
+                }
+            }
+        }
+        // epilogue: chunk after chunk through the (now free) stage region
+        float* Cs = reinterpret_cast<float*>(Wcs);
+        const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+        constexpr int NIT = TMC * 32 / 8;
+        const unsigned orow = (unsigned)(p.W * C);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const unsigned obase = (unsigned)(((n * p.H + y0) * p.W + x0 + r0) * C + q * 128 + c4);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + 4 * F1 + q * 128 + c4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + 4 * F1 + C + q * 128 + c4);
+#pragma unroll
+            for (int h = 0; h < WGMC; ++h) {
+                if (wm == h) {
+#pragma unroll
+                    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNC; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CLD + (wn * TNC + j) * 32 + li] = acc[q][i][j][r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + 8 * it) * CLD + c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = relu_nan(fmaf(v[e], sc[e], sh[e]) + 0.f);      // igemm.hip's epilogue with no residual: + 0
+                    amax = range_note4(amax, v);
+                    *reinterpret_cast<f32x4*>(p.out + (obase + (unsigned)(4 * h + (it >> 1)) * orow + (unsigned)(8 * (it & 1) * C))) = v;
+                }
+                __syncthreads();
+            }
+        }
+    } else {
     // =========================================================================================== phase C: out = relu(bn(W2c t_b) + x)
     {
         const int wm = wave / WGNC, wn = wave % WGNC;
@@ -516,6 +654,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             }
         }
     }
+    }
     range_commit(p.range_acc, amax);
 }
 
@@ -528,6 +667,17 @@ bool resblock_supported(int F1, int H, int W)
 }
 
 int resblock_grid(int F1, int N, int H, int W) { return N * (H / (F1 == 64 ? 8 : 4)) * (W / 16); }
+
+// Projection blocks of the ResNet-50 front: res2a (F1 = 64, 64 input channels, stride 1, 32x32) and res3a (F1 = 128, 256 input channels on the
+// 32x32 grid, stride 2, 16x16 output).  p.H / p.W are the OUTPUT grid; w2c = the merged [2c | shortcut] panel.
+hipError_t launch_resproj(const ResBlockParams& p, int F1, hipStream_t s)
+{
+    if (!resblock_supported(F1, p.H, p.W)) return hipErrorInvalidValue;
+    const int grid = resblock_grid(F1, p.N, p.H, p.W);
+    if (F1 == 64) hipLaunchKernelGGL((resblock_kernel<64, 8, 18, 2, 3, 1, false, 0, 64, 1, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((resblock_kernel<128, 4, 16, 4, 4, 1, false, 0, 256, 2, true>), dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s)
 {

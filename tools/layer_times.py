@@ -38,13 +38,16 @@ def main(path, batch=256):
         layers = [("conv1+pool", LAYERS[0][1])] + LAYERS[2:]
         KF["conv1+pool"] = 49 + 131 + 66       # input, the skip's 32 channels, the pooled tensor
     if any("resblock_kernel" in r[0] for r in ks[:len(layers)]):      # identity bottleneck blocks as one launch each (resblock.hip)
-        fused, out = ("res2b", "res2c", "res3b", "res3c", "res3d"), []
+        seq = [r[0] for r in ks[:12]]
+        n_fused_front = sum("resblock_kernel" in nm for nm in seq)
+        fused = ("res2a", "res2b", "res2c", "res3a", "res3b", "res3c", "res3d") if "resblock_kernel" in seq[1] else ("res2b", "res2c", "res3b", "res3c", "res3d")
+        out = []
         for nm, mmac in layers:
             b = nm.split("_")[0]
             if b in fused:
                 if nm.endswith("_2a"):
                     out.append((b + " (fused)", sum(m for n2, m in layers if n2.split("_")[0] == b)))
-                    KF[b + " (fused)"] = 2 * (262 if b.startswith("res2") else 131)      # block input read once, output written once
+                    KF[b + " (fused)"] = {"res2a": 66 + 262, "res3a": 66 + 131}.get(b, 2 * (262 if b.startswith("res2") else 131))      # block input read once, output written once
                 continue
             out.append((nm, mmac))
         layers = out
