@@ -104,7 +104,7 @@ for r in $(seq 1 $ROUNDS); do
     one_bench prev $AB/prev "" >> $REP
     one_bench head $ROOT "" >> $REP
     one_bench noguard $ROOT $AB/noguard/libp2p_mi355.so >> $REP
-    one_bench nofuse $ROOT $ROOT/pix2pose_amd/libp2p_mi355_dev.so P2P_NO_FUSED_BLOCK=1 >> $REP      # head with the identity blocks as three launches (round 4's route)
+    one_bench nofuse $ROOT $ROOT/pix2pose_amd/libp2p_mi355_dev.so "P2P_NO_FUSED_BLOCK=1 P2P_NO_FUSED_PROJ=1" >> $REP      # head with the identity blocks as three launches (round 4's route)
 done
 
 # per-layer times of one blocking step: prev, head, and head with the three-launch blocks
@@ -112,7 +112,7 @@ for v in prev head nofuse; do
     tree=$ROOT; [ $v == prev ] && tree=$AB/prev
     rm -rf $OUT/ab_prof_$v
     if [ $v == nofuse ]; then
-        (cd $tree && P2P_LIB=$ROOT/pix2pose_amd/libp2p_mi355_dev.so P2P_NO_FUSED_BLOCK=1 rocprofv3 --kernel-trace -d $OUT/ab_prof_$v -o t -- python bench.py --steps 2 --warmup 1 --blocking --no-legs > /dev/null 2>&1)
+        (cd $tree && P2P_LIB=$ROOT/pix2pose_amd/libp2p_mi355_dev.so P2P_NO_FUSED_BLOCK=1 P2P_NO_FUSED_PROJ=1 rocprofv3 --kernel-trace -d $OUT/ab_prof_$v -o t -- python bench.py --steps 2 --warmup 1 --blocking --no-legs > /dev/null 2>&1)
     else
     (cd $tree && rocprofv3 --kernel-trace -d $OUT/ab_prof_$v -o t -- python bench.py --steps 2 --warmup 1 --blocking --no-legs > /dev/null 2>&1)
     fi
