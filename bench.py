@@ -556,7 +556,7 @@ def main():
                 e1.record(cst)
             ctx.synchronize()
             ms = e0.elapsed_time(e1) / args.batch64
-            b64["n%d" % n_in] = {"ms_per_pass": ms, "inputs_per_s": n_in / ms * 1e3, "algo_tflops": n_in * AE_GFLOP[args.backbone] / ms / 1e3}
+            b64["n%d" % n_in] = {"ms_per_pass": ms, "inputs_per_s": n_in / ms * 1e3, "algo_tflops": n_in * AE_GFLOP[args.backbone] / ms}
             del xin, yout
         if "n64" in b64:
             b64["value"] = b64["n64"]["inputs_per_s"]
