@@ -293,6 +293,31 @@ def test_bop_directory_stream_one_and_two_ranks(tmp_path):
         inject = {k: z[k] for k in ("key", "inject1", "inject2")}
     rows = E.run(dict(cfg, path_to_output=None), "ycbv", dump, base_dir="/", batch_images=3, inject=inject)
     assert len(rows) == len(one)
+    # the harness's per-step exchange THROUGH THE C ABI (p2p_est_pose_collect_gathered over RCCL: parallel.CabiPoseGather) with the one rank a
+    # test box has: run_distributed on the "nccl" backend, two images per step -> every pooled batch is collected through the collective and
+    # the rows are rebuilt from the gathered records (mask sums included) -- identical to the plain run
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env_keep = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        rows_c = E.run_distributed(dict(cfg, path_to_output=None), "ycbv", dump, base_dir="/", backend="nccl", batch_images=2, inject=inject)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in env_keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert len(rows_c) == len(rows)
+    for a, b in zip(rows_c, rows):
+        assert [a["scene_id"], a["im_id"], a["obj_id"]] == [b["scene_id"], b["im_id"], b["obj_id"]] and a["score"] == b["score"]
+        np.testing.assert_array_equal(np.asarray(a["R"]).reshape(-1), np.asarray(b["R"]).reshape(-1))
+        np.testing.assert_array_equal(np.asarray(a["t"]).reshape(-1), np.asarray(b["t"]).reshape(-1))
     for a, f in zip(rows, one):
         assert [a["scene_id"], a["im_id"], a["obj_id"]] == [int(f[0]), int(f[1]), int(f[2])]
         assert str(a["score"]) == f[3] and " ".join(map(str, np.asarray(a["R"]).flatten().tolist())) == f[4]
