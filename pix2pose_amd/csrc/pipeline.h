@@ -47,6 +47,9 @@ struct AaItem {
     int mode;               // 0 = 'mirror' (skimage mode 'reflect'), 1 = 'constant'
     int round32;            // the image is a float32 array in the reference: round to float32 after each axis pass
     double cval;
+    int r0, r1, c0, c1;     // r1 > r0: region of interest -- rows [r0, r1) x columns [c0, c1) hold everything of the image that is not EXACTLY zero
+                            // (stage-2 canvases: the object's silhouette is ~45 % of the crop); the image and its filter passes are neither written
+                            // nor read outside the region (grown by the radius per pass), readers take +0.0 there.  r1 <= r0: the whole image
     double vmin, vmax;      // range of the filtered image (skimage clips the warp output to it)
     unsigned long long kmin, kmax;   // the same as order-preserving keys while the filter's workgroups are still reducing into them
 };

@@ -429,10 +429,16 @@ __global__ __launch_bounds__(256) void stage2_input_kernel(const DetInfo* __rest
     const int c[2] = {reflect_idx(tc.i0, S2w), reflect_idx(tc.i1, S2w)};
     const double* cv = (aa.k1 && aa.k1[cand].radius > 0) ? aa.k1[cand].a : nullptr;   // anti-aliased canvas
     if (cv) {
+        // the filtered canvas exists inside its region of interest grown by the filter radius; it is +0.0 everywhere else
+        const AaItem& I = aa.k1[cand];
+        const int R0 = max(0, I.r0 - I.radius), R1 = min(I.H, I.r1 + I.radius), C0 = max(0, I.c0 - I.radius), C1 = min(I.W, I.c1 + I.radius);
+        bool in[2][2];
+        for (int a = 0; a < 2; ++a)
+            for (int e = 0; e < 2; ++e) in[a][e] = P2P_TAP_LIVE(a, e, tr, tc) && r[a] >= R0 && r[a] < R1 && c[e] >= C0 && c[e] < C1;
         for (int ch = 0; ch < 3; ++ch) {
             double v[2][2];
             for (int a = 0; a < 2; ++a)
-                for (int e = 0; e < 2; ++e) v[a][e] = P2P_TAP_LIVE(a, e, tr, tc) ? cv[((size_t)r[a] * S2w + c[e]) * 3 + ch] : 0.0;
+                for (int e = 0; e < 2; ++e) v[a][e] = in[a][e] ? cv[((size_t)r[a] * S2w + c[e]) * 3 + ch] : 0.0;
             out[ch] = (float)lerp2(v[0][0], v[0][1], v[1][0], v[1][1], tr.d, tc.d);
         }
         return;
@@ -990,6 +996,7 @@ __device__ inline void aa_item_off(AaItem& I)
 {
     I.a = I.tmp = nullptr; I.w = nullptr;
     I.H = I.W = I.C = 0; I.radius = 0; I.mode = 0; I.round32 = 0; I.cval = 0; I.vmin = I.vmax = 0;
+    I.r0 = I.r1 = I.c0 = I.c1 = 0;
 }
 
 // phase 0 (before stage 1): every descriptor off, stage-1 canvases planned.  phase 1 (after the stage-1 reductions, which
@@ -1028,6 +1035,17 @@ __global__ void aa_plan_kernel(const DetInfo* __restrict__ dets, const Stage1* _
         AaItem& I = aa.k1[t];
         I.a = B.cv + D.cv_off + (size_t)(1 + slot) * cap3; I.tmp = B.cv_tmp + D.cv_off + (size_t)(1 + slot) * cap3;
         I.H = S2; I.W = S.b2.u2_ori - S.b2.u1_ori; I.C = 3; I.radius = tab.rad[S2]; I.w = tab.w + tab.off[S2];
+        // Region of interest: the canvas is zero wherever the kept mask is (recognition.py:113-120), and the kept mask lies inside the bounding box
+        // of non_gray (Stage1::bb, 128-px rows / columns of the stage-1 square).  A stage-1 canvas row r is foreground only if one of its two
+        // bilinear taps floor(src), ceil(src), src = (r + 0.5) 128 / S1 - 0.5, falls into [bb0, bb2]: r in ((bb0 - 0.5) S1 / 128 - 0.5,
+        // (bb2 + 1.5) S1 / 128 - 0.5); one pixel of slack on either side; stage-1 row r is stage-2 canvas row r + v1_ori(1) - v1_ori(2).
+        const int S1w = D.b1.u2_ori - D.b1.u1_ori;
+        const int dv = D.b1.v1_ori - S.b2.v1_ori, du = D.b1.u1_ori - S.b2.u1_ori;
+        int r0 = (int)floor(((double)S.bb[0] - 0.5) * S1 / 128.0 - 0.5) - 1 + dv, r1 = (int)ceil(((double)S.bb[2] + 1.5) * S1 / 128.0 - 0.5) + 2 + dv;
+        int c0 = (int)floor(((double)S.bb[1] - 0.5) * S1w / 128.0 - 0.5) - 1 + du, c1 = (int)ceil(((double)S.bb[3] + 1.5) * S1w / 128.0 - 0.5) + 2 + du;
+        r0 = max(r0, 0); c0 = max(c0, 0); r1 = min(r1, I.H); c1 = min(c1, I.W);
+        if (r1 <= r0 || c1 <= c0) { r0 = c0 = 0; r1 = c1 = 1; }      // nothing of the object inside the canvas: one (zero) pixel
+        I.r0 = r0; I.r1 = r1; I.c0 = c0; I.c1 = c1;
     }
     if (S2 < 128 && S2 > 0 && tab.rad[S2] > 0)                           // :134,144,146 shrink the network output maps
         for (int j = 0; j < 5; ++j) {
@@ -1131,12 +1149,12 @@ __global__ __launch_bounds__(256) void aa_canvas2_kernel(const DetInfo* __restri
     const DetInfo& D = dets[d];
     const Stage1& S = s1[d];
     const float* y1d = y1 + (size_t)d * 16384 * 4;
-    const int npx = I.H * I.W;
+    const int rw = I.c1 - I.c0, npx = (I.r1 - I.r0) * rw;      // the region of interest (aa_plan_kernel): the canvas is zero outside it and not stored there
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
-        const int r = p / I.W, c = p - r * I.W;
+        const int r = I.r0 + p / rw, c = I.c0 + p % rw;
         int fy = 0, fx = 0;
         const bool fg = stage2_fg(D, S, y1d, slot, r, c, &fy, &fx);
-        for (int ch = 0; ch < 3; ++ch) I.a[(size_t)p * 3 + ch] = fg ? frame_px(D, fy, fx, ch) : 0.0;
+        for (int ch = 0; ch < 3; ++ch) I.a[((size_t)r * I.W + c) * 3 + ch] = fg ? frame_px(D, fy, fx, ch) : 0.0;
     }
 }
 

@@ -148,33 +148,46 @@ __global__ __launch_bounds__(256) void aa_filter_kernel(AaItem* __restrict__ ite
     const double* src = AXIS == 0 ? I.a : I.tmp;
     double* dst = AXIS == 0 ? I.tmp : I.a;
     const int H = I.H, W = I.W, C = I.C;
-    const long long total = (long long)H * W * C;
+    // Region of interest (AaItem::r0..c1): outside it the image is exactly zero, so a filter pass is exactly zero outside the region grown by the
+    // radius along its axis -- 0 * w + (0 + 0) * w = +0.0 -- and neither computed nor stored; taps outside what the previous stage wrote read +0.0.
+    const bool roi = I.r1 > I.r0;
+    const int R0 = roi ? max(0, I.r0 - r) : 0, R1 = roi ? min(H, I.r1 + r) : H;                      // rows both passes produce
+    const int C0 = roi ? (AXIS == 0 ? I.c0 : max(0, I.c0 - r)) : 0, C1 = roi ? (AXIS == 0 ? I.c1 : min(W, I.c1 + r)) : W;
+    // what the source holds: the image itself inside the region (pass 0), pass 0's output (pass 1)
+    const int SR0 = roi ? (AXIS == 0 ? I.r0 : R0) : 0, SR1 = roi ? (AXIS == 0 ? I.r1 : R1) : H;
+    const int SC0 = roi ? I.c0 : 0, SC1 = roi ? I.c1 : W;
+    const int rw = (C1 - C0) * C;
+    const long long total = (long long)(R1 - R0) * rw;
     const double* w = I.w;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const long long px = e / C;
-        const int x = (int)(px % W), y = (int)(px / W);
+        const int yy = (int)(e / rw), rem = (int)(e - (long long)yy * rw);
+        const int xx = rem / C, c = rem - xx * C;
+        const int y = R0 + yy, x = C0 + xx;
         const int pos = AXIS == 0 ? y : x, len = AXIS == 0 ? H : W;
-        const long long stride = AXIS == 0 ? (long long)W * C : (long long)C;
-        const double* line = src + (AXIS == 0 ? (long long)x * C + c : (long long)y * W * C + c);
-        double t = line[(long long)pos * stride] * w[0];
+        auto at = [&](int q) -> double {              // source sample at position q along the axis (border handled by the caller)
+            const int sy = AXIS == 0 ? q : y, sx = AXIS == 0 ? x : q;
+            if (roi && (sy < SR0 || sy >= SR1 || sx < SC0 || sx >= SC1)) return 0.0;
+            return src[((long long)sy * W + sx) * C + c];
+        };
+        double t = at(pos) * w[0];
         for (int d = r; d >= 1; --d) {
-            const int lo = pos - d, hi = pos + d;
+            const int lo_i = pos - d, hi_i = pos + d;
             double a, b;
             if (I.mode == 0) {
-                a = line[(long long)mirror_idx(lo, len) * stride];
-                b = line[(long long)mirror_idx(hi, len) * stride];
+                a = at(mirror_idx(lo_i, len));
+                b = at(mirror_idx(hi_i, len));
             } else {
-                a = lo >= 0 ? line[(long long)lo * stride] : I.cval;
-                b = hi < len ? line[(long long)hi * stride] : I.cval;
+                a = lo_i >= 0 ? at(lo_i) : I.cval;
+                b = hi_i < len ? at(hi_i) : I.cval;
             }
             t += (a + b) * w[d];
         }
         const double v = I.round32 ? (double)(float)t : t;
-        dst[e] = v;
+        dst[((long long)y * W + x) * C + c] = v;
         if (AXIS == 1) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
     }
     if (AXIS == 1) {
+        if (roi && blockIdx.x == 0 && threadIdx.x == 0 && (R0 > 0 || R1 < H || C0 > 0 || C1 < W)) { lo = 0.0 < lo ? 0.0 : lo; hi = 0.0 > hi ? 0.0 : hi; }      // the zeros outside
         for (int o = 32; o > 0; o >>= 1) {
             const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
             lo = l2 < lo ? l2 : lo;
