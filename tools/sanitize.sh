@@ -13,7 +13,7 @@ if [ "$1" = "build" ]; then
     mkdir -p tools/ab /tmp/p2p_asan
     python -c "from pix2pose_amd import build; build.build()"     # regenerates csrc/_build_id.cpp
     OBJS=""
-    for s in igemm igemm_halo igemm_halo8 igemm_halo_s2 igemm_stream heads conv1 misc_kernels model pipeline resize_aa pnp; do
+    for s in igemm igemm_halo igemm_halo8 igemm_halo_s2 igemm_stream resblock heads conv1 misc_kernels model pipeline resize_aa pnp comm; do
         if [ "$MODE" = "ubsan" ]; then SAN="-Xarch_host -fsanitize=undefined -Xarch_host -D_GLIBCXX_ASSERTIONS"; else SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined"; fi
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC $SAN \
             -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined -c pix2pose_amd/csrc/$s.hip -o /tmp/p2p_asan/$s.o &
@@ -22,7 +22,7 @@ if [ "$1" = "build" ]; then
     wait
     g++ -O1 -fPIC -c pix2pose_amd/csrc/_build_id.cpp -o /tmp/p2p_asan/_build_id.o
     if [ "$MODE" = "ubsan" ]; then LSAN="-fsanitize=undefined"; else LSAN="-fsanitize=address -fsanitize=undefined"; fi
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $LSAN -shared-libsan -o $OUT $OBJS /tmp/p2p_asan/_build_id.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $LSAN -shared-libsan -o $OUT $OBJS /tmp/p2p_asan/_build_id.o -ldl
     echo "built $OUT"
     exit 0
 fi
