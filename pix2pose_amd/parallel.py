@@ -140,17 +140,26 @@ class TorchPoseGather:
         import torch
         import torch.distributed as dist
         from . import _lib
-        own = pending.collect() if pending is not None else []
-        if len(own) > n_max:
-            raise ValueError("the batch holds %d detections, n_max is %d" % (len(own), n_max))
+        # like the C path, a local failure never strands the peers: the collective is entered with padding (or POSE_RANGE records) first
+        own, err = [], None
+        try:
+            own = pending.collect() if pending is not None else []
+            if len(own) > n_max:
+                raise ValueError("the batch holds %d detections, n_max is %d" % (len(own), n_max))
+        except Exception as e:      # noqa: BLE001 -- re-raised after the gather
+            own, err = [], e
         buf = np.zeros(n_max, _lib.POSE_DTYPE)
         buf["status"] = _lib.POSE_ABSENT
+        if isinstance(err, _lib.P2PRangeError) and pending is not None:
+            buf["status"][:min(pending.n, n_max)] = _lib.POSE_RANGE
         if own:
             buf[:len(own)] = np.frombuffer(pending.pose_array, dtype=_lib.POSE_DTYPE, count=len(own))
         dev = self.device if self.device is not None else torch.device("cpu")
         send = torch.from_numpy(buf.view(np.uint8).copy()).to(dev)
         out = torch.empty(self.world * send.numel(), dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(out, send)
+        if err is not None:
+            raise err
         return own, np.frombuffer(out.cpu().numpy().tobytes(), dtype=_lib.POSE_DTYPE, count=self.world * n_max)
 
     def close(self):
