@@ -126,3 +126,41 @@ def test_forward_async_reports_through_the_context():
     f32 = Generator(_overflowing("paper"), "paper", ctx, precision="f32")
     f32.forward_device(x.data_ptr(), 3, y.data_ptr())
     assert ctx.range_event() == 0.0                 # the fp32 arithmetic has no such limit and is not guarded
+
+
+def test_range_event_travels_as_pose_range_through_the_gather():
+    """a rank whose batch left the operand range must not broadcast ordinary-looking records.  collect_gathered takes the verdict
+    BEFORE packing: this rank gets P2P_ERR_RANGE, its records travel with status = P2P_POSE_RANGE, nothing is handed over (a pre-filled pose
+    array and a pre-zeroed mask buffer stay untouched), and the communicator keeps working.  Also: a NaN weight is caught (the running
+    maximum and the ReLUs propagate NaN), not turned into finite garbage."""
+    import ctypes as C
+    from pix2pose_amd import _lib
+    from pix2pose_amd.runtime import Comm, Context, Generator, ObjectSpec, est_pose_submit
+    ctx = Context(0, max_batch=16)
+    ths = ([0.2, 0.3, 0.35], 0.2)
+    sc = S.make_scene(3, seed=79)
+    imgs = list(sc["images"])
+    comm = Comm(ctx, 0, 1, Comm.unique_id())
+    bad = ObjectSpec(Generator(_overflowing("resnet50"), "resnet50", ctx, precision="f16x3"), S.OBJ_PARAM, *ths)
+    pend = est_pose_submit(ctx, [bad], imgs, sc["dets"], want_masks=True)
+    poses = (_lib.Pose * 3)()
+    for p in poses:
+        p.n_inliers = 424242
+    allp = (_lib.Pose * 8)()
+    rc = _lib.lib().p2p_est_pose_collect_gathered(ctx.handle, comm.handle, pend.ticket, poses, 8, allp)
+    assert rc == _lib.ERR_RANGE
+    assert [allp[i].status for i in range(8)] == [_lib.POSE_RANGE] * 3 + [_lib.POSE_ABSENT] * 5
+    assert all(p.n_inliers == 424242 for p in poses)                       # nothing handed over
+    assert not pend.extras["valid_mask"].any()
+    ok = ObjectSpec(Generator(W.synthetic_weights("resnet50", 3), "resnet50", ctx), S.OBJ_PARAM, *ths)
+    own, allp2 = est_pose_submit(ctx, [ok], imgs, sc["dets"]).collect_gathered(comm, 8)      # the next batch is clean
+    assert [allp2[i].status for i in range(3)] == [p.status for p in own] and all(s >= 0 for s in [p.status for p in own])
+    comm.close()
+    # NaN: a NaN in a ResNet-front BatchNorm shift would be zeroed by a plain fmaxf ReLU and vanish from every later layer
+    w = dict(W.synthetic_weights("resnet50", 3))
+    k = [n for n in w if n.startswith("res2b_2a") and n.endswith(".beta")][0]
+    beta = w[k].copy(); beta[5] = np.nan; w[k] = beta
+    with pytest.raises(_lib.P2PRangeError):
+        Generator(w, "resnet50", ctx, precision="f16x3").predict(_x(12))   # 12 inputs: res2b runs on the fused kernel
+    with pytest.raises(_lib.P2PRangeError):
+        Generator(w, "resnet50", ctx, precision="f16x3").predict(_x(2))    # 2 inputs: the streaming route
