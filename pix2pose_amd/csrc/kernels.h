@@ -194,10 +194,6 @@ hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s);
 hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cout, const float* scale,
                                 const float* shift, int act, float alpha, float* out, unsigned* range_acc, hipStream_t s);
 
-// same, rows [row0, row0+rows) only (grouped launches: per-object bias); no activation
-hipError_t launch_splitk_reduce_rows(const float* partial, int ksplit, int M, int Cout, int row0, int rows, const float* scale,
-                                     const float* shift, float* out, unsigned* range_acc, hipStream_t s);
-
 // First-layer direct convolution, Cin = 3 (conv1 7x7/2 of the ResNet front, conv1_x 5x5/2 of
 // the paper encoder), fused scale/shift + activation.  w_packed: [kh*kw*3][Cout].
 hipError_t launch_conv_first(const float* x, int N, int H, int W, const float* w_packed, int KH,
@@ -218,6 +214,9 @@ struct Conv1Groups {
     const float* scale[IGEMM_MAX_GROUPS];
     const float* shift[IGEMM_MAX_GROUPS];
 };
+// The split-K reduction of a mixed-object batch: rows [start[g], start[g + 1]) take object g's scale / shift (G.w unused); no activation.
+hipError_t launch_splitk_reduce_groups(const float* partial, int ksplit, int M, int Cout, const Conv1Groups& G, float* out, unsigned* range_acc,
+                                       hipStream_t s);
 hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, float* pool_out,
                               unsigned* range_acc, hipStream_t s);
 

@@ -1021,12 +1021,16 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         if (n_grp == 1) {
             HIP_TRY(launch_splitk_reduce(A["part"], 32, n, 256, L.scale, L.shift, ACT_NONE, LEAKY, A["enc"], M.prec == PREC_F16X3 ? X.range_cur : nullptr, st));
         } else {
-            // per-object bias: reduce each object's sample rows with its own shift.  The partial slabs are
-            // [z][n][256]; a row range is strided by n*256 between slabs, so reduce through a strided view
+            // per-object bias: every row is reduced with its own object's shift, one launch for the batch
+            if (n_grp > IGEMM_MAX_GROUPS) { set_error("forward: %d object groups exceed IGEMM_MAX_GROUPS", n_grp); return P2P_ERR_CAPACITY; }
+            Conv1Groups G;
+            G.n_groups = n_grp;
             for (int g = 0; g < n_grp; ++g) {
                 const ConvLayer& Lg = grp_model(g).L.at("dense_enc");
-                HIP_TRY(launch_splitk_reduce_rows(A["part"], 32, n, 256, g0(g), g0(g + 1) - g0(g), Lg.scale, Lg.shift, A["enc"], M.prec == PREC_F16X3 ? X.range_cur : nullptr, st));
+                G.start[g] = g0(g); G.w[g] = nullptr; G.scale[g] = Lg.scale; G.shift[g] = Lg.shift;
             }
+            G.start[n_grp] = n;
+            HIP_TRY(launch_splitk_reduce_groups(A["part"], 32, n, 256, G, A["enc"], M.prec == PREC_F16X3 ? X.range_cur : nullptr, st));
         }
     }
     {
