@@ -51,6 +51,20 @@ def main(path, batch=256):
                 continue
             out.append((nm, mmac))
         layers = out
+    # small launches (one detection at a time, and up1 at 64 inputs): the four phases of a transposed convolution are ONE streaming launch
+    out, i = [], 0
+    for nm, mmac in layers:
+        if nm.endswith("_p0") and i < len(ks) and "igemm_stream" in ks[i][0]:
+            b = nm.split("_")[0]
+            out.append((b + " (4 phases)", sum(m for n2, m in layers if n2.startswith(b + "_p"))))
+            KF[b + " (4 phases)"] = 4 * KF.get(nm, 0)
+            i += 1
+            continue
+        if out and out[-1][0] == nm.split("_")[0] + " (4 phases)":
+            continue
+        out.append((nm, mmac))
+        i += 1
+    layers = out
     ks = ks[:len(layers)]
     tot = 0
     for (nm, mmac), r in zip(layers, ks):
