@@ -142,7 +142,10 @@ __device__ inline double range_val(unsigned long long k)
 // the outside in --, so the bits do not depend on the grouping.
 // The second pass also takes the [min, max] of what it writes -- the range skimage's clip=True clips the warp output to (a separate pass, one
 // workgroup per image, was 2 ms per step): the first pass resets the item's keys, aa_range_finish_kernel turns them into vmin / vmax.
-constexpr int AA_V0 = 8, AA_V1 = 4, AA_RMAX = 4;
+#ifndef P2P_AA_V1      // A/B builds (tools/ab_build.sh resize_aa.hip -DP2P_AA_V1=2)
+#define P2P_AA_V1 4
+#endif
+constexpr int AA_V0 = 8, AA_V1 = P2P_AA_V1, AA_RMAX = 4;
 template <int AXIS>
 __global__ __launch_bounds__(256) void aa_filter_kernel(AaItem* __restrict__ items)
 {
@@ -195,7 +198,9 @@ __global__ __launch_bounds__(256) void aa_filter_kernel(AaItem* __restrict__ ite
             const double v = round32 ? (double)(float)t : t;
             const int y = AXIS == 0 ? pos : fixed, x = AXIS == 0 ? fixed : pos;
             dst[((long long)y * W + x) * C + c] = v;
+#ifndef P2P_ABL_AA_MINMAX      // timing ablation (A/B builds only: the clip range is garbage with it)
             if (AXIS == 1) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+#endif
         };
         if (r <= AA_RMAX) {                          // (wave-uniform: the radius belongs to the item)
             double win[V + 2 * AA_RMAX];
