@@ -107,7 +107,9 @@ for r in $(seq 1 $ROUNDS); do
     one_bench nofuse $ROOT $ROOT/pix2pose_amd/libp2p_mi355_dev.so "P2P_NO_FUSED_BLOCK=1 P2P_NO_FUSED_PROJ=1" >> $REP      # head with the identity blocks as three launches (round 4's route)
 done
 
-# per-layer times of one blocking step: prev, head, and head with the three-launch blocks
+# per-layer times of one blocking step: prev, head, and head with the three-launch blocks -- two interleaved traces each, the smaller time of
+# a layer counts (one trace of a 10-us launch, or of a whole run that met a power excursion, is noise)
+for rep in 1 2; do
 for v in prev head nofuse; do
     tree=$ROOT; [ $v == prev ] && tree=$AB/prev
     rm -rf $OUT/ab_prof_$v
@@ -117,12 +119,13 @@ for v in prev head nofuse; do
     (cd $tree && rocprofv3 --kernel-trace -d $OUT/ab_prof_$v -o t -- python bench.py --steps 2 --warmup 1 --blocking --no-legs > /dev/null 2>&1)
     fi
     db=$(find $OUT/ab_prof_$v -name "t_results.db" | head -1)
-    python $tree/tools/layer_times.py $db > $OUT/ab_layers_$v.txt 2>&1
+    python $tree/tools/layer_times.py $db > $OUT/ab_layers_${v}_$rep.txt 2>&1
     rm -rf $OUT/ab_prof_$v
 done
-python - $OUT/ab_layers_prev.txt $OUT/ab_layers_head.txt $OUT/ab_layers_nofuse.txt >> $REP <<'EOF'
+done
+python - $OUT/ab_layers_prev $OUT/ab_layers_head $OUT/ab_layers_nofuse >> $REP <<'EOF'
 import sys
-def load(f):
+def load1(f):
     d, order = {}, []
     for ln in open(f):
         p = ln.split()
@@ -134,8 +137,13 @@ def load(f):
         elif ln.startswith("total"):
             d["total"] = float(p[1]); order.append("total")
     return d, order
+def load(stem):           # the smaller time of the two traces, layer by layer (the total: sum of those)
+    d1, o1 = load1(stem + "_1.txt"); d2, _ = load1(stem + "_2.txt")
+    d = {k: min(v, d2.get(k, v)) for k, v in d1.items()}
+    d["total"] = sum(v for k, v in d.items() if k != "total")
+    return d, o1
 a, oa = load(sys.argv[1]); b, ob = load(sys.argv[2]); c, oc = load(sys.argv[3])
-print("## per-layer times of one blocking 256-input pass (rocprofv3 kernel trace, us; ResNet blocks summed per block):")
+print("## per-layer times of one blocking 256-input pass (rocprofv3 kernel trace, us; two interleaved traces per variant, the smaller time per layer; ResNet blocks summed per block):")
 print("## %-12s %9s %9s %9s   %s" % ("layer", "prev", "head", "nofuse", "head/prev  nofuse/prev"))
 for k in ob:
     if k in a:
