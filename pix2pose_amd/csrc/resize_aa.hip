@@ -134,7 +134,7 @@ __device__ inline double range_val(unsigned long long k)
 }
 
 // one axis pass of every item.  A thread produces V consecutive outputs ALONG the filter axis from one register window of V + 2 r samples
-// (radius <= AA_RMAX: every crop side up to 640 px) -- V = 8 rows in pass 0, where neighbouring threads take neighbouring memory elements of a
+// (radius <= AA_RMAX = 4, i.e. crop sides below 416 px; larger radii take one output at a time) -- V = 8 rows in pass 0, where neighbouring threads take neighbouring memory elements of a
 // row; V = 4 columns in pass 1 (channel fastest over the threads: a wave's loads of one window position are strided, of all positions together
 // they cover whole cache lines; 8 columns, and 4 ROWS per thread with the taps' border handling resolved once, both measured slower).
 // One output per thread re-read 2 r + 1 samples and paid the item's set-up, two divisions and 2 r mirror computations per output: 2.7 ms per
