@@ -134,18 +134,18 @@ __device__ inline double range_val(unsigned long long k)
 }
 
 // one axis pass of every item.  A thread produces V consecutive outputs ALONG the filter axis from one register window of V + 2 r samples
-// (radius <= AA_RMAX = 4, i.e. crop sides below 416 px; larger radii take one output at a time) -- V = 8 rows in pass 0, where neighbouring threads take neighbouring memory elements of a
+// (radius <= AA_RMAX = 8, i.e. crop sides below 928 px; larger radii take one output at a time) -- V = 8 rows in pass 0, where neighbouring threads take neighbouring memory elements of a
 // row; V = 4 columns in pass 1 (channel fastest over the threads: a wave's loads of one window position are strided, of all positions together
 // they cover whole cache lines; 8 columns, and 4 ROWS per thread with the taps' border handling resolved once, both measured slower).
 // One output per thread re-read 2 r + 1 samples and paid the item's set-up, two divisions and 2 r mirror computations per output: 2.7 ms per
-// 256-detection step at 40 - 300-px boxes, 1.8 ms now.  An output's sum is the expression it always was -- centre first, then the pairs from
+// 256-detection step at 40 - 300-px boxes, 1.6 ms now; 19 -> 8 ms at 250 - 420-px boxes (tools/aa_big_sides.sh).  An output's sum is the expression it always was -- centre first, then the pairs from
 // the outside in --, so the bits do not depend on the grouping.
 // The second pass also takes the [min, max] of what it writes -- the range skimage's clip=True clips the warp output to (a separate pass, one
 // workgroup per image, was 2 ms per step): the first pass resets the item's keys, aa_range_finish_kernel turns them into vmin / vmax.
 #ifndef P2P_AA_V1      // A/B builds (tools/ab_build.sh resize_aa.hip -DP2P_AA_V1=2)
 #define P2P_AA_V1 4
 #endif
-constexpr int AA_V0 = 8, AA_V1 = P2P_AA_V1, AA_RMAX = 4;
+constexpr int AA_V0 = 8, AA_V1 = P2P_AA_V1, AA_RMAX = 8;
 template <int AXIS>
 __global__ __launch_bounds__(256) void aa_filter_kernel(AaItem* __restrict__ items)
 {
