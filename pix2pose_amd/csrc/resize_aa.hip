@@ -138,7 +138,7 @@ __device__ inline double range_val(unsigned long long k)
 // row; V = 4 columns in pass 1 (channel fastest over the threads: a wave's loads of one window position are strided, of all positions together
 // they cover whole cache lines; 8 columns, and 4 ROWS per thread with the taps' border handling resolved once, both measured slower).
 // One output per thread re-read 2 r + 1 samples and paid the item's set-up, two divisions and 2 r mirror computations per output: 2.7 ms per
-// 256-detection step at 40 - 300-px boxes, 1.6 ms now; 19 -> 8 ms at 250 - 420-px boxes (tools/aa_big_sides.sh).  An output's sum is the expression it always was -- centre first, then the pairs from
+// 256-detection step at 40 - 300-px boxes, 1.6 ms now; 15 -> 6 ms at 250 - 420-px boxes (tools/aa_big_sides.sh).  An output's sum is the expression it always was -- centre first, then the pairs from
 // the outside in --, so the bits do not depend on the grouping.
 // The second pass also takes the [min, max] of what it writes -- the range skimage's clip=True clips the warp output to (a separate pass, one
 // workgroup per image, was 2 ms per step): the first pass resets the item's keys, aa_range_finish_kernel turns them into vmin / vmax.
