@@ -205,6 +205,13 @@ def test_large_frames_large_crops(rig, aa):
     assert _run_injected(rig, sc, anti_aliasing=aa) >= 5
 
 
+def test_huge_crop_takes_the_one_output_filter_path(rig):
+    """A 640-700-px box in a 1920x1080 frame: crop side 960-1050 px, Gaussian radius 13-15 -- beyond the register window of the
+    anti-aliasing filter (resize_aa.hip: AA_RMAX = 8), so the one-output-at-a-time path runs; 0.17 / 0.18 generation, against the oracle."""
+    sc = synth.make_scene(1, seed=97, bbox_side=(640, 700), H=1080, W=1920, n_images=1)
+    assert _run_injected(rig, sc, anti_aliasing=True) >= 1
+
+
 def test_anti_aliasing_off_and_on_differ_and_identity_at_128(rig):
     import torch
     from pix2pose_amd.runtime import est_pose_batch
