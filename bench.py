@@ -153,8 +153,8 @@ def _self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="detections per GPU per step")
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--chunk", type=int, default=1024, help="generator inputs per pass (activation workspace: 13 MB per input; 1024 holds the 768 stage-2 inputs of a 256-detection batch in one pass)")
