@@ -52,4 +52,4 @@ for i in range(60):
     runtime._marshal([spec], [rgb], [(0, 0, [int(b) for b in bbox], K)], inj["inject1"], inj["inject2"], 3, True, None, 0, 0.0, 0.0)
     tm.append(time.perf_counter() - t1)
 print("C call alone: median %.3f ms; marshalling alone: %.3f ms" % (np.median(tc[10:]) * 1e3, np.median(tm[10:]) * 1e3))
-print("single est_pose: median %.3f ms  p10 %.3f  p90 %.3f  (%d calls)" % (np.median(lat), np.percentile(lat, 10), np.percentile(lat, 90), calls))
+print("single est_pose: median %.3f ms  mean %.3f  p10 %.3f  p90 %.3f  (%d calls)" % (np.median(lat), lat.mean(), np.percentile(lat, 10), np.percentile(lat, 90), calls))
