@@ -186,3 +186,20 @@ def test_pnp_large_crops_with_heavy_outliers_match_oracle():
         if len(objs[p]) > 1000:
             rounds.add(0 if meta["iterations"] <= 16 else 1 if meta["iterations"] <= 64 else 2)
     assert len(rounds) >= 2, rounds          # the large problems really end in different hypothesis rounds
+
+
+def test_small_and_large_launches_agree_bit_for_bit():
+    """Launches of up to 48 problems solve hypotheses [0, 48) up front (pnp.hip: launch_pnp_ransac), larger ones in the lazy rounds
+    [0, 16) [16, 64) [64, 100): WHEN a hypothesis is solved must not change any result -- the same 40 problems alone and as the head of a
+    72-problem launch, compared bit for bit (noisy problems: many of them run past 16 iterations)."""
+    from pix2pose_amd.runtime import default_context, pnp_ransac_batch
+    Ks, objs, imgs, _ = _scenes(72, seed0=321, n_pts=(40, 2500), outliers=(0.3, 0.6))
+    ok_a, R_a, t_a, info_a, m_a = pnp_ransac_batch(default_context(), Ks[:40], objs[:40], imgs[:40], want_mask=True)
+    ok_b, R_b, t_b, info_b, m_b = pnp_ransac_batch(default_context(), Ks, objs, imgs, want_mask=True)
+    assert (np.asarray(info_a)[:, 1] > 16).sum() >= 5          # iterations: the second round is exercised
+    np.testing.assert_array_equal(np.asarray(ok_a), np.asarray(ok_b)[:40])
+    np.testing.assert_array_equal(np.asarray(info_a), np.asarray(info_b)[:40])
+    np.testing.assert_array_equal(np.asarray(R_a), np.asarray(R_b)[:40])
+    np.testing.assert_array_equal(np.asarray(t_a), np.asarray(t_b)[:40])
+    for p in range(40):
+        np.testing.assert_array_equal(np.asarray(m_a[p]), np.asarray(m_b[p]))
