@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
 // Kernel 2a -- inlier counts.  Only the COUNT of a hypothesis enters OpenCV's sequential rule (keep the best, shrink the iteration
 // bound), and a count is an integer: any partition of the points and any order of the hypotheses gives the same numbers.  So the
 // counts of a round's hypotheses are taken by independent workgroups -- work item = (problem, chunk of SCORE_CHUNK hypotheses, slice of the
-// points): a point is loaded once and tested against the chunk's models out of LDS, four points in flight per thread -- and added to
+// points): a point is loaded once and tested against the chunk's models (scalar registers), four points in flight per thread -- and added to
 // the problem's counters; pnp_score_kernel then replays the rule over them.  With detections of 200 - 450 px a candidate carries up
 // to 200 000 correspondences: one workgroup per problem walking chunk after chunk (and starting over after every hypothesis round)
 // took 9 ms of kernel time per 256-detection step at bbox sides of 40 - 300 px, most of it in a few workgroups on an idle chip.
@@ -1161,8 +1161,6 @@ __global__ __launch_bounds__(COUNT_NT) void pnp_count_kernel(const PnpProblem* _
                                                              double reproj_err, int min_points, int h_begin, int n_solved, int nchunks,
                                                              int slices, int round, int n_problems)
 {
-    __shared__ double s_R[SCORE_CHUNK][9];
-    __shared__ double s_t[SCORE_CHUNK][3];
     __shared__ int s_cnt[SCORE_CHUNK];
     int* counts = act + 2 + 2 * n_problems;
     const int tid = threadIdx.x;
@@ -1173,7 +1171,7 @@ __global__ __launch_bounds__(COUNT_NT) void pnp_count_kernel(const PnpProblem* _
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int slot = item / per_prob, rem = item - slot * per_prob;
         const int c = rem / slices, sl = rem - c * slices;
-        const int prob = round == 0 ? slot : act[2 + (round - 1) * n_problems + slot];
+        const int prob = __builtin_amdgcn_readfirstlane(round == 0 ? slot : act[2 + (round - 1) * n_problems + slot]);      // (wave-uniform: scalar loads below)
         const PnpProblem& pb = probs[prob];
         const int n = pb.n;
         if (n < min_points || n <= 5) continue;                          // n == 5: the direct solution, nothing to count
@@ -1181,14 +1179,14 @@ __global__ __launch_bounds__(COUNT_NT) void pnp_count_kernel(const PnpProblem* _
         const int n_hyp = iterations > 1 ? iterations : 1;
         const int n_avail = min(n_hyp, n_solved);
         const int it0 = h_begin + c * SCORE_CHUNK;
-        const int hc = min(SCORE_CHUNK, min(n_avail, round == 0 ? n_avail : fits[prob].niters) - it0);
+        const int hc = __builtin_amdgcn_readfirstlane(min(SCORE_CHUNK, min(n_avail, round == 0 ? n_avail : fits[prob].niters) - it0));
         if (hc <= 0) continue;
-        __syncthreads();                                                 // the previous item's models are no longer read
-        for (int i = tid; i < hc * 12; i += COUNT_NT) {
-            const int h = i / 12, k = i - h * 12;
-            const double v = hyp[((size_t)prob * MAX_ITERS + it0 + h) * 12 + k];
-            if (k < 9) s_R[h][k] = v; else s_t[h][k - 9] = v;
-        }
+        __syncthreads();                                                 // the previous item's counters are no longer read
+        // The chunk's models are the same for every lane: read straight from the hypothesis array at wave-uniform addresses they arrive through
+        // the scalar cache in SGPRs, and an fp64 VALU instruction takes one of them as its scalar operand.  (Staged in LDS they were hoisted into
+        // 192 VGPRs -- 251 in all, two waves per SIMD, or re-read at 4 LDS cycles per broadcast double: 532 -> 358 us per launch at 40 - 300-px
+        // boxes, 69 VGPRs.)  Model h: R = M[12 h .. 12 h + 8], t = M[12 h + 9 .. 12 h + 11]; models past hc are never counted.
+        const double* __restrict__ M = hyp + ((size_t)prob * MAX_ITERS + it0) * 12;
         if (tid < SCORE_CHUNK) s_cnt[tid] = 0;
         __syncthreads();
         const float* PX = pb.pts;
@@ -1212,7 +1210,7 @@ __global__ __launch_bounds__(COUNT_NT) void pnp_count_kernel(const PnpProblem* _
                 if (i0 + COUNT_NT * u >= n) break;
 #pragma unroll
                 for (int h = 0; h < SCORE_CHUNK; ++h)
-                    if (h < hc) cnt[h] += is_inlier(s_R[h], s_t[h], cam, px[u], py[u], pz[u], pu[u], pv[u], thr2) ? 1 : 0;
+                    if (h < hc) cnt[h] += is_inlier(M + 12 * h, M + 12 * h + 9, cam, px[u], py[u], pz[u], pu[u], pv[u], thr2) ? 1 : 0;
             }
         }
 #pragma unroll
