@@ -982,6 +982,27 @@ __device__ void block_reduce(double (&v)[NV], double* red /* LDS: >= 4*NV double
     __syncthreads();
 }
 
+// The same reduction for sums only ONE thread consumes (the 56 Gram sums of the refit go straight to the problem's PnpFit record): the second
+// stage runs on thread 0 alone, sum by sum.  block_reduce<56> made every thread form all 56 totals, and the scheduler issued their 224 LDS reads
+// together: 448 registers -- pnp_score_kernel held 254 VGPRs + 246 AGPRs, i.e. one 4-wave workgroup per CU.  Same additions in the same order.
+template <int NV>
+__device__ void block_reduce_store(double (&v)[NV], double* red /* LDS: >= 4*NV doubles */, double* __restrict__ dst)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0 && wave < 4) red[wave * NV + k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll 1
+        for (int k = 0; k < NV; k++) dst[k] = red[k] + red[NV + k] + red[2 * NV + k] + red[3 * NV + k];
+    }
+    __syncthreads();
+}
+
 __device__ int block_reduce_int(int x, int* red)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1426,13 +1447,12 @@ __global__ __launch_bounds__(SCORE_NT) void pnp_score_kernel(const PnpProblem* _
             }
         }
     }
-    block_reduce<56>(g, s_red);
+    block_reduce_store<56>(g, s_red, fit.g);
 
     if (tid == 0) {
         for (int i = 0; i < 4; i++)
             for (int j = 0; j < 3; j++) fit.cws[3 * i + j] = cws[i][j];
         for (int k = 0; k < 9; k++) fit.ci[k] = ci[k];
-        for (int k = 0; k < 56; k++) fit.g[k] = g[k];
         // epnp's solve_for_sign looks at the depth of the FIRST inlier's camera-frame point
         int first = 0;
         while (first < n && !is_inlier(Rb, tb, cam, PX[first], PY[first], PZ[first], PU[first], PV[first], thr2)) ++first;
