@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define P2P_ABI_VERSION 8
+#define P2P_ABI_VERSION 9
 
 /* The library is built with -fvisibility=hidden: the entry points declared here (P2P_API) are its ONLY dynamic symbols
  * (tests/test_host_cpu.py holds `nm -D` to exactly this list). */
@@ -357,10 +357,12 @@ P2P_API int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double*
  *   7  igemm_halo_s2_kernel (5x5 stride-2 convolutions on larger grids: the paper encoder's conv2 / conv3)
  *   8  igemm_stream_kernel (small launches: one wave per 32x32 tile, same K order and bits as the batched kernels)
  *   9  resblock_kernel (a ResNet identity bottleneck block -- 1x1, 3x3, 1x1 + residual -- in one launch, intermediates in LDS)
+ *   10 wino_gemm_kernel (the 5x5 stride-1 decoder layers in Winograd F(4,5) form along the row axis: 2.5x fewer MFMA products; algo_flops
+ *      stays the DIRECT form's 2 x MACs of the layer)     11 wino_input_kernel (its input transform: x -> split-f16 V in HBM; algo_flops 0)
  * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md
  * section 8a-L), not padded work and not the 3 MFMA products per MAC of the split-f16 arithmetic.
  * ---------------------------------------------------------------------------------------- */
-#define P2P_PROFILE_SLOTS 10
+#define P2P_PROFILE_SLOTS 12
 typedef struct {
     int64_t launches;
     double total_ms;

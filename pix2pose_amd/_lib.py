@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P2P_LIB", os.path.join(_HERE, "libp2p_mi355.so"))     # P2P_LIB: development override
 
 P2P_OK = 0
-ABI_VERSION = 8            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
+ABI_VERSION = 9            # P2P_ABI_VERSION of include/p2p_mi355.h these ctypes declarations follow
 MAX_RANSAC_ITERATIONS = 128
 BACKBONE = {"paper": 0, "resnet50": 1}
 PRECISION = {"f32": 0, "f16x3": 1, "auto": 2}     # p2p_precision; "auto" = split-f16 with an fp32 twin it falls back to on a range event
@@ -78,7 +78,7 @@ class EstPoseOpts(C.Structure):
                 ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int), ("mask_prezeroed", C.c_int)]
 
 
-PROFILE_SLOTS = 10    # P2P_PROFILE_SLOTS
+PROFILE_SLOTS = 12    # P2P_PROFILE_SLOTS
 # kernel family of each slot: (label, substring of the rocprofv3 kernel name; %d = precision template argument)
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
                    ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
@@ -89,7 +89,9 @@ PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"
                    ("igemm_halo8_kernel 128x128 tiles (8x8-grid layers: conv4 through parity planes, first transposed conv)", "igemm_halo8_kernel"),
                    ("igemm_halo_s2_kernel (5x5 stride-2 convolutions on 16x16 and larger grids: the paper encoder)", "igemm_halo_s2_kernel"),
                    ("igemm_stream_kernel (small launches: one wave per 32x32 output tile, operands streamed to registers)", "igemm_stream_kernel"),
-                   ("resblock_kernel (ResNet identity bottleneck block in one launch: 1x1 -> 3x3 -> 1x1 + residual, intermediates in LDS)", "resblock_kernel")]
+                   ("resblock_kernel (ResNet identity bottleneck block in one launch: 1x1 -> 3x3 -> 1x1 + residual, intermediates in LDS)", "resblock_kernel"),
+                   ("wino_gemm_kernel (5x5 stride-1 decoder layers, Winograd F(4,5) along the row axis: eight position GEMMs + inverse transform)", "wino_gemm_kernel"),
+                   ("wino_input_kernel (input transform of the Winograd layers: x -> split-f16 V)", "wino_input_kernel")]
 
 
 class KernelStats(C.Structure):

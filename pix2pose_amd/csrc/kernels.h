@@ -155,6 +155,40 @@ int resblock_grid(int F1, int N, int H, int W);        // workgroups of the laun
 hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s);
 hipError_t launch_resproj(const ResBlockParams& p, int F1, hipStream_t s);      // the projection blocks res2a / res3a (H, W = output grid)
 
+// Winograd F(4,5) along the row axis for Conv2D 5x5 stride 1 'SAME' over a two-segment channel concatenation (wino.hip): 2.5x fewer MFMA
+// products than the direct form.  Two launches: the input transform writes V (split-f16, 8 bytes per input element: two positions per input
+// column), the GEMM kernel consumes it.  U = the layer's Winograd panel (model.hip: pack_wino), fragment order:
+//   [Cout / 64][position 8][Cin / 16][ky 5][(32-channel tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo)][lane 64][8 halves]
+struct WinoGroup {
+    const float* U;
+    const float* scale;
+    const float* shift;
+    int sample0;
+    int pad_;
+};
+struct WinoParams {
+    IgemmSeg seg[2];       // input: channels [coff, coff + C) of two NHWC tensors on the same H x W grid
+    unsigned seg_bytes[2];
+    int seg0_groups;       // seg[0].C / 32
+    int N, H, W, Cin, Cout;
+    float* V;              // wino_v_bytes(N, H, W, Cin)
+    const float* U;
+    const float* scale;    // folded BatchNorm (carries the inverse of the panel's per-channel pre-scale)
+    const float* shift;
+    int act;
+    float alpha;
+    float* out;            // [N, H, W, out_cstride], channels [out_coff, out_coff + Cout)
+    int out_cstride, out_coff;
+    unsigned* range_acc;   // operand-range guard: the transform reports the TRANSFORMED operand, the GEMM epilogue what it stores
+    int n_groups;          // mixed-object batches: samples [grp[g].sample0, grp[g + 1].sample0) use group g's panel
+    WinoGroup grp[IGEMM_MAX_GROUPS + 1];
+};
+bool wino_supported(int H, int W, int Cin0, int Cin1, int Cout);
+size_t wino_v_bytes(int N, int H, int W, int Cin);
+int wino_gemm_grid(const WinoParams& p);
+hipError_t launch_wino_input(const WinoParams& p, hipStream_t s);
+hipError_t launch_wino_gemm(const WinoParams& p, hipStream_t s);
+
 // Small-batch variant (igemm_stream.hip): one wave per 32x32 / 64x32 output tile, operands streamed global -> registers with a deep
 // software pipeline.  Bit-identical to the batched kernel that serves the layer: every output element is the same chain of MFMAs over
 // the same K-step order, which StreamOrder describes as that kernel's loop nest -- for g in groups: for slice: for tap in group g.

@@ -25,6 +25,10 @@ struct ConvLayer {
     std::string name;         // key in Model::L (grouped launches look the same layer up in every object)
     int8_t dy[IGEMM_MAX_TAPS + 3] = {0};
     int8_t dx[IGEMM_MAX_TAPS + 3] = {0};
+    // 5x5 stride-1 layers of split-f16 models: the Winograd F(4,5) panel beside the direct one (wino.hip; kernels.h: WinoParams)
+    float* wino_u = nullptr;
+    float* wino_scale = nullptr;   // folded BatchNorm scale times the inverse of the Winograd panel's per-channel pre-scale
+    size_t wino_bytes = 0;
 };
 
 struct Model {

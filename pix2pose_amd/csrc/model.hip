@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <thread>
 
 namespace p2p {
@@ -249,6 +250,77 @@ static int pack_conv(const TensorMap& T, const std::vector<std::string>& names, 
     return finish_layer(L, w, scale, shift);
 }
 
+// Winograd F(4,5) panel of a Conv2D 5x5 stride-1 layer (wino.hip), beside the direct panel pack_conv built: along the row axis
+//   U_j[ky][ci][co] = sum_kx G[j][kx] w[ky][kx][ci][co],   G = the Cook-Toom filter matrix at the points {0, 1, -1, 2, -2, 1/2, -1/2, inf}
+// computed in double, rounded to fp32, pre-scaled per output channel by a power of two (the epilogue scale carries the inverse, like
+// split_panel), split hi / lo and stored in the order the GEMM kernel's waves stream it:
+//   [Cout / 64][position 8][Cin / 16][ky 5][fragment: (tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo)][lane 64][8 halves]
+// lane (li, lk) of a fragment = output channel 32 tile + li, input channels 16 slice + 8 lk + (0..7): the A operand of v_mfma_f32_32x32x16_f16.
+static const double kWinoG[8][5] = {
+    {-1.0, 0.0, 0.0, 0.0, 0.0},
+    {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+    {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+    {1.0 / 90, 2.0 / 90, 4.0 / 90, 8.0 / 90, 16.0 / 90},
+    {1.0 / 90, -2.0 / 90, 4.0 / 90, -8.0 / 90, 16.0 / 90},
+    {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+    {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+    {0.0, 0.0, 0.0, 0.0, 1.0}};
+
+static int pack_wino(const TensorMap& T, const std::string& name, int Cin, int Cout, ConvLayer& L)
+{
+    if (L.prec != PREC_F16X3 || Cin % 32 || Cout % 64) return P2P_OK;       // strict-fp32 models keep the direct form only
+    const float* k = T.get(name + ".kernel", (int64_t)25 * Cin * Cout);
+    if (!k) return P2P_ERR_WEIGHTS;
+    const int S = Cin / 16;
+    // U as [co][j][ky][ci] floats
+    const size_t per_co = (size_t)8 * 5 * Cin;
+    std::vector<float> U((size_t)Cout * per_co);
+    std::vector<float> rs((size_t)Cout, 1.f);
+    parallel_rows((size_t)Cout, per_co * 5, [&](size_t c0, size_t c1) {
+        for (size_t co = c0; co < c1; ++co) {
+            float* u = U.data() + co * per_co;
+            for (int j = 0; j < 8; ++j)
+                for (int ky = 0; ky < 5; ++ky)
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        double a = 0.0;
+                        for (int kx = 0; kx < 5; ++kx) a += kWinoG[j][kx] * (double)k[((size_t)(ky * 5 + kx) * Cin + ci) * Cout + co];
+                        u[((size_t)j * 5 + ky) * Cin + ci] = (float)a;
+                    }
+            rs[co] = f16x3_row_scale(u, per_co);
+        }
+    });
+    const size_t halves = (size_t)(Cout / 64) * 8 * S * 5 * 4 * 512 + 4 * 512;      // + one K-step of padding (wino_gemm_kernel loads one ahead)
+    std::vector<float> panel((halves + 1) / 2, 0.f);
+    uint16_t* o = reinterpret_cast<uint16_t*>(panel.data());
+    parallel_rows((size_t)(Cout / 64) * 8, (size_t)S * 5 * 4 * 512, [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const int nt = (int)(r / 8), j = (int)(r % 8);
+            for (int s = 0; s < S; ++s)
+                for (int ky = 0; ky < 5; ++ky)
+                    for (int f = 0; f < 4; ++f)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = nt * 64 + (f >> 1) * 32 + (lane & 31);
+                            const float sc = rs[co];
+                            const float* u = U.data() + (size_t)co * per_co + ((size_t)j * 5 + ky) * Cin + s * 16 + (lane >> 5) * 8;
+                            uint16_t* dst = o + ((((r * S + s) * 5 + ky) * 4 + f) * 64 + lane) * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = u[e] * sc;
+                                const uint16_t hi = f32_to_f16(v);
+                                dst[e] = (f & 1) ? f32_to_f16(v - f16_to_f32(hi)) : hi;
+                            }
+                        }
+        }
+    });
+    std::vector<float> scale, shift;
+    int rc = fold_bn(T, name, Cout, true, scale, shift);
+    if (rc) return rc;
+    for (int c = 0; c < Cout; ++c) scale[c] *= 1.f / rs[c];          // exact: a power of two
+    if ((rc = upload(panel, &L.wino_u))) return rc;
+    if ((rc = upload(scale, &L.wino_scale))) return rc;
+    L.wino_bytes = panel.size() * sizeof(float);
+    return P2P_OK;
+}
+
 // First-layer (Cin=3) direct-conv panel: [kh*kw*3][Cout] (branches concatenated along Cout).
 static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& names, int KH, int cout_each,
                            ConvLayer& L)
@@ -417,7 +489,9 @@ static void free_layer(ConvLayer& L)
     if (L.w) hipFree(L.w);
     if (L.scale) hipFree(L.scale);
     if (L.shift) hipFree(L.shift);
-    L.w = L.scale = L.shift = nullptr;
+    if (L.wino_u) hipFree(L.wino_u);
+    if (L.wino_scale) hipFree(L.wino_scale);
+    L.w = L.scale = L.shift = L.wino_u = L.wino_scale = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -437,6 +511,9 @@ static int build_decoder(const TensorMap& T, Model& M, int skip3, int skip2, int
     if ((rc = pack_conv(T, {"deconv1"}, 5, 256 + skip3, 256, 2, true, M.L["deconv1"]))) return rc;
     if ((rc = pack_conv(T, {"deconv2"}, 5, 128 + skip2, 256, 2, true, M.L["deconv2"]))) return rc;
     if ((rc = pack_conv(T, {"deconv3"}, 5, 64 + skip1, 128, 2, true, M.L["deconv3"]))) return rc;
+    if ((rc = pack_wino(T, "deconv1", 256 + skip3, 256, M.L["deconv1"]))) return rc;
+    if ((rc = pack_wino(T, "deconv2", 128 + skip2, 256, M.L["deconv2"]))) return rc;
+    if ((rc = pack_wino(T, "deconv3", 64 + skip1, 128, M.L["deconv3"]))) return rc;
     return pack_heads(T, M.L["heads"]);
 }
 
@@ -509,6 +586,7 @@ static const struct { const char* name; size_t per_sample; } kBuffers[] = {
     {"f4", 8 * 8 * 512}, {"enc", 256}, {"dd", 8 * 8 * 256}, {"u1", 16 * 16 * 256}, {"c1", 16 * 16 * 256},
     {"u2", 32 * 32 * 128}, {"c2", 32 * 32 * 256}, {"u3", 64 * 64 * 64}, {"c3", 64 * 64 * 128},
     {"part", 32 * 256},
+    {"wv", 64 * 64 * 128 * 2},      // Winograd-transformed input of the largest 5x5 layer (deconv3 of the paper backbone: 8 bytes per input element)
     // front (resnet50 sizes dominate the paper ones)
     {"f1", 64 * 64 * 128}, {"p1", 32 * 32 * 64}, {"t_a", 32 * 32 * 64}, {"t_b", 32 * 32 * 64},
     {"sc", 32 * 32 * 256}, {"o_a", 32 * 32 * 256}, {"o_b", 32 * 32 * 256}, {"f2", 32 * 32 * 256},
@@ -750,10 +828,80 @@ static int conv_layer(Ctx& X, const ConvLayer& L, const float* in, int N, int H,
     return run_conv(X, L, c);
 }
 
+// The 5x5 stride-1 layers of split-f16 models in Winograd form (wino.hip: 2.5x fewer MFMA products) when the launch fills the chip;
+// smaller launches (one detection at a time) keep the direct kernels.  Unlike the other route pairs of this file the two routes do NOT
+// compute the same bits: both sit within the generator's error bar of the oracle (tests/test_wino_gpu.py), 2e-5 apart.
+// Development builds: P2P_NO_WINO=1 keeps the direct route, P2P_WINO_MIN_WGS moves the threshold.
+static bool wino_enabled() { static const bool on = dev_env("P2P_NO_WINO") == nullptr; return on && specialised_kernels(); }
+static int wino_min_wgs() { static const int v = dev_env("P2P_WINO_MIN_WGS") ? atoi(dev_env("P2P_WINO_MIN_WGS")) : 256; return v; }
+
+static int timed_launch(Ctx& X, int slot, double flops, double bytes, const std::function<hipError_t()>& launch)
+{
+    hipStream_t st = X.cur->stream;
+    if (X.profiling) {
+        Ctx::ProfEvent ev{X.prof_get_event(), X.prof_get_event(), slot, flops, bytes};
+        if (!ev.a || !ev.b) return P2P_ERR_HIP;
+        HIP_TRY(hipEventRecord(ev.a, st));
+        HIP_TRY(launch());
+        HIP_TRY(hipEventRecord(ev.b, st));
+        X.prof_pending.push_back(ev);
+        return P2P_OK;
+    }
+    HIP_TRY(launch());
+    return P2P_OK;
+}
+
+// 0 = not for this route (the caller falls through to the direct kernels), 1 = done, < 0 = error
+static int try_wino(Ctx& X, const ConvLayer& L, const float* a, int Ca, const float* b, int Cb, int cb_stride, int cb_off, int N, int H, float* out)
+{
+    if (!L.wino_u || L.prec != PREC_F16X3 || !wino_enabled() || !wino_supported(H, H, Ca, Cb, L.Cout)) return 0;
+    WinoParams p;
+    memset(&p, 0, sizeof(p));
+    p.seg[0] = {a, Ca, Ca, 0};
+    p.seg[1] = {b, Cb, cb_stride, cb_off};
+    const size_t px = (size_t)N * H * H;
+    const size_t b0 = px * Ca * sizeof(float), b1 = px * cb_stride * sizeof(float);
+    if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || L.wino_bytes >= 0xFFFFFFF0ull) return 0;
+    p.seg_bytes[0] = (unsigned)b0; p.seg_bytes[1] = (unsigned)b1;
+    p.seg0_groups = Ca / 32;
+    p.N = N; p.H = H; p.W = H; p.Cin = Ca + Cb; p.Cout = L.Cout;
+    p.V = X.cur->act["wv"];
+    p.U = L.wino_u; p.scale = L.wino_scale; p.shift = L.shift;
+    p.act = ACT_LEAKY; p.alpha = LEAKY;
+    p.out = out; p.out_cstride = L.Cout; p.out_coff = 0;
+    p.range_acc = X.range_cur;
+    if (wino_gemm_grid(p) < wino_min_wgs()) return 0;
+    if (X.grp && X.grp->models.size() > 1) {
+        const GroupCtx& G = *X.grp;
+        const int ng = (int)G.models.size();
+        if (ng > IGEMM_MAX_GROUPS) return 0;
+        for (int g = 0; g < ng; ++g) {
+            const ConvLayer& Lg = G.models[g]->L.at(L.name);
+            if (!Lg.wino_u || Lg.prec != PREC_F16X3) return 0;
+            if (H == 16 && (G.start[g] & 1)) return 0;                  // two samples per workgroup: a pair must not straddle two objects
+            p.grp[g] = {Lg.wino_u, Lg.wino_scale, Lg.shift, G.start[g], 0};
+        }
+        p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng], 0};
+        p.n_groups = ng;
+    }
+    hipStream_t st = X.cur->stream;
+    const double in_el = (double)px * p.Cin, out_el = (double)px * L.Cout;
+    int rc = timed_launch(X, 11, 0.0, 4.0 * in_el + 8.0 * in_el, [&]() { return launch_wino_input(p, st); });
+    if (rc) return rc;
+    // algorithmic work of the LAYER (the direct form's MACs, like every other slot); compulsory bytes: V once, the panel once, the output
+    rc = timed_launch(X, 10, 2.0 * out_el * 25.0 * p.Cin, 8.0 * in_el + (double)L.wino_bytes + 4.0 * out_el, [&]() { return launch_wino_gemm(p, st); });
+    return rc ? rc : 1;
+}
+
 // 5x5 stride-1 'SAME' conv over the concatenation [a (Ca ch) || b[..., :Cb] (pixel stride cb_stride)]
 static int concat_conv(Ctx& X, const ConvLayer& L, const float* a, int Ca, const float* b, int Cb,
                        int cb_stride, int cb_off, int N, int H, float* out)
 {
+    {
+        const int rc = try_wino(X, L, a, Ca, b, Cb, cb_stride, cb_off, N, H, out);
+        if (rc < 0) return rc;          // (error codes of this library are negative)
+        if (rc == 1) return P2P_OK;
+    }
     ConvCall c;
     c.s0 = {a, Ca, Ca, 0};
     c.s1 = {b, Cb, cb_stride, cb_off};

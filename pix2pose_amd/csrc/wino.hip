@@ -1,0 +1,355 @@
+// Winograd / Cook-Toom minimal filtering F(4, 5) ALONG THE ROW AXIS for the three 5x5 stride-1 'SAME' decoder layers (gfx950, PREC_F16X3).
+//
+// deconv1 / deconv2 / deconv3 (reference pix2pose_model/ae_model.py:207-211,217-220,227-230) are 67 % of the generator's MACs, and the
+// direct kernel (igemm_halo.hip) already runs them at 0.82 of the power wall of their MFMA stream: the only lever left is fewer products.
+// Four outputs of a row need 8 products per (vertical tap, channel) instead of 20:
+//
+//     y[4t + i] = sum_j AT[i][j] * ( sum_{ky, c} V_j[y + ky - 2][t][c] * U_j[ky][c][co] ),   V_j = sum_p BT[j][p] x[4t - 2 + p],
+//                                                                                              U_j = sum_kx G[j][kx] w[ky][kx]
+//
+// with the points {0, +-1, +-2, +-1/2, inf}.  The vertical axis stays direct (5 taps): the eight positions j are eight independent
+// GEMMs [(y, t) x (ky, c)] x [(ky, c) x co] -- 2.5x fewer MFMA products than the direct form.  Arithmetic: the transforms in fp32, the
+// 22-bit hi/lo f16 split AFTER the transform (both operands), three products per block, fp32 accumulation, fp32 inverse transform.
+// oracle/wino_study.py is the error study behind the choice (network output 3.2e-5 from the fp64 graph; the direct form 7.5e-6; the 2-D
+// forms F(2x2,5x5) / F(4x4,5x5) 5.6e-5 / 9.9e-5 -- and their 36 / 64 accumulator sets per tile cannot be fused).
+//
+// Two kernels:
+//   wino_input_kernel   x (two channel segments: the skip concatenation is never materialised) -> V in HBM, already split, in the
+//                       plane layout the GEMM kernel's LDS image has: [n][patch column][16-channel slice][plane = (j, hi/lo, k half)]
+//                       [row][tile 0..3][8 halves].  A fragment read of the GEMM kernel is then 32 consecutive 16-byte slots of a plane:
+//                       conflict-free without padding, and a vertical tap is a constant byte shift (64 B per row).
+//   wino_gemm_kernel    512 threads = 8 waves, wave j owns position j: 128 (y, t) pairs (32 rows x 16 columns of one sample, or two
+//                       16 x 16 samples) x 64 output channels = 128 accumulator registers.  Per K-step (one vertical tap of a
+//                       16-channel slice): 8 V fragments from LDS, 4 U fragments STRAIGHT FROM GLOBAL in fragment order (no wave shares
+//                       another wave's weights, so an LDS round trip would buy nothing; the panel of one 64-channel tile is 1.3-2.6 MB
+//                       and stays in the L2 of the XCDs that work on that tile), 24 MFMAs.  The V image of the next slice is copied
+//                       global -> registers -> LDS two pieces per K-step into the second buffer: one barrier per slice.  Epilogue:
+//                       the eight positions meet in LDS (four passes of 32 pairs), inverse transform, BN + LeakyReLU, 256-byte stores.
+#include "kernels.h"
+
+namespace p2p {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// input transform.  Thread = (row of an 8-row block, tile t of the 16-column patch, channel quad of a 32-channel group); quads fastest, so
+// a load instruction reads whole 128-byte pixel records and a store instruction writes 128-byte runs (two rows x four tiles) of 4 planes.
+// ------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p)
+{
+    const int tid = threadIdx.x;
+    const int quad = tid & 7, t = (tid >> 3) & 3, r = tid >> 5;
+    int b = blockIdx.x;
+    const int rblocks = p.H >> 3;
+    const int rb = b % rblocks; b /= rblocks;
+    const int cgroups = p.Cin >> 5;
+    const int cg = b % cgroups; b /= cgroups;
+    const int PC = p.W >> 4;
+    const int pc = b % PC;
+    const int n = b / PC;
+    const int y = rb * 8 + r;
+
+    const bool s1 = cg >= p.seg0_groups;               // block-uniform
+    const IgemmSeg sg = s1 ? p.seg[1] : p.seg[0];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sg.ptr, 0, s1 ? p.seg_bytes[1] : p.seg_bytes[0], 0x00020000);
+    const unsigned c0 = (unsigned)(sg.coff + (s1 ? cg - p.seg0_groups : cg) * 32 + quad * 4);
+    const int x0 = pc * 16 + t * 4 - 2;
+    const unsigned rowpix = (unsigned)((n * p.H + y) * p.W);
+    f32x4 d[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = x0 + k;
+        const unsigned off = (unsigned)x < (unsigned)p.W ? ((rowpix + (unsigned)x) * (unsigned)sg.cstride + c0) * 4u : OOB;
+        d[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+    f32x4 v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d0 = d[0][e], d1 = d[1][e], d2 = d[2][e], d3 = d[3][e], d4 = d[4][e], d5 = d[5][e], d6 = d[6][e], d7 = d[7][e];
+        // BT of F(4,5) at {0, 1, -1, 2, -2, 1/2, -1/2, inf}; every coefficient is exact in binary, the order of operations is fixed
+        const float a12 = __builtin_fmaf(-4.25f, d4, d2 + d6), b12 = __builtin_fmaf(-4.25f, d3, d1 + d5);
+        const float a34 = __builtin_fmaf(-1.25f, d4, __builtin_fmaf(0.25f, d2, d6)), b34 = __builtin_fmaf(-2.5f, d3, __builtin_fmaf(0.5f, d1, 2.f * d5));
+        const float a56 = __builtin_fmaf(-5.f, d4, __builtin_fmaf(4.f, d2, d6)), b56 = __builtin_fmaf(-2.5f, d3, __builtin_fmaf(2.f, d1, 0.5f * d5));
+        v[0][e] = __builtin_fmaf(5.25f, d2 - d4, d6 - d0);
+        v[1][e] = a12 + b12; v[2][e] = a12 - b12;
+        v[3][e] = a34 + b34; v[4][e] = a34 - b34;
+        v[5][e] = a56 + b56; v[6][e] = a56 - b56;
+        v[7][e] = __builtin_fmaf(5.25f, d3 - d5, d7 - d1);
+    }
+    // plane (j, hl, lk) of slice cg * 2 + (quad >> 2); this thread holds halves [4 (quad & 1), +4) of the 16-byte piece (row y, tile t)
+    const int S = p.Cin >> 4;
+    const int slice = cg * 2 + (quad >> 2), lk = (quad >> 1) & 1;
+    const size_t plane_bytes = (size_t)p.H * 64;
+    char* dst = reinterpret_cast<char*>(p.V) + ((((size_t)n * PC + pc) * S + slice) * 32 + lk) * plane_bytes + (size_t)y * 64 + t * 16 + (quad & 1) * 8;
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x4 w = v[j];
+        amax = range_note4(amax, w);
+        const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(w[0], w[1]), h23 = __builtin_amdgcn_cvt_pkrtz(w[2], w[3]);
+        fp16x2 l01, l23;              // residuals are exact in fp32; round them to nearest
+        l01[0] = (__fp16)(w[0] - (float)h01[0]); l01[1] = (__fp16)(w[1] - (float)h01[1]);
+        l23[0] = (__fp16)(w[2] - (float)h23[0]); l23[1] = (__fp16)(w[3] - (float)h23[1]);
+        *reinterpret_cast<uint2*>(dst + (size_t)(j * 4) * plane_bytes) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+        *reinterpret_cast<uint2*>(dst + (size_t)(j * 4 + 2) * plane_bytes) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    }
+    range_commit(p.range_acc, amax);       // the transformed operand is what the split sees: up to 15x the activation
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// the eight position GEMMs + inverse transform + epilogue
+// ------------------------------------------------------------------------------------------------------------------------------------
+// LDS image of one 16-channel slice: 32 planes [R rows][4 tiles][16 B].  Single: R = 36 = rows y0 - 2 .. y0 + 33 of one sample.
+// DUAL (16x16 grids: two samples per workgroup): R = 38 = [2 zero rows | sample A's 16 | 2 zero rows | sample B's 16 | 2 zero rows].
+// m-tile i = 8 output rows x 4 tiles; its tap ky reads image rows base_i + ky + (0..7): base = 8 i, or {0, 8, 18, 26}.
+template <bool DUAL>
+__global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
+{
+    constexpr int R = DUAL ? 38 : 36;
+    constexpr int PLANE = R * 64;
+    constexpr int BUF = 32 * PLANE;
+    constexpr int NPIECE = BUF / 16;
+    constexpr int NQ = 10;                          // pieces per thread and slice (the last ones partly idle): two per K-step
+    static_assert(NQ * 512 >= NPIECE, "piece schedule");
+    constexpr int XLD = 68;                         // exchange image: [position 8][pair 32][64 channels + 4] floats
+    constexpr int XBUF = 8 * 32 * XLD * 4;
+    static_assert(2 * XBUF <= 2 * BUF, "exchange image fits the two slice buffers");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int j = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = position (kept in an SGPR: it selects the weight stream's descriptor)
+    const int li = lane & 31, lk = lane >> 5;
+
+    const int S = p.Cin >> 4;
+    const int PC = p.W >> 4;
+    const int RB = DUAL ? 1 : p.H >> 5;
+    const int units = DUAL ? (p.N + 1) >> 1 : p.N;
+    const int mt = units * PC * RB;
+
+    // XCD-aware order (block b runs on XCD b % 8): contiguous runs of tiles per XCD, channel tile SLOWEST -- the XCDs that share a
+    // channel tile keep its weight panel in their L2
+    int tl;
+    {
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        tl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ntile = tl / mt;
+    int rest = tl - ntile * mt;
+    const int rb = rest % RB; rest /= RB;
+    const int pc = rest % PC;
+    const int unit = rest / PC;
+    const int n0 = DUAL ? unit * 2 : unit;
+    const bool has_b = DUAL && n0 + 1 < p.N;
+    const int y0 = rb * 32;
+
+    const float* gu = p.U;
+    const float* gscale = p.scale;
+    const float* gshift = p.shift;
+    if (p.n_groups > 1) {                            // groups are runs of samples (DUAL: group starts are even, the host checks)
+        int g = 0;
+        while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= n0) ++g;
+        gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
+    }
+
+    // ---- V: global -> registers -> LDS.  Piece q of this thread = 16-byte slot tid + 512 q of the image (lane-linear in LDS).
+    const unsigned slice_bytes = 32u * (unsigned)p.H * 64u;
+    const size_t unit_block = (size_t)S * slice_bytes;           // bytes of one (sample, patch column)
+    const char* vbase = reinterpret_cast<const char*>(p.V) + ((size_t)n0 * PC + pc) * unit_block;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)(has_b ? 2 * unit_block : unit_block), 0x00020000);
+    unsigned voff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pi = tid + 512 * q;
+        const int plane = pi / (R * 4), rem = pi - plane * (R * 4);
+        const int l = rem >> 2, t = rem & 3;
+        unsigned o = OOB;
+        if (pi < NPIECE) {
+            if (DUAL) {
+                const int sel = l >= 19 ? 1 : 0;
+                const int rr = l - 2 - 18 * sel;
+                if ((unsigned)rr < 16u && (sel == 0 || has_b)) o = (unsigned)sel * (unsigned)unit_block + (unsigned)((plane * 16 + rr) * 64 + t * 16);
+            } else {
+                const int yy = y0 - 2 + l;
+                if ((unsigned)yy < (unsigned)p.H) o = (unsigned)((plane * p.H + yy) * 64 + t * 16);
+            }
+        }
+        voff[q] = o;
+    }
+    f32x4 rv[2];
+    auto vload = [&](int slice, int g, bool on) {   // group g = pieces 2g, 2g + 1; `on` is wave-uniform: off = out of range = no traffic
+        const unsigned so = (unsigned)slice * slice_bytes;
+        const unsigned mask = on ? 0u : OOB;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) rv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff[2 * g + e] | mask, so, 0));
+    };
+    auto vstore = [&](int buf, int g) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int pi = tid + 512 * (2 * g + e);
+            if (pi < NPIECE) *reinterpret_cast<f32x4*>(smem + buf * BUF + pi * 16) = rv[e];
+        }
+    };
+
+    // ---- U: this wave's stream (channel tile, position j): K-step kb = 4 fragments of 1 KB, contiguous.  The panel carries one K-step
+    //      of padding behind its last stream, so the load one K-step ahead needs no condition.
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(gu) + ((size_t)(ntile * 8 + j) * S * 5) * 4096), 0,
+                                                                          (unsigned)((S * 5 + 1) * 4096), 0x00020000);
+    const unsigned uoff = (unsigned)lane * 16u;
+    f16x8 u[2][4];                                   // (tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo) of the even / odd K-steps
+    auto uload = [&](int set, int kb) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) u[set][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + f * 1024, kb * 4096, 0));
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
+
+    // V fragment of m-tile i, tap ky, half hl: plane (j, hl, lk), image row base_i + ky + (li >> 2), tile li & 3
+    const char* img0 = smem + (j * 4 + lk) * PLANE + (li >> 2) * 64 + (li & 3) * 16;
+
+    // prologue: slice 0 -> buffer 0
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { vload(0, g, true); vstore(0, g); }
+    uload(0, 0);
+    __syncthreads();
+    vload(1, 0, true);                               // S is even (Cin % 32 == 0)
+
+    // Two slices (10 K-steps) per iteration: buffer and weight register set of every K-step are compile-time.
+    for (int s2 = 0; s2 < S; s2 += 2) {
+#pragma unroll
+        for (int kk = 0; kk < 10; ++kk) {
+            const int half = kk / 5, ky = kk % 5;
+            const int s = s2 + half;
+            uload((kk + 1) & 1, s * 5 + ky + 1);
+            vstore(half ^ 1, ky);                                // loaded one K-step ago (a slice past the last one: zeros nobody reads)
+            if (ky < 4) vload(s + 1, ky + 1, half == 0 || s + 1 < S);
+            else vload(s + 2, 0, s + 2 < S);
+            const char* img = img0 + half * BUF;
+            f16x8 vh[4], vl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (DUAL ? (i < 2 ? 8 * i : 8 * i + 2) : 8 * i) + ky;
+                vh[i] = *reinterpret_cast<const f16x8*>(img + row * 64);
+                vl[i] = *reinterpret_cast<const f16x8*>(img + row * 64 + 2 * PLANE);
+            }
+            const f16x8* uc = u[kk & 1];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c + 1], vh[i], acc[c][i], 0, 0, 0);
+                    acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vl[i], acc[c][i], 0, 0, 0);
+                    acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vh[i], acc[c][i], 0, 0, 0);
+                }
+            if (ky == 4) __syncthreads();          // everyone is done with this slice's image; the next one is complete
+        }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA with U as the A operand: row = channel (r & 3) + 8 (r >> 2) + 4 lk of the 32-tile,
+    //      column li = pair.  Pass i: the eight waves put m-tile i into the exchange image (a lane writes 4 consecutive channels),
+    //      then thread (pair = tid >> 4, channel quad = tid & 15) combines the eight positions into four output pixels.
+    const int pair = tid >> 4, cq = tid & 15;
+    const int col = ntile * 64 + cq * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + col);
+    if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* X = reinterpret_cast<float*>(smem + (i & 1) * XBUF);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[c][i][4 * q], acc[c][i][4 * q + 1], acc[c][i][4 * q + 2], acc[c][i][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(X + (j * 32 + li) * XLD + c * 32 + 8 * q + 4 * lk) = v;
+            }
+        __syncthreads();
+        f32x4 m[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) m[jj] = *reinterpret_cast<const f32x4*>(X + (jj * 32 + pair) * XLD + cq * 4);
+        int n, y;
+        if (DUAL) { n = n0 + (i >> 1); y = (i & 1) * 8 + (pair >> 2); }
+        else { n = n0; y = y0 + i * 8 + (pair >> 2); }
+        if (DUAL && n >= p.N) continue;
+        const size_t pix = ((size_t)n * p.H + y) * p.W + pc * 16 + (pair & 3) * 4;
+        float* o = p.out + pix * p.out_cstride + p.out_coff + col;
+        f32x4 yv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // AT of F(4,5): rows (1 1 1 1 1 1 1 0), (0 1 -1 2 -2 1/2 -1/2 0), (0 1 1 4 4 1/4 1/4 0), (0 1 -1 8 -8 1/8 -1/8 1)
+            const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
+            const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+            const float s56 = m[5][e] + m[6][e], d56 = m[5][e] - m[6][e];
+            yv[0][e] = (m[0][e] + s12) + (s34 + s56);
+            yv[1][e] = __builtin_fmaf(0.5f, d56, __builtin_fmaf(2.f, d34, d12));
+            yv[2][e] = __builtin_fmaf(0.25f, s56, __builtin_fmaf(4.f, s34, s12));
+            yv[3][e] = __builtin_fmaf(0.125f, d56, __builtin_fmaf(8.f, d34, d12)) + m[7][e];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 v = yv[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
+            } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+            }
+            amax = range_note4(amax, v);
+            *reinterpret_cast<f32x4*>(o + (size_t)k * p.out_cstride) = v;
+        }
+    }
+    range_commit(p.range_acc, amax);
+}
+
+}  // namespace
+
+bool wino_supported(int H, int W, int Cin0, int Cin1, int Cout)
+{
+    if (Cin0 % 32 || Cin1 % 32 || Cout % 64 || W % 16) return false;
+    return (H == 16 && W == 16) || H % 32 == 0;
+}
+
+// bytes of V for N samples
+size_t wino_v_bytes(int N, int H, int W, int Cin) { return (size_t)N * H * W * Cin * 8; }
+
+int wino_gemm_grid(const WinoParams& p)
+{
+    const bool dual = p.H == 16;
+    return (dual ? (p.N + 1) / 2 : p.N * (p.H / 32)) * (p.W / 16) * (p.Cout / 64);
+}
+
+hipError_t launch_wino_input(const WinoParams& p, hipStream_t s)
+{
+    const int grid = p.N * (p.W / 16) * (p.Cin / 32) * (p.H / 8);
+    hipLaunchKernelGGL(wino_input_kernel, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino_gemm(const WinoParams& p, hipStream_t s)
+{
+    const int grid = wino_gemm_grid(p);
+    if (p.H == 16) hipLaunchKernelGGL((wino_gemm_kernel<true>), dim3(grid), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((wino_gemm_kernel<false>), dim3(grid), dim3(512), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace p2p

@@ -1,0 +1,152 @@
+"""The 5x5 stride-1 decoder layers deconv1 / deconv2 / deconv3 (reference pix2pose_model/ae_model.py:207-211,217-220,227-230) in Winograd
+F(4,5) form along the row axis (csrc/wino.hip: input transform + eight position GEMMs + inverse transform; 2.5x fewer MFMA products than
+the direct kernels of csrc/igemm_halo.hip).
+
+Unlike the other route pairs of the library the two forms do NOT compute the same bits (different products are formed), so the bar is the
+ORACLE: network output within 1e-4 abs (north_star: 1e-3) on either route, both backbones, freshly-initialised and trained-like weight
+statistics -- and the two routes within 6e-5 of each other (oracle/wino_study.py predicts 3.2e-5 from fp64 for this form).
+
+The shipped library takes the Winograd route when a layer's launch has >= 256 workgroups (deconv3 from 16 inputs, deconv2 from 32, deconv1
+from 128); the development twin's P2P_WINO_MIN_WGS / P2P_NO_WINO move that, which is how 3 and 5 inputs (odd: the two-samples-per-workgroup
+form of the 16x16 layer with a missing partner) reach the kernels here next to an oracle that takes a second per input."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pix2pose_amd.build import dev_switches
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+XYZ_TOL = 1e-4
+ROUTE_TOL = 6e-5
+
+_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from pix2pose_amd import weights as W
+from pix2pose_amd.runtime import Context, Generator
+out, backbone, fam, ns = sys.argv[1], sys.argv[2], sys.argv[3], [int(v) for v in sys.argv[4].split(",")]
+x = (np.random.RandomState(11).randint(0, 256, (max(ns), 128, 128, 3)).astype(np.float32) - 128) / 128
+w = W.trained_like_weights(backbone, 5) if fam == "trained_like" else W.synthetic_weights(backbone, 3)
+ctx = Context(0, max_batch=max(ns))
+g = Generator(w, backbone, ctx)
+r = {}
+for n in ns:
+    ctx.profile(True)
+    dec, prob = g.predict(x[:n])
+    st = ctx.profile_read()
+    ctx.profile(False)
+    r["dec%%d" %% n], r["prob%%d" %% n] = dec, prob
+    r["launches%%d" %% n] = np.array([s["launches"] for s in st])
+np.savez(out, **r)
+""" % ROOT
+
+
+def _run(tmp_path, tag, backbone, fam, ns, env_extra):
+    out = str(tmp_path / ("%s.npz" % tag))
+    env = dict(os.environ)
+    env.update(env_extra)
+    subprocess.run([sys.executable, "-c", _SCRIPT, out, backbone, fam, ",".join(map(str, ns))], check=True, env=env, cwd=ROOT, timeout=900)
+    return np.load(out)
+
+
+def _inputs(n):
+    return (np.random.RandomState(11).randint(0, 256, (n, 128, 128, 3)).astype(np.float32) - 128) / 128
+
+
+@pytest.mark.parametrize("fam", ["synthetic", "trained_like"])
+@pytest.mark.parametrize("backbone", ["resnet50", "paper"])
+def test_winograd_route_matches_oracle_and_direct_route(tmp_path, backbone, fam):
+    from oracle import ae_oracle as O
+    from pix2pose_amd import weights as W
+    ns = [3, 5]
+    a = _run(tmp_path, "wino", backbone, fam, ns, dev_switches(P2P_WINO_MIN_WGS=1, P2P_STREAM_WGS=0))
+    b = _run(tmp_path, "direct", backbone, fam, ns, dev_switches(P2P_NO_WINO=1, P2P_STREAM_WGS=0))
+    w = W.trained_like_weights(backbone, 5) if fam == "trained_like" else W.synthetic_weights(backbone, 3)
+    d0, p0 = O.forward(w, _inputs(5), backbone)
+    for n in ns:
+        assert a["launches%d" % n][10] == 3 and a["launches%d" % n][11] == 3, a["launches%d" % n]       # the three layers, both kernels
+        assert b["launches%d" % n][10] == 0 and b["launches%d" % n][11] == 0
+        for k, ref in (("dec", d0), ("prob", p0)):
+            ya, yb = a["%s%d" % (k, n)], b["%s%d" % (k, n)]
+            assert np.isfinite(ya).all()
+            ea, eb, ed = np.abs(ya - ref[:n]).max(), np.abs(yb - ref[:n]).max(), np.abs(ya - yb).max()
+            print("%s/%s n=%d %s: winograd-oracle %.2e  direct-oracle %.2e  winograd-direct %.2e" % (backbone, fam, n, k, ea, eb, ed))
+            assert ea < XYZ_TOL and eb < XYZ_TOL and ed < ROUTE_TOL
+    # a sample's bits do not depend on the batch it travels in as long as the route is the same
+    np.testing.assert_array_equal(a["dec5"][:3], a["dec3"])
+    np.testing.assert_array_equal(a["prob5"][:3], a["prob3"])
+
+
+@pytest.mark.parametrize("backbone,n,precision", [("resnet50", 72, "f16x3"), ("resnet50", 24, "f32"), ("paper", 40, "f16x3"), ("paper", 20, "f32")])
+def test_batched_routes_match_oracle(backbone, n, precision):
+    """The kernels that carry the benchmark, held to the oracle DIRECTLY (not through the route-equivalence chain).  At 72 inputs EVERY
+    layer of a split-f16 resnet50 pass runs its batched / fused kernel -- asserted through the launch counts of p2p_profile_read: no launch
+    on the small-launch route (igemm_stream_kernel), conv1 + pool, the seven fused bottleneck blocks, conv4 and the four up1 phases on
+    igemm_halo8_kernel, deconv1 + up2 on igemm_halo_kernel<2,2>, up3 on <4,2>, deconv2 / deconv3 in Winograd form, the merged heads.
+    (Reference graph: pix2pose_model/ae_model.py:175-240.)"""
+    from oracle import ae_oracle as O
+    from pix2pose_amd import weights as W
+    from pix2pose_amd.runtime import Context, Generator
+    w = W.synthetic_weights(backbone, 4)
+    ctx = Context(0, max_batch=n)
+    g = Generator(w, backbone, ctx, precision=precision)
+    x = _inputs(n)
+    ctx.profile(True)
+    dec, prob = g.predict(x)
+    st = ctx.profile_read()
+    ctx.profile(False)
+    launches = [s["launches"] for s in st]
+    print(backbone, precision, n, "launches per kernel family:", launches)
+    if precision == "f16x3":
+        assert launches[10] == 2 and launches[11] == 2, launches          # deconv2, deconv3 in Winograd form
+        assert launches[5] == 1, launches                                  # merged heads
+    if precision == "f16x3" and backbone == "resnet50":
+        assert launches[8] == 0, launches                                  # nothing on the small-launch route
+        assert launches[9] == 7, launches                                  # all seven bottleneck blocks fused
+        assert launches[6] == 5, launches                                  # conv4 + four up1 phases
+        assert launches[3] == 5 and launches[4] == 4, launches             # deconv1 + up2's phases; up3's phases
+    d0, p0 = O.forward(w, x, backbone)
+    e = max(np.abs(dec - d0).max(), np.abs(prob - p0).max())
+    print("%s/%s %d inputs: |d|max vs oracle %.2e" % (backbone, precision, n, e))
+    assert e < XYZ_TOL
+
+
+_MIXED = r"""
+import sys
+sys.path.insert(0, %r)
+from pix2pose_amd import synthetic as S
+from pix2pose_amd import weights as W
+from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
+ctx = Context(0, max_batch=256)
+specs = [ObjectSpec(Generator(W.synthetic_weights("resnet50", 10 + k), "resnet50", ctx), S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2) for k in range(3)]
+sc = S.make_scene(48, seed=3)
+dets = [(d[0], i %% 3, d[2], d[3]) for i, d in enumerate(sc["dets"])]
+ctx.profile(True)
+mixed = est_pose_batch(ctx, specs, list(sc["images"]), dets)[0]
+st = ctx.profile_read()
+assert st[10]["launches"] >= 3 and st[10]["launches"] == st[11]["launches"], [s["launches"] for s in st]
+for k in range(3):
+    idx = [i for i in range(48) if i %% 3 == k]
+    alone = est_pose_batch(ctx, specs, list(sc["images"]), [dets[i] for i in idx])[0]
+    for i, q in zip(idx, alone):
+        p = mixed[i]
+        assert (p.status, p.n_inliers, p.n_init_mask, tuple(p.bbox_t), tuple(p.R), tuple(p.t)) == \
+               (q.status, q.n_inliers, q.n_init_mask, tuple(q.bbox_t), tuple(q.R), tuple(q.t)), i
+print("mixed == alone")
+""" % ROOT
+
+
+def test_winograd_route_in_a_mixed_object_pass():
+    """Grouped generator passes (BASELINE.json configs[3]: detections of several objects in one batch, every workgroup of the Winograd
+    kernels looks its sample's panel up; the two samples of a 16x16-layer workgroup belong to one object): 3 objects x 16 detections through
+    est_pose_batch == the same detections object by object, bit for bit -- with the route pinned (P2P_WINO_MIN_WGS=1: all three layers in
+    Winograd form whatever the batch size), a sample's bits do not depend on the batch it travels in."""
+    env = dict(os.environ)
+    env.update(dev_switches(P2P_WINO_MIN_WGS=1))
+    r = subprocess.run([sys.executable, "-c", _MIXED], env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0 and "mixed == alone" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

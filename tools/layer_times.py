@@ -65,6 +65,19 @@ def main(path, batch=256):
         out.append((nm, mmac))
         i += 1
     layers = out
+    # 5x5 stride-1 layers in Winograd form (wino.hip): two launches per layer -- the input transform, then the position GEMMs
+    out, i = [], 0
+    for nm, mmac in layers:
+        if nm.startswith("deconv") and i < len(ks) and "wino_input" in ks[i][0]:
+            out.append((nm + " V", 0))
+            KF[nm + " V"] = {"deconv1": 3 * 98, "deconv2": 3 * 262, "deconv3": 3 * 393}.get(nm, 0)      # x read once, V (2x the elements) written once
+            out.append((nm + " gemm", mmac))
+            KF[nm + " gemm"] = KF.get(nm, 0)
+            i += 2
+            continue
+        out.append((nm, mmac))
+        i += 1
+    layers = out
     ks = ks[:len(layers)]
     tot = 0
     for (nm, mmac), r in zip(layers, ks):
