@@ -38,6 +38,10 @@ namespace {
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
+// Workgroup barrier for LDS traffic only: __syncthreads() carries a release fence, which on gfx950 is s_waitcnt vmcnt(0) -- every global
+// STORE of the epilogue would have to reach L2 before the next exchange pass (and, in the persistent loop, before the next tile) could start.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 // input transform.  Thread = (row of an 8-row block, tile t of the 16-column patch, channel quad of a 32-channel group); quads fastest, so
 // a load instruction reads whole 128-byte pixel records and a store instruction writes 128-byte runs (two rows x four tiles) of 4 planes.
@@ -109,15 +113,16 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p)
 // LDS image of one 16-channel slice: 32 planes [R rows][4 tiles][16 B].  Single: R = 36 = rows y0 - 2 .. y0 + 33 of one sample.
 // DUAL (16x16 grids: two samples per workgroup): R = 38 = [2 zero rows | sample A's 16 | 2 zero rows | sample B's 16 | 2 zero rows].
 // m-tile i = 8 output rows x 4 tiles; its tap ky reads image rows base_i + ky + (0..7): base = 8 i, or {0, 8, 18, 26}.
+// Wave j reads only the four planes of ITS position -- so it also stages them itself (9-10 pieces of 1 KB per slice, two per K-step,
+// each written to LDS two K-steps after its load was issued: V comes from HBM): the K loop has no workgroup barrier at all, the eight
+// waves drift freely.  The kernel is persistent (one workgroup per CU walks the tiles): the output stores of a tile drain behind the next
+// tile's K loop instead of the whole chip storing in lockstep.
 template <bool DUAL>
 __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
 {
     constexpr int R = DUAL ? 38 : 36;
     constexpr int PLANE = R * 64;
     constexpr int BUF = 32 * PLANE;
-    constexpr int NPIECE = BUF / 16;
-    constexpr int NQ = 10;                          // pieces per thread and slice (the last ones partly idle): two per K-step
-    static_assert(NQ * 512 >= NPIECE, "piece schedule");
     constexpr int XLD = 68;                         // exchange image: [position 8][pair 32][64 channels + 4] floats
     constexpr int XBUF = 8 * 32 * XLD * 4;
     static_assert(2 * XBUF <= 2 * BUF, "exchange image fits the two slice buffers");
@@ -131,20 +136,27 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
     const int S = p.Cin >> 4;
     const int PC = p.W >> 4;
     const int RB = DUAL ? 1 : p.H >> 5;
+    const int NT = p.Cout >> 6;
     const int units = DUAL ? (p.N + 1) >> 1 : p.N;
-    const int mt = units * PC * RB;
+    const int ntiles = units * PC * RB * NT;
+    const unsigned slice_bytes = 32u * (unsigned)p.H * 64u;
+    const size_t unit_block = (size_t)S * slice_bytes;           // bytes of one (sample, patch column)
 
-    // XCD-aware order (block b runs on XCD b % 8): contiguous runs of tiles per XCD, channel tile SLOWEST -- the XCDs that share a
-    // channel tile keep its weight panel in their L2
-    int tl;
+    // XCD-aware order (block b runs on XCD b % 8): every sweep of gridDim.x tiles is cut into contiguous runs per XCD, channel tile fastest:
+    // the workgroups that share a V patch (one per channel tile) run on one XCD at the same time
+    int tl0;
     {
         const int nblk = gridDim.x, b = blockIdx.x;
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = b & 7, idx = b >> 3;
-        tl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tl0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int ntile = tl / mt;
-    int rest = tl - ntile * mt;
+    const int pair = tid >> 4, cq = tid & 15;       // epilogue role
+    float amax = 0.f;
+
+    for (int tl = tl0; tl < ntiles; tl += gridDim.x) {
+    const int ntile = tl % NT;
+    int rest = tl / NT;
     const int rb = rest % RB; rest /= RB;
     const int pc = rest % PC;
     const int unit = rest / PC;
@@ -161,44 +173,57 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
         gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
     }
 
-    // ---- V: global -> registers -> LDS.  Piece q of this thread = 16-byte slot tid + 512 q of the image (lane-linear in LDS).
-    const unsigned slice_bytes = 32u * (unsigned)p.H * 64u;
-    const size_t unit_block = (size_t)S * slice_bytes;           // bytes of one (sample, patch column)
+    // ---- V: global -> registers -> LDS, this wave's four planes only, in 1 KB pieces (16 rows x 4 tiles of one plane per wave-instruction).
+    //      Single: piece q < 8 = rows [16 (q & 1), +16) of plane q >> 1; piece 8 = the last four rows of all four planes (16 lanes each).
+    //      DUAL:   piece q < 8 = sample q & 1 of plane q >> 1 (the zero rows between and around the samples are written once per tile).
+    //      Per lane only the validity of border rows differs: three address registers (one for DUAL), everything else is scalar.
     const char* vbase = reinterpret_cast<const char*>(p.V) + ((size_t)n0 * PC + pc) * unit_block;
-    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)(has_b ? 2 * unit_block : unit_block), 0x00020000);
-    unsigned voff[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int pi = tid + 512 * q;
-        const int plane = pi / (R * 4), rem = pi - plane * (R * 4);
-        const int l = rem >> 2, t = rem & 3;
-        unsigned o = OOB;
-        if (pi < NPIECE) {
-            if (DUAL) {
-                const int sel = l >= 19 ? 1 : 0;
-                const int rr = l - 2 - 18 * sel;
-                if ((unsigned)rr < 16u && (sel == 0 || has_b)) o = (unsigned)sel * (unsigned)unit_block + (unsigned)((plane * 16 + rr) * 64 + t * 16);
-            } else {
-                const int yy = y0 - 2 + l;
-                if ((unsigned)yy < (unsigned)p.H) o = (unsigned)((plane * p.H + yy) * 64 + t * 16);
-            }
-        }
-        voff[q] = o;
+    const unsigned vrange = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(has_b ? 2 * unit_block : unit_block));     // (kept scalar: a vector select here makes every load a waterfall loop)
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vrange, 0x00020000);
+    const unsigned plane_bytes = (unsigned)p.H * 64u;
+    unsigned vo_a, vo_b, vo_c;
+    if (DUAL) {
+        vo_a = vo_b = vo_c = (unsigned)lane * 16u;
+    } else {
+        const int row = lane >> 2, t = lane & 3;
+        vo_b = (unsigned)((y0 + 14 + row) * 64 + t * 16);                                   // rows y0 + 14 .. y0 + 29: always inside
+        vo_a = y0 - 2 + row >= 0 ? vo_b - 1024u : OOB;                                      // rows y0 - 2 .. y0 + 13
+        const int yc = y0 + 30 + ((lane & 15) >> 2);                                        // rows y0 + 30 .. y0 + 33 of plane lane >> 4
+        vo_c = yc < p.H ? (unsigned)(lane >> 4) * plane_bytes + (unsigned)(yc * 64 + t * 16) : OOB;
     }
-    f32x4 rv[2];
-    auto vload = [&](int slice, int g, bool on) {   // group g = pieces 2g, 2g + 1; `on` is wave-uniform: off = out of range = no traffic
-        const unsigned so = (unsigned)slice * slice_bytes;
-        const unsigned mask = on ? 0u : OOB;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) rv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff[2 * g + e] | mask, so, 0));
+    char* wreg = smem + j * 4 * PLANE + lane * 16;                                          // rows 0..15 of the wave's first plane, buffer 0
+    char* wreg_c = smem + (j * 4 + (lane >> 4)) * PLANE + 32 * 64 + (lane & 15) * 16;       // single: the quarter piece
+    f32x4 rv[2][2];                                                                         // two groups of two pieces in flight
+    auto vload1 = [&](f32x4& dst, int slice, int q, bool on) {     // `on` is wave-uniform: off = out of range = no traffic
+#ifdef P2P_ABL_WV
+        on = false;
+#endif
+        unsigned so = (unsigned)slice * slice_bytes + (unsigned)(j * 4) * plane_bytes;
+        unsigned vo;
+        if (DUAL) {
+            if (q >= 8) return;
+            so += (unsigned)(q >> 1) * plane_bytes + ((q & 1) ? (unsigned)unit_block : 0u);
+            vo = vo_a;
+            if ((q & 1) && !has_b) on = false;
+        } else if (q < 8) {
+            so += (unsigned)(q >> 1) * plane_bytes;
+            vo = (q & 1) ? vo_b : vo_a;
+        } else if (q == 8) {
+            vo = vo_c;
+        } else return;
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo | (on ? 0u : OOB), so, 0));
     };
-    auto vstore = [&](int buf, int g) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int pi = tid + 512 * (2 * g + e);
-            if (pi < NPIECE) *reinterpret_cast<f32x4*>(smem + buf * BUF + pi * 16) = rv[e];
+    auto vstore1 = [&](const f32x4& src, int buf, int q) {
+        if (DUAL) {
+            if (q < 8) *reinterpret_cast<f32x4*>(wreg + buf * BUF + (q >> 1) * PLANE + ((q & 1) ? 20 : 2) * 64) = src;
+        } else if (q < 8) {
+            *reinterpret_cast<f32x4*>(wreg + buf * BUF + (q >> 1) * PLANE + (q & 1) * 1024) = src;
+        } else if (q == 8) {
+            *reinterpret_cast<f32x4*>(wreg_c + buf * BUF) = src;
         }
     };
+    auto vload = [&](int set, int slice, int g, bool on) { vload1(rv[set][0], slice, 2 * g, on); vload1(rv[set][1], slice, 2 * g + 1, on); };
+    auto vstore = [&](int set, int buf, int g) { vstore1(rv[set][0], buf, 2 * g); vstore1(rv[set][1], buf, 2 * g + 1); };
 
     // ---- U: this wave's stream (channel tile, position j): K-step kb = 4 fragments of 1 KB, contiguous.  The panel carries one K-step
     //      of padding behind its last stream, so the load one K-step ahead needs no condition.
@@ -222,23 +247,43 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
     // V fragment of m-tile i, tap ky, half hl: plane (j, hl, lk), image row base_i + ky + (li >> 2), tile li & 3
     const char* img0 = smem + (j * 4 + lk) * PLANE + (li >> 2) * 64 + (li & 3) * 16;
 
-    // prologue: slice 0 -> buffer 0
+    lds_barrier();                                   // (persistent loop) the previous tile's exchange image has been read
+    if (DUAL) {
+        // the six zero rows of this wave's planes in both buffers (the exchange image overwrites them every tile): 2 x 4 x 6 rows x 4 slots
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 5; ++g) { vload(0, g, true); vstore(0, g); }
+        for (int k = 0; k < 3; ++k) {
+            const int sl = lane + 64 * k;                  // 0..191: (buffer, plane, zero row 0..5, slot)
+            const int bf = sl / 96, r2 = sl - bf * 96;
+            const int pl = r2 / 24, r3 = r2 - pl * 24;
+            const int zr = r3 >> 2, t = r3 & 3;
+            const int row = zr < 2 ? zr : (zr < 4 ? 16 + zr : 32 + zr);     // 0, 1, 18, 19, 36, 37
+            *reinterpret_cast<f32x4*>(smem + bf * BUF + (j * 4 + pl) * PLANE + row * 64 + t * 16) = z;
+        }
+    }
+    // prologue: slice 0 -> buffer 0; the first two groups of slice 1 on their way
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { vload(g & 1, 0, g, true); vstore(g & 1, 0, g); }
     uload(0, 0);
-    __syncthreads();
-    vload(1, 0, true);                               // S is even (Cin % 32 == 0)
+    vload(0, 1, 0, true);                            // S is even (Cin % 32 == 0)
+    vload(1, 1, 1, true);
 
-    // Two slices (10 K-steps) per iteration: buffer and weight register set of every K-step are compile-time.
+    // Two slices (10 K-steps) per iteration: buffer, weight register set and staging register set of every K-step are compile-time.
+    // K-step (s, ky): write group ky of slice s + 1 (loaded two K-steps ago), issue the load of the group two K-steps ahead.
     for (int s2 = 0; s2 < S; s2 += 2) {
 #pragma unroll
         for (int kk = 0; kk < 10; ++kk) {
             const int half = kk / 5, ky = kk % 5;
             const int s = s2 + half;
+#ifndef P2P_ABL_WU
             uload((kk + 1) & 1, s * 5 + ky + 1);
-            vstore(half ^ 1, ky);                                // loaded one K-step ago (a slice past the last one: zeros nobody reads)
-            if (ky < 4) vload(s + 1, ky + 1, half == 0 || s + 1 < S);
-            else vload(s + 2, 0, s + 2 < S);
+#else
+            if (s2 == 0) uload((kk + 1) & 1, s * 5 + ky + 1);
+#endif
+            vstore(kk & 1, half ^ 1, ky);                        // (a slice past the last one: zeros nobody reads)
+            if (ky < 3) vload(kk & 1, s + 1, ky + 2, half == 0 || s + 1 < S);
+            else vload(kk & 1, s + 2, ky - 3, s + 2 < S);
+            __builtin_amdgcn_sched_barrier(0);                   // the loads above stay AHEAD of this K-step's matrix work (the scheduler would sink them to their uses)
             const char* img = img0 + half * BUF;
             f16x8 vh[4], vl[4];
 #pragma unroll
@@ -256,19 +301,31 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
                     acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vl[i], acc[c][i], 0, 0, 0);
                     acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vh[i], acc[c][i], 0, 0, 0);
                 }
-            if (ky == 4) __syncthreads();          // everyone is done with this slice's image; the next one is complete
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    lds_barrier();                                   // every wave is done with its planes: the exchange image may overwrite them
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA with U as the A operand: row = channel (r & 3) + 8 (r >> 2) + 4 lk of the 32-tile,
     //      column li = pair.  Pass i: the eight waves put m-tile i into the exchange image (a lane writes 4 consecutive channels),
     //      then thread (pair = tid >> 4, channel quad = tid & 15) combines the eight positions into four output pixels.
-    const int pair = tid >> 4, cq = tid & 15;
     const int col = ntile * 64 + cq * 4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + col);
     if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
-    float amax = 0.f;
+#ifdef P2P_ABL_WEPI
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[c][i][r];
+        if (t == 123.456f) p.out[tid] = t;
+        continue;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float* X = reinterpret_cast<float*>(smem + (i & 1) * XBUF);
@@ -279,44 +336,49 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
                 const f32x4 v = {acc[c][i][4 * q], acc[c][i][4 * q + 1], acc[c][i][4 * q + 2], acc[c][i][4 * q + 3]};
                 *reinterpret_cast<f32x4*>(X + (j * 32 + li) * XLD + c * 32 + 8 * q + 4 * lk) = v;
             }
-        __syncthreads();
+        lds_barrier();
         f32x4 m[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) m[jj] = *reinterpret_cast<const f32x4*>(X + (jj * 32 + pair) * XLD + cq * 4);
         int n, y;
         if (DUAL) { n = n0 + (i >> 1); y = (i & 1) * 8 + (pair >> 2); }
         else { n = n0; y = y0 + i * 8 + (pair >> 2); }
-        if (DUAL && n >= p.N) continue;
-        const size_t pix = ((size_t)n * p.H + y) * p.W + pc * 16 + (pair & 3) * 4;
-        float* o = p.out + pix * p.out_cstride + p.out_coff + col;
-        f32x4 yv[4];
+        if (!DUAL || n < p.N) {
+            const size_t pix = ((size_t)n * p.H + y) * p.W + pc * 16 + (pair & 3) * 4;
+            float* o = p.out + pix * p.out_cstride + p.out_coff + col;
+            f32x4 yv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // AT of F(4,5): rows (1 1 1 1 1 1 1 0), (0 1 -1 2 -2 1/2 -1/2 0), (0 1 1 4 4 1/4 1/4 0), (0 1 -1 8 -8 1/8 -1/8 1)
-            const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
-            const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
-            const float s56 = m[5][e] + m[6][e], d56 = m[5][e] - m[6][e];
-            yv[0][e] = (m[0][e] + s12) + (s34 + s56);
-            yv[1][e] = __builtin_fmaf(0.5f, d56, __builtin_fmaf(2.f, d34, d12));
-            yv[2][e] = __builtin_fmaf(0.25f, s56, __builtin_fmaf(4.f, s34, s12));
-            yv[3][e] = __builtin_fmaf(0.125f, d56, __builtin_fmaf(8.f, d34, d12)) + m[7][e];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            f32x4 v = yv[k];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
-            if (p.act == ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
-            } else if (p.act == ACT_LEAKY) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+            for (int e = 0; e < 4; ++e) {
+                // AT of F(4,5): rows (1 1 1 1 1 1 1 0), (0 1 -1 2 -2 1/2 -1/2 0), (0 1 1 4 4 1/4 1/4 0), (0 1 -1 8 -8 1/8 -1/8 1)
+                const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
+                const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+                const float s56 = m[5][e] + m[6][e], d56 = m[5][e] - m[6][e];
+                yv[0][e] = (m[0][e] + s12) + (s34 + s56);
+                yv[1][e] = __builtin_fmaf(0.5f, d56, __builtin_fmaf(2.f, d34, d12));
+                yv[2][e] = __builtin_fmaf(0.25f, s56, __builtin_fmaf(4.f, s34, s12));
+                yv[3][e] = __builtin_fmaf(0.125f, d56, __builtin_fmaf(8.f, d34, d12)) + m[7][e];
             }
-            amax = range_note4(amax, v);
-            *reinterpret_cast<f32x4*>(o + (size_t)k * p.out_cstride) = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 v = yv[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+                if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
+                } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                }
+                amax = range_note4(amax, v);
+#ifdef P2P_ABL_WST
+                if (v[0] == 123.456f)
+#endif
+                *reinterpret_cast<f32x4*>(o + (size_t)k * p.out_cstride) = v;
+            }
         }
     }
+    }   // tiles
     range_commit(p.range_acc, amax);
 }
 
@@ -346,7 +408,16 @@ hipError_t launch_wino_input(const WinoParams& p, hipStream_t s)
 
 hipError_t launch_wino_gemm(const WinoParams& p, hipStream_t s)
 {
-    const int grid = wino_gemm_grid(p);
+    // persistent: one workgroup per CU (the kernel's LDS image admits no second one) walks the tiles
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int tiles = wino_gemm_grid(p);
+    const int grid = tiles < n_cu ? tiles : n_cu;
     if (p.H == 16) hipLaunchKernelGGL((wino_gemm_kernel<true>), dim3(grid), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((wino_gemm_kernel<false>), dim3(grid), dim3(512), 0, s, p);
     return hipGetLastError();

@@ -85,8 +85,8 @@ def test_winograd_route_matches_oracle_and_direct_route(tmp_path, backbone, fam)
 @pytest.mark.parametrize("backbone,n,precision", [("resnet50", 72, "f16x3"), ("resnet50", 24, "f32"), ("paper", 40, "f16x3"), ("paper", 20, "f32")])
 def test_batched_routes_match_oracle(backbone, n, precision):
     """The kernels that carry the benchmark, held to the oracle DIRECTLY (not through the route-equivalence chain).  At 72 inputs EVERY
-    layer of a split-f16 resnet50 pass runs its batched / fused kernel -- asserted through the launch counts of p2p_profile_read: no launch
-    on the small-launch route (igemm_stream_kernel), conv1 + pool, the seven fused bottleneck blocks, conv4 and the four up1 phases on
+    convolution of a split-f16 resnet50 pass runs its batched / fused kernel -- asserted through the launch counts of p2p_profile_read: nothing
+    but the split-K Dense layer on the small-launch route (igemm_stream_kernel), conv1 + pool, the seven fused bottleneck blocks, conv4 and the four up1 phases on
     igemm_halo8_kernel, deconv1 + up2 on igemm_halo_kernel<2,2>, up3 on <4,2>, deconv2 / deconv3 in Winograd form, the merged heads.
     (Reference graph: pix2pose_model/ae_model.py:175-240.)"""
     from oracle import ae_oracle as O
@@ -106,7 +106,7 @@ def test_batched_routes_match_oracle(backbone, n, precision):
         assert launches[10] == 2 and launches[11] == 2, launches          # deconv2, deconv3 in Winograd form
         assert launches[5] == 1, launches                                  # merged heads
     if precision == "f16x3" and backbone == "resnet50":
-        assert launches[8] == 0, launches                                  # nothing on the small-launch route
+        assert launches[8] == 1 and launches[0] == 1, launches             # small-launch route: only dense_enc (its grid is the split-K factor x 2 up to 128 inputs); dense_dec batched
         assert launches[9] == 7, launches                                  # all seven bottleneck blocks fused
         assert launches[6] == 5, launches                                  # conv4 + four up1 phases
         assert launches[3] == 5 and launches[4] == 4, launches             # deconv1 + up2's phases; up3's phases
