@@ -126,6 +126,19 @@ P2P_API int p2p_model_precision(const p2p_model* model);
  * largest offending magnitude in *max_abs (0 = none) and clears the flag.  No reference counterpart (TensorFlow computes in fp32). */
 P2P_API int p2p_ctx_range_event(p2p_ctx* ctx, float* max_abs);
 
+/* Form of the 5x5 stride-1 decoder convolutions deconv1 / deconv2 / deconv3 (reference ae_model.py:207-211,217-220,227-230; 67 % of the
+ * generator's multiplications) in P2P_PREC_F16X3 passes of this context.  The Winograd form F(4,5) along the row axis needs 2.5x fewer
+ * matrix-core products; it forms different products than the direct convolution, so the two forms do not give the same bits: both are
+ * held to the same bar against the oracle (network output within 1e-4; measured 3e-5 / 2.6e-5; tests/test_wino_gpu.py), 3e-5 apart.
+ *   P2P_WINOGRAD_AUTO (default)  Winograd form for launches that fill the chip (>= 256 workgroups: deconv3 from 16 inputs per pass,
+ *                                deconv2 from 32, deconv1 from 128), direct form below -- the fastest choice at every batch size; a
+ *                                sample's bits then depend on the SIZE of the batch it travels in (never on its content or position)
+ *   P2P_WINOGRAD_OFF             direct form always   } either way a sample's output bits do not depend on the batch it travels in
+ *   P2P_WINOGRAD_ALWAYS          Winograd form always }
+ * Strict-fp32 objects (P2P_PREC_F32, the twin of P2P_PREC_AUTO) always use the direct form.  No reference counterpart. */
+typedef enum { P2P_WINOGRAD_OFF = 0, P2P_WINOGRAD_AUTO = 1, P2P_WINOGRAD_ALWAYS = 2 } p2p_winograd_mode;
+P2P_API int p2p_ctx_set_winograd(p2p_ctx* ctx, int mode);
+
 /* Replaces `self.generator_train.predict(x)` (reference recognition.py:84,129):
  * x [n,128,128,3] float32 NHWC -> xyz [n,128,128,3] (tanh) and prob [n,128,128,1] (sigmoid).
  * `mem` says whether x/xyz/prob are host or device pointers.  Blocking. */

@@ -209,6 +209,7 @@ def lib():
     L.p2p_model_destroy.restype = None
     L.p2p_model_precision.argtypes = [vp]
     L.p2p_ctx_range_event.argtypes = [vp, C.POINTER(C.c_float)]
+    L.p2p_ctx_set_winograd.argtypes = [vp, ci]
     L.p2p_predict.argtypes = [vp, vp, vp, ci, vp, vp, ci]
     L.p2p_forward_async.argtypes = [vp, vp, vp, ci, vp]
     L.p2p_est_pose_batch.argtypes = [vp, C.POINTER(Object), ci, C.POINTER(Image), ci, C.POINTER(Detection), ci,

@@ -77,6 +77,7 @@ struct Ctx {
     float* xyz_stage = nullptr;
     float* prob_stage = nullptr;
     Pipeline* pipe = nullptr;
+    int wino_mode = P2P_WINOGRAD_AUTO;    // p2p_ctx_set_winograd
     int dev_part = 0;                     // timing builds only (P2P_TIMING_SWITCHES): run a part of the generator pass
     // operand-range guard (kernels.h): device words raised by the epilogues of split-f16 passes.  Word 0: direct forward calls
     // (p2p_predict / p2p_forward_async), words 1.. : one per est_pose batch slot.  range_cur = where the passes being enqueued report.

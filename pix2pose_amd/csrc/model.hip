@@ -829,11 +829,10 @@ static int conv_layer(Ctx& X, const ConvLayer& L, const float* in, int N, int H,
 }
 
 // The 5x5 stride-1 layers of split-f16 models in Winograd form (wino.hip: 2.5x fewer MFMA products) when the launch fills the chip;
-// smaller launches (one detection at a time) keep the direct kernels.  Unlike the other route pairs of this file the two routes do NOT
-// compute the same bits: both sit within the generator's error bar of the oracle (tests/test_wino_gpu.py), 2e-5 apart.
-// Development builds: P2P_NO_WINO=1 keeps the direct route, P2P_WINO_MIN_WGS moves the threshold.
-static bool wino_enabled() { static const bool on = dev_env("P2P_NO_WINO") == nullptr; return on && specialised_kernels(); }
-static int wino_min_wgs() { static const int v = dev_env("P2P_WINO_MIN_WGS") ? atoi(dev_env("P2P_WINO_MIN_WGS")) : 256; return v; }
+// smaller launches (one detection at a time) keep the direct kernels.  Unlike the other route pairs of this file the two forms do NOT
+// compute the same bits: both sit within the generator's error bar of the oracle (tests/test_wino_gpu.py), 3e-5 apart -- so the choice is
+// the caller's (p2p_ctx_set_winograd: off / auto / always), not a development switch.
+constexpr int WINO_MIN_WGS = 256;
 
 static int timed_launch(Ctx& X, int slot, double flops, double bytes, const std::function<hipError_t()>& launch)
 {
@@ -854,7 +853,7 @@ static int timed_launch(Ctx& X, int slot, double flops, double bytes, const std:
 // 0 = not for this route (the caller falls through to the direct kernels), 1 = done, < 0 = error
 static int try_wino(Ctx& X, const ConvLayer& L, const float* a, int Ca, const float* b, int Cb, int cb_stride, int cb_off, int N, int H, float* out)
 {
-    if (!L.wino_u || L.prec != PREC_F16X3 || !wino_enabled() || !wino_supported(H, H, Ca, Cb, L.Cout)) return 0;
+    if (!L.wino_u || L.prec != PREC_F16X3 || X.wino_mode == P2P_WINOGRAD_OFF || !specialised_kernels() || !wino_supported(H, H, Ca, Cb, L.Cout)) return 0;
     WinoParams p;
     memset(&p, 0, sizeof(p));
     p.seg[0] = {a, Ca, Ca, 0};
@@ -870,7 +869,7 @@ static int try_wino(Ctx& X, const ConvLayer& L, const float* a, int Ca, const fl
     p.act = ACT_LEAKY; p.alpha = LEAKY;
     p.out = out; p.out_cstride = L.Cout; p.out_coff = 0;
     p.range_acc = X.range_cur;
-    if (wino_gemm_grid(p) < wino_min_wgs()) return 0;
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && wino_gemm_grid(p) < WINO_MIN_WGS) return 0;
     if (X.grp && X.grp->models.size() > 1) {
         const GroupCtx& G = *X.grp;
         const int ng = (int)G.models.size();
@@ -1477,6 +1476,13 @@ int p2p_ctx_range_event(p2p_ctx* ctx, float* max_abs)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return c->range_read(0, max_abs);
+}
+
+int p2p_ctx_set_winograd(p2p_ctx* ctx, int mode)
+{
+    if (!ctx || mode < P2P_WINOGRAD_OFF || mode > P2P_WINOGRAD_ALWAYS) { set_error("p2p_ctx_set_winograd: bad arguments"); return P2P_ERR_INVALID_ARG; }
+    reinterpret_cast<Ctx*>(ctx)->wino_mode = mode;
+    return P2P_OK;
 }
 
 int p2p_model_precision(const p2p_model* model)

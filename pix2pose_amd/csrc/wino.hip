@@ -10,7 +10,7 @@
 // with the points {0, +-1, +-2, +-1/2, inf}.  The vertical axis stays direct (5 taps): the eight positions j are eight independent
 // GEMMs [(y, t) x (ky, c)] x [(ky, c) x co] -- 2.5x fewer MFMA products than the direct form.  Arithmetic: the transforms in fp32, the
 // 22-bit hi/lo f16 split AFTER the transform (both operands), three products per block, fp32 accumulation, fp32 inverse transform.
-// oracle/wino_study.py is the error study behind the choice (network output 3.2e-5 from the fp64 graph; the direct form 7.5e-6; the 2-D
+// profiles/r06_wino_error_study.json is the error study behind the choice (network output 3.2e-5 from the fp64 graph; the direct form 7.5e-6; the 2-D
 // forms F(2x2,5x5) / F(4x4,5x5) 5.6e-5 / 9.9e-5 -- and their 36 / 64 accumulator sets per tile cannot be fused).
 //
 // Two kernels:

@@ -12,11 +12,20 @@ from . import weights as W
 class Context:
     """One GPU's pipeline context (stream + workspaces).  Not thread-safe (p2p_mi355.h)."""
 
-    def __init__(self, device: int = 0, max_batch: int = 256):
+    WINOGRAD = {"off": 0, "auto": 1, "always": 2}
+
+    def __init__(self, device: int = 0, max_batch: int = 256, winograd: str = "auto"):
         self._h = C.c_void_p()
         _lib.check(_lib.lib().p2p_ctx_create(device, max_batch, C.byref(self._h)), "p2p_ctx_create")
         self.device = device
         self.max_batch = max_batch
+        if winograd != "auto":
+            self.set_winograd(winograd)
+
+    def set_winograd(self, mode: str):
+        """Form of the 5x5 stride-1 decoder layers in split-f16 passes (p2p_ctx_set_winograd): "auto" (default) = Winograd F(4,5) for launches
+        that fill the chip, direct below -- fastest, a sample's bits depend on the batch SIZE; "off" / "always" = one form at every size."""
+        _lib.check(_lib.lib().p2p_ctx_set_winograd(self._h, self.WINOGRAD[mode]), "p2p_ctx_set_winograd")
 
     @property
     def handle(self):

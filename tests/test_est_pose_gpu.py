@@ -21,7 +21,7 @@ TH_I = 0.2
 @pytest.fixture(scope="module")
 def rig():
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec
-    ctx = Context(0, max_batch=64)
+    ctx = Context(0, max_batch=64, winograd="off")      # bit-identity tests across batch compositions below: one form of the 5x5 layers at every size
     gen = Generator(W.synthetic_weights("paper", 1), "paper", ctx)
     spec = ObjectSpec(gen, synth.OBJ_PARAM, TH_O, TH_I)
     return ctx, gen, spec

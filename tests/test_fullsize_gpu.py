@@ -22,9 +22,9 @@ def test_generator_batch64_chunking_and_device_pointers():
     from pix2pose_amd.runtime import Context, Generator
     w = W.synthetic_weights("resnet50", 1)
     x = (np.random.RandomState(1).randint(0, 256, (64, 128, 128, 3)).astype(np.float32) - 128) / 128
-    big = Generator(w, "resnet50", Context(0, max_batch=64))
+    big = Generator(w, "resnet50", Context(0, max_batch=64, winograd="off"))      # one form of the 5x5 layers at every pass size: bits do not depend on the chunking
     d64, p64 = big.predict(x)
-    small = Generator(w, "resnet50", Context(0, max_batch=24))       # 64 = 24 + 24 + 16
+    small = Generator(w, "resnet50", Context(0, max_batch=24, winograd="off"))       # 64 = 24 + 24 + 16
     d24, p24 = small.predict(x)
     np.testing.assert_array_equal(d64, d24)
     np.testing.assert_array_equal(p64, p24)
@@ -44,7 +44,7 @@ def test_est_pose_256_detections_invariants():
     import torch
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
     ctx = Context(0, max_batch=256)
-    gen = Generator(W.synthetic_weights("resnet50", 1), "resnet50", ctx)
+    gen = Generator(W.synthetic_weights("resnet50", 1), "resnet50", ctx)       # (decoder maps injected: the generator's form of the 5x5 layers does not reach the poses)
     spec = ObjectSpec(gen, S.OBJ_PARAM, TH_O, TH_I)
     sc = S.make_scene(256, seed=5)
     j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()

@@ -26,7 +26,7 @@ out, ns, trained_like = sys.argv[1], [int(v) for v in sys.argv[2].split(",")], s
 x = (np.random.RandomState(5).randint(0, 256, (max(ns), 128, 128, 3)).astype(np.float32) - 128) / 128
 x[1] *= 30.0                        # one sample far outside [-1, 1]
 w = W.trained_like_weights("resnet50", 3) if trained_like else W.synthetic_weights("resnet50", 3)
-g = Generator(w, "resnet50", Context(0, max_batch=max(ns)))
+g = Generator(w, "resnet50", Context(0, max_batch=max(ns), winograd="off"))
 r = {}
 for n in ns:
     dec, prob = g.predict(x[:n])
@@ -66,7 +66,7 @@ def test_fused_block_in_a_mixed_object_pass():
     from pix2pose_amd import synthetic as S
     from pix2pose_amd import weights as W
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
-    ctx = Context(0, max_batch=256)
+    ctx = Context(0, max_batch=256, winograd="off")
     specs = [ObjectSpec(Generator(W.synthetic_weights("resnet50", 10 + k), "resnet50", ctx), S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2) for k in range(3)]
     sc = S.make_scene(48, seed=3)
     dets = [(d[0], i % 3, d[2], d[3]) for i, d in enumerate(sc["dets"])]

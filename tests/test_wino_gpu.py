@@ -6,52 +6,35 @@ Unlike the other route pairs of the library the two forms do NOT compute the sam
 ORACLE: network output within 1e-4 abs (north_star: 1e-3) on either route, both backbones, freshly-initialised and trained-like weight
 statistics -- and the two routes within 6e-5 of each other (oracle/wino_study.py predicts 3.2e-5 from fp64 for this form).
 
-The shipped library takes the Winograd route when a layer's launch has >= 256 workgroups (deconv3 from 16 inputs, deconv2 from 32, deconv1
-from 128); the development twin's P2P_WINO_MIN_WGS / P2P_NO_WINO move that, which is how 3 and 5 inputs (odd: the two-samples-per-workgroup
-form of the 16x16 layer with a missing partner) reach the kernels here next to an oracle that takes a second per input."""
-import os
-import subprocess
-import sys
-
+The form is the caller's choice (p2p_ctx_set_winograd / Context(winograd=...)): "auto" (default) takes the Winograd route when a layer's
+launch has >= 256 workgroups (deconv3 from 16 inputs, deconv2 from 32, deconv1 from 128); "always" / "off" pin one form at every size, which
+is how 3 and 5 inputs (odd: the two-samples-per-workgroup form of the 16x16 layer with a missing partner) reach the kernels here next to an
+oracle that takes a second per input."""
 import numpy as np
 import pytest
 
-from pix2pose_amd.build import dev_switches
-
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 XYZ_TOL = 1e-4
 ROUTE_TOL = 6e-5
 
-_SCRIPT = r"""
-import sys, numpy as np
-sys.path.insert(0, %r)
-from pix2pose_amd import weights as W
-from pix2pose_amd.runtime import Context, Generator
-out, backbone, fam, ns = sys.argv[1], sys.argv[2], sys.argv[3], [int(v) for v in sys.argv[4].split(",")]
-x = (np.random.RandomState(11).randint(0, 256, (max(ns), 128, 128, 3)).astype(np.float32) - 128) / 128
-w = W.trained_like_weights(backbone, 5) if fam == "trained_like" else W.synthetic_weights(backbone, 3)
-ctx = Context(0, max_batch=max(ns))
-g = Generator(w, backbone, ctx)
-r = {}
-for n in ns:
-    ctx.profile(True)
-    dec, prob = g.predict(x[:n])
-    st = ctx.profile_read()
-    ctx.profile(False)
-    r["dec%%d" %% n], r["prob%%d" %% n] = dec, prob
-    r["launches%%d" %% n] = np.array([s["launches"] for s in st])
-np.savez(out, **r)
-""" % ROOT
 
-
-def _run(tmp_path, tag, backbone, fam, ns, env_extra):
-    out = str(tmp_path / ("%s.npz" % tag))
-    env = dict(os.environ)
-    env.update(env_extra)
-    subprocess.run([sys.executable, "-c", _SCRIPT, out, backbone, fam, ",".join(map(str, ns))], check=True, env=env, cwd=ROOT, timeout=900)
-    return np.load(out)
+def _run(backbone, fam, ns, winograd):
+    from pix2pose_amd import weights as W
+    from pix2pose_amd.runtime import Context, Generator
+    x = _inputs(max(ns))
+    w = W.trained_like_weights(backbone, 5) if fam == "trained_like" else W.synthetic_weights(backbone, 3)
+    ctx = Context(0, max_batch=max(ns), winograd=winograd)
+    g = Generator(w, backbone, ctx)
+    r = {}
+    for n in ns:
+        ctx.profile(True)
+        dec, prob = g.predict(x[:n])
+        st = ctx.profile_read()
+        ctx.profile(False)
+        r["dec%d" % n], r["prob%d" % n] = dec, prob
+        r["launches%d" % n] = np.array([s["launches"] for s in st])
+    return r
 
 
 def _inputs(n):
@@ -60,12 +43,12 @@ def _inputs(n):
 
 @pytest.mark.parametrize("fam", ["synthetic", "trained_like"])
 @pytest.mark.parametrize("backbone", ["resnet50", "paper"])
-def test_winograd_route_matches_oracle_and_direct_route(tmp_path, backbone, fam):
+def test_winograd_route_matches_oracle_and_direct_route(backbone, fam):
     from oracle import ae_oracle as O
     from pix2pose_amd import weights as W
     ns = [3, 5]
-    a = _run(tmp_path, "wino", backbone, fam, ns, dev_switches(P2P_WINO_MIN_WGS=1, P2P_STREAM_WGS=0))
-    b = _run(tmp_path, "direct", backbone, fam, ns, dev_switches(P2P_NO_WINO=1, P2P_STREAM_WGS=0))
+    a = _run(backbone, fam, ns, "always")
+    b = _run(backbone, fam, ns, "off")
     w = W.trained_like_weights(backbone, 5) if fam == "trained_like" else W.synthetic_weights(backbone, 3)
     d0, p0 = O.forward(w, _inputs(5), backbone)
     for n in ns:
@@ -116,37 +99,27 @@ def test_batched_routes_match_oracle(backbone, n, precision):
     assert e < XYZ_TOL
 
 
-_MIXED = r"""
-import sys
-sys.path.insert(0, %r)
-from pix2pose_amd import synthetic as S
-from pix2pose_amd import weights as W
-from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
-ctx = Context(0, max_batch=256)
-specs = [ObjectSpec(Generator(W.synthetic_weights("resnet50", 10 + k), "resnet50", ctx), S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2) for k in range(3)]
-sc = S.make_scene(48, seed=3)
-dets = [(d[0], i %% 3, d[2], d[3]) for i, d in enumerate(sc["dets"])]
-ctx.profile(True)
-mixed = est_pose_batch(ctx, specs, list(sc["images"]), dets)[0]
-st = ctx.profile_read()
-assert st[10]["launches"] >= 3 and st[10]["launches"] == st[11]["launches"], [s["launches"] for s in st]
-for k in range(3):
-    idx = [i for i in range(48) if i %% 3 == k]
-    alone = est_pose_batch(ctx, specs, list(sc["images"]), [dets[i] for i in idx])[0]
-    for i, q in zip(idx, alone):
-        p = mixed[i]
-        assert (p.status, p.n_inliers, p.n_init_mask, tuple(p.bbox_t), tuple(p.R), tuple(p.t)) == \
-               (q.status, q.n_inliers, q.n_init_mask, tuple(q.bbox_t), tuple(q.R), tuple(q.t)), i
-print("mixed == alone")
-""" % ROOT
-
-
 def test_winograd_route_in_a_mixed_object_pass():
     """Grouped generator passes (BASELINE.json configs[3]: detections of several objects in one batch, every workgroup of the Winograd
     kernels looks its sample's panel up; the two samples of a 16x16-layer workgroup belong to one object): 3 objects x 16 detections through
-    est_pose_batch == the same detections object by object, bit for bit -- with the route pinned (P2P_WINO_MIN_WGS=1: all three layers in
+    est_pose_batch == the same detections object by object, bit for bit -- with the form pinned (winograd="always": all three layers in
     Winograd form whatever the batch size), a sample's bits do not depend on the batch it travels in."""
-    env = dict(os.environ)
-    env.update(dev_switches(P2P_WINO_MIN_WGS=1))
-    r = subprocess.run([sys.executable, "-c", _MIXED], env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
-    assert r.returncode == 0 and "mixed == alone" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    from pix2pose_amd import synthetic as S
+    from pix2pose_amd import weights as W
+    from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
+    ctx = Context(0, max_batch=256, winograd="always")
+    specs = [ObjectSpec(Generator(W.synthetic_weights("resnet50", 10 + k), "resnet50", ctx), S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2) for k in range(3)]
+    sc = S.make_scene(48, seed=3)
+    dets = [(d[0], i % 3, d[2], d[3]) for i, d in enumerate(sc["dets"])]
+    ctx.profile(True)
+    mixed = est_pose_batch(ctx, specs, list(sc["images"]), dets)[0]
+    st = ctx.profile_read()
+    ctx.profile(False)
+    assert st[10]["launches"] >= 3 and st[10]["launches"] == st[11]["launches"], [s["launches"] for s in st]
+    for k in range(3):
+        idx = [i for i in range(48) if i % 3 == k]
+        alone = est_pose_batch(ctx, specs, list(sc["images"]), [dets[i] for i in idx])[0]
+        for i, q in zip(idx, alone):
+            p = mixed[i]
+            assert (p.status, p.n_inliers, p.n_init_mask, tuple(p.bbox_t), tuple(p.R), tuple(p.t)) == \
+                   (q.status, q.n_inliers, q.n_init_mask, tuple(q.bbox_t), tuple(q.R), tuple(q.t)), i
