@@ -388,7 +388,10 @@ def main():
         all_ms = sum(s["total_ms"] for s in stats)
         # peak in the same unit as `achieved` (ALGORITHMIC FLOPs): the f16x3 arithmetic spends three dense-f16 MFMA products per
         # algorithmic MAC, so its ceiling is the dense f16 peak / 3; the fp32 mode is priced against the fp32-MFMA peak
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+        # The Winograd form of the 5x5 layers (profile slot 10) forms 10 products where the direct form has 25: 3 x 10 / 25 = 1.2 MFMA FLOPs
+        # per algorithmic FLOP (algo_flops stays the DIRECT form's 2 x MACs of the layer)
+        mfma_per_algo = (1.2 if dom == 10 else 3.0) if precision == "f16x3" else 1.0
+        peak = PEAK_F16_MFMA_TFLOPS / mfma_per_algo if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         r = {"bound": "mfma", "kernel": "%s: %s" % (dom_name, dom_label),
              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
              "frac_algorithmic": ach / (PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS),
@@ -396,13 +399,14 @@ def main():
              # what the chip sustains when it does NOTHING but these MFMAs on operands distributed like the split's (data-dependent power: all-zero
              # operands run at 2231): the ceiling any kernel shape is under, measured with tools/mfma_f16_wall.hip
              "measured_mfma_power_wall_tflops": POWER_WALL_F16X3_TFLOPS if precision == "f16x3" else None,
-             "frac_of_measured_power_wall": (3 * ach / POWER_WALL_F16X3_TFLOPS) if precision == "f16x3" else None,
-             "mfma_flops_per_algorithmic_flop": 3 if precision == "f16x3" else 1,
-             "note": ("achieved = algorithmic FLOPs (2 x MACs of the layers) / launch time.  frac = utilisation of the f16 matrix pipe: the split-f16 "
-                      "arithmetic (fp32-equivalent results) issues 3 MFMA products per algorithmic MAC, so peak = 2500 / 3 and the pipe sustains "
-                      "%.0f of its 2500 TFLOP/s.  frac_algorithmic = achieved / 2500 (no credit for the emulation overhead).  The power-limited "
-                      "ceiling of dense f16 MFMA on random operands is ~1330 TFLOP/s (cdna_hip_programming.md 5.4 rule 25); the kernel "
-                      "delivers %.2fx the fp32-MFMA peak (157.3)" % (3 * ach, ach / PEAK_F32_MFMA_TFLOPS))
+             "frac_of_measured_power_wall": (mfma_per_algo * ach / POWER_WALL_F16X3_TFLOPS) if precision == "f16x3" else None,
+             "mfma_flops_per_algorithmic_flop": mfma_per_algo,
+             "note": ("achieved = algorithmic FLOPs (2 x MACs of the layers in their DIRECT form) / launch time.  frac = utilisation of the f16 matrix "
+                      "pipe: the split-f16 arithmetic (fp32-equivalent results) issues 3 MFMA products per MAC it forms%s, so peak = 2500 / %.1f and the "
+                      "pipe sustains %.0f of its 2500 TFLOP/s.  frac_algorithmic = achieved / 2500 (no credit for the emulation overhead).  The "
+                      "power-limited ceiling of dense f16 MFMA on random operands is ~1330 TFLOP/s (cdna_hip_programming.md 5.4 rule 25); the kernel "
+                      "delivers %.2fx the fp32-MFMA peak (157.3)" % (", and the Winograd form F(4,5) forms 10 MACs where the direct 5x5 row has 25" if dom == 10 else "",
+                                                                    mfma_per_algo, mfma_per_algo * ach, ach / PEAK_F32_MFMA_TFLOPS))
                      if precision == "f16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s",
              "avg_launch_ms": s0["total_ms"] / max(s0["launches"], 1), "launches": s0["launches"],
              "algo_gflop_per_launch": s0["algo_flops"] / max(s0["launches"], 1) / 1e9,
@@ -420,6 +424,7 @@ def main():
         out = []
         for i, label in ((5, "decoder output heads"), (9, "ResNet identity bottleneck blocks, fused: 1x1 -> 3x3 -> 1x1 + residual in one launch (block input read once + "
                                                           "its 3x3 halo, output written once; the three-launch route moved 2x these bytes)"),
+                         (11, "input transform of the Winograd layers (x read once, the split-f16 V -- two positions per input column, 8 bytes per element -- written once)"),
                          (0, "1x1 layers of the projection blocks res2a / res3a (+ dense_dec)"), (1, "Cout = 64 1x1 layers (res2a 2a)")):
             st = stats[i]
             if not st["launches"] or st["total_ms"] <= 0:

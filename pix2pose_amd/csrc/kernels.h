@@ -164,7 +164,7 @@ struct WinoGroup {
     const float* scale;
     const float* shift;
     int sample0;
-    int pad_;
+    int unit0;             // 16x16 grids (two samples per workgroup): first pair of the group -- pairs never straddle two objects
 };
 struct WinoParams {
     IgemmSeg seg[2];       // input: channels [coff, coff + C) of two NHWC tensors on the same H x W grid

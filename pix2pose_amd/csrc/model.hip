@@ -869,20 +869,21 @@ static int try_wino(Ctx& X, const ConvLayer& L, const float* a, int Ca, const fl
     p.act = ACT_LEAKY; p.alpha = LEAKY;
     p.out = out; p.out_cstride = L.Cout; p.out_coff = 0;
     p.range_acc = X.range_cur;
-    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && wino_gemm_grid(p) < WINO_MIN_WGS) return 0;
     if (X.grp && X.grp->models.size() > 1) {
         const GroupCtx& G = *X.grp;
         const int ng = (int)G.models.size();
-        if (ng > IGEMM_MAX_GROUPS) return 0;
+        if (ng > IGEMM_MAX_GROUPS) { set_error("run_conv: %d object groups exceed IGEMM_MAX_GROUPS", ng); return P2P_ERR_CAPACITY; }
+        int unit0 = 0;                  // 16x16 grids: two samples per workgroup, every object paired up on its own
         for (int g = 0; g < ng; ++g) {
             const ConvLayer& Lg = G.models[g]->L.at(L.name);
-            if (!Lg.wino_u || Lg.prec != PREC_F16X3) return 0;
-            if (H == 16 && (G.start[g] & 1)) return 0;                  // two samples per workgroup: a pair must not straddle two objects
-            p.grp[g] = {Lg.wino_u, Lg.wino_scale, Lg.shift, G.start[g], 0};
+            if (!Lg.wino_u || Lg.prec != PREC_F16X3) { set_error("run_conv: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
+            p.grp[g] = {Lg.wino_u, Lg.wino_scale, Lg.shift, G.start[g], unit0};
+            unit0 += (G.start[g + 1] - G.start[g] + 1) / 2;
         }
-        p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng], 0};
+        p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng], unit0};
         p.n_groups = ng;
     }
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && wino_gemm_grid(p) < WINO_MIN_WGS) return 0;
     hipStream_t st = X.cur->stream;
     const double in_el = (double)px * p.Cin, out_el = (double)px * L.Cout;
     int rc = timed_launch(X, 11, 0.0, 4.0 * in_el + 8.0 * in_el, [&]() { return launch_wino_input(p, st); });

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
     const int PC = p.W >> 4;
     const int RB = DUAL ? 1 : p.H >> 5;
     const int NT = p.Cout >> 6;
-    const int units = DUAL ? (p.N + 1) >> 1 : p.N;
+    const int units = DUAL ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) >> 1) : p.N;
     const int ntiles = units * PC * RB * NT;
     const unsigned slice_bytes = 32u * (unsigned)p.H * 64u;
     const size_t unit_block = (size_t)S * slice_bytes;           // bytes of one (sample, patch column)
@@ -160,18 +160,25 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
     const int rb = rest % RB; rest /= RB;
     const int pc = rest % PC;
     const int unit = rest / PC;
-    const int n0 = DUAL ? unit * 2 : unit;
-    const bool has_b = DUAL && n0 + 1 < p.N;
+    int n0 = DUAL ? unit * 2 : unit;
+    int n_end = p.N;                                 // first sample that is not this object's
     const int y0 = rb * 32;
 
     const float* gu = p.U;
     const float* gscale = p.scale;
     const float* gshift = p.shift;
-    if (p.n_groups > 1) {                            // groups are runs of samples (DUAL: group starts are even, the host checks)
+    if (p.n_groups > 1) {                            // groups are runs of samples; DUAL: every group is paired up on its own (unit0)
         int g = 0;
-        while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= n0) ++g;
+        if (DUAL) {
+            while (g + 1 < p.n_groups && p.grp[g + 1].unit0 <= unit) ++g;
+            n0 = p.grp[g].sample0 + 2 * (unit - p.grp[g].unit0);
+            n_end = p.grp[g + 1].sample0;
+        } else {
+            while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= n0) ++g;
+        }
         gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
     }
+    const bool has_b = DUAL && n0 + 1 < n_end;
 
     // ---- V: global -> registers -> LDS, this wave's four planes only, in 1 KB pieces (16 rows x 4 tiles of one plane per wave-instruction).
     //      Single: piece q < 8 = rows [16 (q & 1), +16) of plane q >> 1; piece 8 = the last four rows of all four planes (16 lanes each).
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
         int n, y;
         if (DUAL) { n = n0 + (i >> 1); y = (i & 1) * 8 + (pair >> 2); }
         else { n = n0; y = y0 + i * 8 + (pair >> 2); }
-        if (!DUAL || n < p.N) {
+        if (!DUAL || n == n0 || has_b) {
             const size_t pix = ((size_t)n * p.H + y) * p.W + pc * 16 + (pair & 3) * 4;
             float* o = p.out + pix * p.out_cstride + p.out_coff + col;
             f32x4 yv[4];
@@ -396,7 +403,8 @@ size_t wino_v_bytes(int N, int H, int W, int Cin) { return (size_t)N * H * W * C
 int wino_gemm_grid(const WinoParams& p)
 {
     const bool dual = p.H == 16;
-    return (dual ? (p.N + 1) / 2 : p.N * (p.H / 32)) * (p.W / 16) * (p.Cout / 64);
+    const int units = dual ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) / 2) : p.N * (p.H / 32);
+    return units * (p.W / 16) * (p.Cout / 64);
 }
 
 hipError_t launch_wino_input(const WinoParams& p, hipStream_t s)

@@ -108,7 +108,9 @@ def test_configs3_share_30_objects_256_detections():
     import torch
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
     n_obj, n_det = 30, 256
-    ctx = Context(0, max_batch=1024)
+    # (c) compares a 256-input pass with 8-9-input passes bit for bit: the form of the 5x5 decoder layers must not depend on the pass size --
+    # "always" = Winograd form throughout (objects with odd detection counts: the two-samples-per-workgroup layer pairs every object up on its own)
+    ctx = Context(0, max_batch=1024, winograd="always")
     params = [S.OBJ_PARAM * (1.0 + 0.02 * k) for k in range(n_obj)]
     specs = [ObjectSpec(Generator(W.synthetic_weights("resnet50", 100 + k), "resnet50", ctx), params[k], TH_O, TH_I) for k in range(n_obj)]
     sc = S.make_scene(n_det, seed=31)

@@ -1,4 +1,5 @@
-"""Generator forward passes only: wall time per pass and the per-family kernel times of p2p_profile_read:  python tools/time_pass.py [n_inputs] [reps] [backbone]"""
+"""Generator forward passes only: wall time per pass and the per-family kernel times of p2p_profile_read:
+    python tools/time_pass.py [n_inputs] [reps] [backbone] [winograd: auto|off|always]"""
 import os
 import sys
 import time
@@ -12,7 +13,7 @@ from pix2pose_amd.runtime import Context, Generator
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 bb = sys.argv[3] if len(sys.argv) > 3 else "resnet50"
-ctx = Context(0, max_batch=n)
+ctx = Context(0, max_batch=n, winograd=sys.argv[4] if len(sys.argv) > 4 else "auto")
 g = Generator(W.synthetic_weights(bb, 1), bb, ctx)
 x = (torch.randint(0, 256, (n, 128, 128, 3), device="cuda").float() - 128) / 128
 y = torch.empty(n, 128, 128, 4, device="cuda")
