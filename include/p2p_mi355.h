@@ -130,9 +130,9 @@ P2P_API int p2p_ctx_range_event(p2p_ctx* ctx, float* max_abs);
  * generator's multiplications) in P2P_PREC_F16X3 passes of this context.  The Winograd form F(4,5) along the row axis needs 2.5x fewer
  * matrix-core products; it forms different products than the direct convolution, so the two forms do not give the same bits: both are
  * held to the same bar against the oracle (network output within 1e-4; measured 3e-5 / 2.6e-5; tests/test_wino_gpu.py), 3e-5 apart.
- *   P2P_WINOGRAD_AUTO (default)  Winograd form for launches that fill the chip (>= 256 workgroups: deconv3 from 16 inputs per pass,
- *                                deconv2 from 32, deconv1 from 128), direct form below -- the fastest choice at every batch size; a
- *                                sample's bits then depend on the SIZE of the batch it travels in (never on its content or position)
+ *   P2P_WINOGRAD_AUTO (default)  Winograd form for passes of two or more inputs, direct form for one-input passes (the stage-1 pass of a
+ *                                single est_pose call: 5 % faster there) -- the fastest choice at every batch size; a sample's bits then
+ *                                depend on whether it travels ALONE (never on the content, size or order of a batch of two or more)
  *   P2P_WINOGRAD_OFF             direct form always   } either way a sample's output bits do not depend on the batch it travels in
  *   P2P_WINOGRAD_ALWAYS          Winograd form always }
  * Strict-fp32 objects (P2P_PREC_F32, the twin of P2P_PREC_AUTO) always use the direct form.  No reference counterpart. */

@@ -828,11 +828,13 @@ static int conv_layer(Ctx& X, const ConvLayer& L, const float* in, int N, int H,
     return run_conv(X, L, c);
 }
 
-// The 5x5 stride-1 layers of split-f16 models in Winograd form (wino.hip: 2.5x fewer MFMA products) when the launch fills the chip;
-// smaller launches (one detection at a time) keep the direct kernels.  Unlike the other route pairs of this file the two forms do NOT
-// compute the same bits: both sit within the generator's error bar of the oracle (tests/test_wino_gpu.py), 3e-5 apart -- so the choice is
-// the caller's (p2p_ctx_set_winograd: off / auto / always), not a development switch.
-constexpr int WINO_MIN_WGS = 256;
+// The 5x5 stride-1 layers of split-f16 models in Winograd form (wino.hip: 2.5x fewer MFMA products).  Measured per generator pass
+// (profiles/r06_wino_small_batches.txt): faster than the direct kernels from 3 inputs up (703 vs 772 us; 8: 841 vs 971; 64: 2100 vs 2613;
+// 256: 5490 vs 7740), 5 % slower at ONE input (651 vs 622 us: three launches of 4-16 workgroups walking their whole K range) -- so "auto"
+// keeps the direct kernels for one-input passes only.  Unlike the other route pairs of this file the two forms do NOT compute the same
+// bits: both sit within the generator's error bar of the oracle (tests/test_wino_gpu.py), 3e-5 apart -- so the choice is the caller's
+// (p2p_ctx_set_winograd: off / auto / always), not a development switch.
+constexpr int WINO_MIN_INPUTS = 2;
 
 static int timed_launch(Ctx& X, int slot, double flops, double bytes, const std::function<hipError_t()>& launch)
 {
@@ -883,7 +885,7 @@ static int try_wino(Ctx& X, const ConvLayer& L, const float* a, int Ca, const fl
         p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng], unit0};
         p.n_groups = ng;
     }
-    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && wino_gemm_grid(p) < WINO_MIN_WGS) return 0;
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < WINO_MIN_INPUTS) return 0;
     hipStream_t st = X.cur->stream;
     const double in_el = (double)px * p.Cin, out_el = (double)px * L.Cout;
     int rc = timed_launch(X, 11, 0.0, 4.0 * in_el + 8.0 * in_el, [&]() { return launch_wino_input(p, st); });
