@@ -259,7 +259,10 @@ typedef struct {
      * (recognition.py:82,103,121,134,144,146) and does not pin scikit-image (requirements.txt does not list it):
      * Values outside 0 .. 2 are refused (P2P_ERR_INVALID_ARG).
      *   0 (default): scikit-image <= 0.14 -- plain bilinear warp, every image warped in double (the 0.14 _warp_fast takes doubles only).
-     *      Restated from the published semantics; no such version exists in the build image, so this mode is NOT pinned to a real library.
+     *      PINNED to the real library's float64 warp: no 0.14 wheel exists in the build image, but what 0.14 runs for order=1 -- _warp_fast in
+     *      double, the reflect / constant border modes, clip -- is what the real 0.18.3 runs for resize(image.astype(float64),
+     *      anti_aliasing=False); tests/golden/reference_est_pose_skimage014.json is the reference's est_pose with that on all six call
+     *      sites (masks, uint8 images, boxes, poses identical).  Restated: that 0.14 converts every image to double before the warp.
      *   1: scikit-image 0.17 - 0.18, PINNED bit for bit to the real 0.18.3 (+ scipy 1.7.1) of the build image's /opt/conda/bin/python3.9
      *      (tests/golden/external_vectors.json: resize itself; tests/golden/reference_est_pose_skimage018.json: the reference's est_pose
      *      with the real library on all six call sites -- masks, uint8 images, boxes identical):
@@ -284,6 +287,8 @@ typedef struct {
      *      the image as passed and the real scikit-image 0.18.3 float64 warp -- filter (bool path included) and warp pinned, their order and the
      *      double conversion restated from the 0.15 / 0.16 sources.  The Gaussian weights are built with libm's exp like numpy <= 1.18 (the
      *      reference's era); numpy >= 1.19 uses a SIMD exp 1 ulp apart on some arguments, which the bool filter can amplify into a whole mask.
+     *      So against a caller's scipy this generation is bit-exact only for crop sides whose weights agree between the two exp
+     *      implementations (the parity tests skip the others; p2p_aa_weights() returns the library's weights of a side for comparison).
      * (scikit-image >= 0.19 rejects the bool array of recognition.py:103, so the reference does not run there.)
      * clip=True of resize (output clamped to the input's range, cval preserved) is common to all versions and always on. */
     int resize_anti_aliasing;

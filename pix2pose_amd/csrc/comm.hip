@@ -120,20 +120,36 @@ int comm_gather(Ctx& X, Comm& C, Slot* s, bool range_event, hipStream_t ts, int 
     (void)X;
     if (C.stream) ts = C.stream;
     const size_t rec = sizeof(p2p_pose), per = (size_t)n_max * rec;
+    // The receive side must exist to join at all: an allocation failure HERE (first step, or a larger n_max than before) is the one error that
+    // cannot be reported through the collective.  Everything after it is: a local failure is recorded, this rank still enters ncclAllGather
+    // with padding records, and the error is returned after the collective -- the peers are never left waiting.
     if ((rc = C.send.reserve(per)) || (rc = C.recv.reserve(per * C.world)) || (rc = C.h_recv.reserve(per * C.world))) return rc;
-    if (!C.landed) HIP_TRY(hipEventCreateWithFlags(&C.landed, hipEventDisableTiming));
-    HIP_TRY(hipMemsetAsync(C.send.p, 0xFF, per, ts));                    // padding records: status = -1 (P2P_POSE_ABSENT)
-    if (s && s->n > 0) {
-        hipLaunchKernelGGL(gather_pack_kernel, dim3((s->n + 255) / 256), dim3(256), 0, ts, s->det.as<DetInfo>(), s->poses.as<p2p_pose>(), s->n, C.send.as<p2p_pose>(),
-                           range_event ? (int)P2P_POSE_RANGE : 0, s->opt.det_mask ? s->mstat.as<unsigned long long>() : nullptr);
-        HIP_TRY(hipGetLastError());
+    int local = P2P_OK;
+    char local_msg[256] = "";
+    auto fail = [&](const char* what, hipError_t e) {
+        if (local == P2P_OK) { local = P2P_ERR_HIP; snprintf(local_msg, sizeof(local_msg), "comm_gather: %s failed: %s (this rank joined the collective with padding records)", what, hipGetErrorString(e)); }
+    };
+    hipError_t e;
+    if (!C.landed && (e = hipEventCreateWithFlags(&C.landed, hipEventDisableTiming)) != hipSuccess) { C.landed = nullptr; fail("hipEventCreate", e); }
+    if ((e = hipMemsetAsync(C.send.p, 0xFF, per, ts)) != hipSuccess) fail("hipMemsetAsync", e);      // padding records: status = -1 (P2P_POSE_ABSENT)
+    static const bool inject = dev_env("P2P_COMM_INJECT_PACK_FAILURE") != nullptr;                     // development builds: tests/test_comm_gpu.py
+    if (local == P2P_OK && s && s->n > 0) {
+        if (inject) fail("gather_pack_kernel (injected)", hipErrorLaunchFailure);
+        else {
+            hipLaunchKernelGGL(gather_pack_kernel, dim3((s->n + 255) / 256), dim3(256), 0, ts, s->det.as<DetInfo>(), s->poses.as<p2p_pose>(), s->n, C.send.as<p2p_pose>(),
+                               range_event ? (int)P2P_POSE_RANGE : 0, s->opt.det_mask ? s->mstat.as<unsigned long long>() : nullptr);
+            if ((e = hipGetLastError()) != hipSuccess) { fail("gather_pack_kernel", e); (void)hipMemsetAsync(C.send.p, 0xFF, per, ts); }
+        }
     }
     const ncclResult_t r = C.lib->all_gather(C.send.p, C.recv.p, per, ncclChar, C.comm, ts);
     if (r != ncclSuccess) { set_error("ncclAllGather failed: %s", C.lib->error_string(r)); return P2P_ERR_HIP; }
     HIP_TRY(hipMemcpyAsync(C.h_recv.p, C.recv.p, per * C.world, hipMemcpyDeviceToHost, ts));
-    HIP_TRY(hipEventRecord(C.landed, ts));
-    HIP_TRY(hipEventSynchronize(C.landed));
+    if (C.landed) {
+        HIP_TRY(hipEventRecord(C.landed, ts));
+        HIP_TRY(hipEventSynchronize(C.landed));
+    } else HIP_TRY(hipStreamSynchronize(ts));
     memcpy(gathered, C.h_recv.p, per * C.world);
+    if (local != P2P_OK) { set_error("%s", local_msg); return local; }
     return P2P_OK;
 }
 

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             const int hy = hp / HPX, hx = hp - hy * HPX;
             const int iy = y0 - 1 + hy, ix = x0 - HX0 + hx;
             const bool ok = hp < NPA && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            x_off[j] = ok ? (unsigned)((((n * p.H * STRIDE + iy * STRIDE) * (p.W * STRIDE) + ix * STRIDE) * CIN + q * 4) * 4) : OOB;
+            x_off[j] = ok ? ((((unsigned)(n * p.H * STRIDE + iy * STRIDE) * (unsigned)(p.W * STRIDE) + (unsigned)(ix * STRIDE)) * (unsigned)CIN + (unsigned)(q * 4)) * 4u) : OOB;      // unsigned from the pixel index on: tensors up to 4 GB
             x_dst[j] = hp * REC + q * 8;
         }
         unsigned wa_off[F1 / 32];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             const int idx = tid + 256 * j;
             const int t8 = idx >> 3, q = idx & 7;
             const int px = (t8 & ~7) | ((t8 & 1) << 2) | ((t8 >> 1) & 3);
-            xc_off[j] = (unsigned)((((n * p.H * STRIDE + (y0 + (px >> 4)) * STRIDE) * (p.W * STRIDE) + (x0 + (px & 15)) * STRIDE) * CIN + q * 4) * 4);
+            xc_off[j] = (((unsigned)(n * p.H * STRIDE + (y0 + (px >> 4)) * STRIDE) * (unsigned)(p.W * STRIDE) + (unsigned)((x0 + (px & 15)) * STRIDE)) * (unsigned)CIN + (unsigned)(q * 4)) * 4u;
             xc_dst[j] = px * REC + q * 8;
         }
         f32x4 rxc[XP];

@@ -269,6 +269,8 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
         per_image = {}
         for k, (ti, r_id) in enumerate(owners):
             p = recs[k]
+            if int(p["status"]) == -2:                                        # _lib.POSE_RANGE: the producing rank's batch left the split-f16 operand range
+                range_events.append(tuple(chunk[ti][:2]))                     # (every rank sees the same gathered records: all of them raise at the end)
             if int(p["status"]) != 0:                                         # frac_inlier == -1 (:305-306)
                 continue
             scene_id, im_id = chunk[ti][:2]
@@ -288,11 +290,17 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
     def finish(job):
         chunk, owners, pending, t1, _held, step = job    # _held: injected maps stay alive until the batch is collected
         from . import _lib
+        if pending is not None:
+            assert len(plan(chunk)) == pending.n, "plan() and prepare() disagree on the detections of this step (%d vs %d)" % (len(plan(chunk)), pending.n)
         if gather is None:
             pending.collect()
             rows_of(chunk, owners, np.frombuffer(pending.pose_array, dtype=_lib.POSE_DTYPE, count=max(pending.n, 1)), time.time() - t1)
             return
-        _own, allp = gather(pending, n_max)               # collective: every rank, every step; pending is None for an empty shard
+        try:
+            _own, allp = gather(pending, n_max)           # collective: every rank, every step; pending is None for an empty shard
+        except Exception as e:                            # noqa: BLE001 -- reported after the collective ran (the library joins with padding records):
+            step_errors.append(e)                         # keep walking the steps so that the peers' remaining collectives are joined, re-raise at the end
+            return
         dt = time.time() - t1
         for r in range(shard[1]):                          # every rank builds every rank's rows of this step from the gathered records
             ch = chunks_of(r)[step] if step < len(chunks_of(r)) else []
@@ -305,6 +313,7 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
     def frame_paths(chunk):
         return [os.path.join(base_dir, by_image[(c[0], c[1])]["rgb"]) for c in chunk if (c[0], c[1]) in by_image]
 
+    step_errors, range_events = [], []
     gather, n_max, n_steps = None, 0, (len(tlist) + batch_images - 1) // batch_images
     _chunks = {}
 
@@ -327,7 +336,13 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
         chunk = tlist[b0:b0 + batch_images]
         t1 = time.time()
         loader.request(frame_paths(tlist[b0 + batch_images:b0 + 2 * batch_images]))      # decoded while this chunk is prepared and runs
-        frames, dets, det_masks, owners = prepare(chunk)
+        try:
+            frames, dets, det_masks, owners = prepare(chunk)
+        except Exception as e:                            # noqa: BLE001 -- a missing mask / unreadable frame on ONE rank
+            if gather is None:
+                raise
+            step_errors.append(e)                         # lockstep: this rank keeps joining every remaining collective (as an empty shard) and re-raises at the end
+            frames, dets, det_masks, owners = [], [], [], []
         if not dets:
             if gather is not None:                        # lockstep: an empty shard still joins this step's collective
                 in_flight.append((chunk, owners, None, t1, None, step))
@@ -346,9 +361,15 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
                     torch.from_numpy(np.ascontiguousarray(inject["inject2"][idx])).cuda(device))
             torch.cuda.synchronize(device)
             extra = dict(extra, inject1=held[0].data_ptr(), inject2=held[1].data_ptr(), inject_slots=int(held[1].shape[1]))
-        pending = runtime.est_pose_submit(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
-                                          anti_aliasing=_resize_generation(cfg),
-                                          **extra)
+        try:
+            pending = runtime.est_pose_submit(ctx, specs, frames, dets, det_masks=det_masks if det_masks else None,
+                                              anti_aliasing=_resize_generation(cfg),
+                                              **extra)
+        except Exception as e:                            # noqa: BLE001
+            if gather is None:
+                raise
+            step_errors.append(e)
+            pending = None
         in_flight.append((chunk, owners, pending, t1, held, step))
         if len(in_flight) == 2:
             finish(in_flight.pop(0))
@@ -358,6 +379,12 @@ def run(cfg: dict, dataset: str, dump: dict, device: int = 0, base_dir: str = ".
         rows.sort(key=lambda r: r["_order"])
         gather.close()
     loader.close()
+    if step_errors:
+        raise step_errors[0]
+    if range_events:
+        from . import _lib as _l
+        raise _l.P2PRangeError("a rank's generator pass left the split-f16 operand range on image(s) %s: its detections are missing from the "
+                                    "rows (use precision='auto' or 'f32')" % sorted(set(range_events))[:4])
     out_dir = cfg.get("path_to_output")
     if out_dir and write_csv:
         os.makedirs(out_dir, exist_ok=True)

@@ -68,7 +68,7 @@ class pix2pose():
         # pre-filter when down-scaling); the reference does not pin the version
         # skimage="0.14" / "0.18" names the generation outright ("0.18" is pinned bit for bit to the real scikit-image 0.18.3)
         # "0.15" / "0.16": anti-aliasing also on the bool keep mask of recognition.py:103 (what the reference's own python-3.5 image resolves to).
-        # Nothing named: generation 0 with a one-time warning that it is the unpinned one.
+        # Nothing named: generation 0 with a one-time warning that the choice was made for the caller (the reference pins no version).
         gen = kwargs.get("skimage")
         if gen is not None:
             self.anti_aliasing = runtime.resize_generation(str(gen))

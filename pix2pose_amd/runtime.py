@@ -201,7 +201,7 @@ _warned_unpinned = False
 
 
 def resize_generation(spec) -> int:
-    """None / False / 0 / "0.14" -> 0 (scikit-image <= 0.14: no anti-aliasing; NOT pinned to a real library);
+    """None / False / 0 / "0.14" -> 0 (scikit-image <= 0.14: no anti-aliasing, every image warped in double; pinned to the real 0.18.3 float64 warp);
     True / 1 / "0.17" / "0.18" -> 1 (pinned bit for bit to the real 0.18.3); 2 / "0.15" / "0.16" -> 2 (anti-aliasing on for every input
     including the bool keep mask; its Gaussian filter pinned to the real scipy, its warp restated)."""
     if spec is None or spec is False:
@@ -219,14 +219,16 @@ def resize_generation(spec) -> int:
 
 
 def warn_unpinned_generation(who: str):
-    """The default generation (scikit-image <= 0.14) cannot be checked against any real library in the build image: say so, once."""
+    """The reference does not pin scikit-image and its six resize calls differ between the library's generations: a caller that names none gets
+    the <= 0.14 semantics (pinned to the real library's float64 warp like the others) -- say so, once."""
     global _warned_unpinned
     if not _warned_unpinned:
         _warned_unpinned = True
         import warnings
-        warnings.warn("%s: no scikit-image generation was named -- using the <= 0.14 resize semantics, which are restated from the published "
-                      "behaviour and NOT pinned to a real library; name the version the reference environment resolves to (skimage='0.18' is "
-                      "pinned bit for bit to scikit-image 0.18.3, '0.15' / '0.16' has its filter pinned) to silence this" % who, stacklevel=3)
+        warnings.warn("%s: no scikit-image generation was named -- using the <= 0.14 resize semantics (no anti-aliasing filter).  The reference "
+                      "does not pin scikit-image and the generations give different masks: name the version the reference environment "
+                      "resolves to (skimage='0.14', '0.15' / '0.16' -- what the reference's python-3.5 image installs -- or '0.17' / '0.18') "
+                      "to silence this" % who, stacklevel=3)
 
 
 def _marshal(objects, images, detections, inject1, inject2, inject_slots, want_masks, det_masks, ransac_iterations,

@@ -18,6 +18,8 @@ and numpy's removed aliases (np.int) are restored.
     /opt/conda/bin/python3.9 tests/golden/make_reference_vectors.py --real-skimage     (writes reference_est_pose_skimage018.json)
     /opt/conda/bin/python3.9 tests/golden/make_reference_vectors.py --skimage015       (writes reference_est_pose_skimage015.json: the
                                                                                          0.15 / 0.16 generation, see main_skimage015)
+    /opt/conda/bin/python3.9 tests/golden/make_reference_vectors.py --skimage014       (writes reference_est_pose_skimage014.json: the
+                                                                                         <= 0.14 generation = the library's DEFAULT, see main_skimage014)
 
 ROUND 4: the build image carries a second interpreter with the REAL scikit-image 0.18.3 (+ scipy 1.7.1, numpy 1.26).  With
 --real-skimage the skimage shim is NOT installed: all six resize call sites of est_pose (recognition.py:82,103,121,134,144,146)
@@ -351,7 +353,59 @@ def main_skimage015():
           ";", sum(1 for d in ds if "skip" in d), "skipped")
 
 
+SCENES_014 = SCENES + [dict(seed=541, n_det=6, bbox_side=(40, 300)),      # the bench's general-crop distribution
+                       dict(seed=542, n_det=4, bbox_side=(100, 180), outlier_frac=0.4),
+                       dict(seed=543, n_det=4, bbox_side=(36, 60)),        # stage-1 sides < 128: the maps are shrunk WITHOUT a filter in this generation
+                       dict(seed=544, n_det=4, bbox_side=(90, 210))]
+
+
+def main_skimage014():
+    """est_pose of the reference under the scikit-image <= 0.14 GENERATION -- the DEFAULT of the C ABI (resize_anti_aliasing = 0), the shim
+    and eval_bop: ``resize`` has no anti-aliasing filter at all and warps every image in double.  No 0.14 wheel exists in the build image;
+    what 0.14 runs for order=1 is the float64 ``_warp_fast`` + clip=True that the REAL scikit-image 0.18.3 still runs for
+    ``resize(image.astype(float64), anti_aliasing=False)`` -- main_skimage015's resize_015 without its filter branch -- with the exact
+    affine map as in --real-skimage (the SVD fit's noise is not reproducible across machines).
+    PINNED by the real library: the warp, the reflect / constant border modes, cval, clip.  RESTATED: that 0.14 converts every image
+    (bool mask, float32 maps) to double before the warp (from the published 0.14 sources of transform/_warps.py)."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    version = install_shims(real_skimage=True)
+    import scipy
+    import skimage.transform as skt
+    real_resize = skt.resize
+    _w, _Exact = _exact_affine_patch()
+    _w.AffineTransform = _Exact
+
+    def resize_014(image, output_shape, order=1, mode="reflect", cval=0, clip=True, preserve_range=False):
+        assert order == 1 and not preserve_range
+        return real_resize(np.asarray(image).astype(np.float64), output_shape, order=1, mode=mode, cval=cval, clip=clip, anti_aliasing=False)
+
+    skt.resize = resize_014
+    sys.path.insert(0, REF)
+    from pix2pose_model import recognition as ref
+    ref.resize = resize_014                                # `from skimage.transform import resize` already ran in the module
+    scenes = run_scenes(ref, SCENES_014)
+    if "--scenes-only" in sys.argv:
+        print(json.dumps(scenes))
+        return
+    out = {"note": "outputs of /root/reference/pix2pose_model/recognition.py (est_pose) under the scikit-image <= 0.14 resize generation (no "
+                   "anti-aliasing filter, every image warped in double): all six resize call sites run the REAL scikit-image 0.18.3 "
+                   "resize(image.astype(float64), anti_aliasing=False) with the exact affine map; cv2 / keras stood in "
+                   "(tests/golden/make_reference_vectors.py --skimage014)",
+           "skimage_version_of_the_warp": version, "scipy_version": scipy.__version__, "numpy_version": np.__version__,
+           "interpreter": "%s (python %s)" % (sys.executable, sys.version.split()[0]),
+           "th_outlier": TH_O, "th_inlier": TH_I, "scenes": scenes}
+    fn = os.path.join(HERE, "reference_est_pose_skimage014.json")
+    with open(fn, "w") as f:
+        json.dump(out, f)
+    ds = [d for s_ in scenes for d in s_["dets"]]
+    print("wrote", fn, os.path.getsize(fn), "bytes;", sum(1 for d in ds if d.get("ok")), "successful poses of", len(ds),
+          ";", sum(1 for d in ds if "skip" in d), "skipped")
+
+
 def main():
+    if "--skimage014" in sys.argv:
+        return main_skimage014()
     if "--skimage015" in sys.argv:
         return main_skimage015()
     if "--real-skimage" in sys.argv:

@@ -88,6 +88,43 @@ def test_empty_shard_and_errors_still_enter_the_collective():
     comm.close()
 
 
+_INJECT = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from pix2pose_amd import _lib, synthetic as S, weights as W
+from pix2pose_amd.runtime import Comm, Context, Generator, ObjectSpec, collect_gathered_empty, est_pose_submit
+ctx = Context(0, max_batch=16)
+comm = Comm(ctx, 0, 1, Comm.unique_id())
+spec = ObjectSpec(Generator(W.synthetic_weights("paper", 2), "paper", ctx), S.OBJ_PARAM, [0.2, 0.3, 0.35], 0.2)
+sc = S.make_scene(3, seed=78)
+j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
+torch.cuda.synchronize()
+pend = est_pose_submit(ctx, [spec], list(sc["images"]), sc["dets"], inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3)
+L = _lib.lib()
+poses, out = (_lib.Pose * 8)(), (_lib.Pose * 8)()
+rc = L.p2p_est_pose_collect_gathered(ctx.handle, comm.handle, pend.ticket, poses, 8, out)
+assert rc == -2, rc                                                               # P2P_ERR_HIP, reported AFTER the collective ...
+assert b"joined the collective" in L.p2p_last_error(), L.p2p_last_error()
+assert all(out[i].status == _lib.POSE_ABSENT for i in range(8))                   # ... which ran with this rank's padding records
+allp = collect_gathered_empty(ctx, comm, 8)                                       # and the communicator is still usable
+assert all(allp[i].status == _lib.POSE_ABSENT for i in range(8))
+print("joined")
+"""
+
+
+def test_local_failure_before_the_collective_still_joins_it():
+    """A failure between the buffers and ncclAllGather (memset / pack-kernel launch; injected here through a switch of the development
+    twin) must not strand the peers: the rank joins with padding records and reports the error after the collective."""
+    import os, subprocess, sys
+    from pix2pose_amd.build import dev_switches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(dev_switches(P2P_COMM_INJECT_PACK_FAILURE=1))
+    r = subprocess.run([sys.executable, "-c", _INJECT % root], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "joined" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_comm_argument_validation():
     from pix2pose_amd import _lib
     from pix2pose_amd.runtime import Comm, Context

@@ -97,6 +97,23 @@ def test_committed_skimage015_vectors_are_what_the_real_libraries_produce():
     assert n >= 25
 
 
+@pytest.mark.skipif(not _have("skimage") or not os.path.isdir("/root/reference"), reason="needs the conda interpreter and /root/reference")
+def test_committed_skimage014_vectors_are_what_the_real_library_produces():
+    """tests/golden/reference_est_pose_skimage014.json (the <= 0.14 resize generation = the library's default: every resize call site of the
+    reference's est_pose served by the REAL scikit-image 0.18.3 float64 warp without a filter, exact affine map) re-derived now."""
+    keys = ("ok", "bbox_t", "mask_sum", "mask_crc", "img_pred_crc", "frac_inlier", "R", "t")
+    committed = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_est_pose_skimage014.json")))
+    r = _run([os.path.join("tests", "golden", "make_reference_vectors.py"), "--skimage014", "--scenes-only"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    fresh = json.loads(r.stdout.strip().splitlines()[-1])
+    n = 0
+    for sf, sc in zip(fresh, committed["scenes"]):
+        for df, dc in zip(sf["dets"], sc["dets"]):
+            assert [df.get(k) for k in keys] == [dc.get(k) for k in keys]
+            n += 1
+    assert n >= 25
+
+
 def test_bool_mask_filter_restatement_equals_scipy():
     """What csrc/pipeline.hip restates for generation 2 -- scipy.ndimage.gaussian_filter on a BOOL array: per axis
     t = x0 w0 + sum_{d = r .. 1} (x[-d] + x[+d]) w[d] in double, then a C cast to npy_bool -- against the scipy of THIS interpreter, for

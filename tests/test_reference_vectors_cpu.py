@@ -40,9 +40,10 @@ GS = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage018.
 
 
 G15 = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage015.json")))
+G14 = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage014.json")))
 
 
-@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage", "skimage015"])
+@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage", "skimage015", "skimage014"])
 def test_est_pose_matches_reference(key):
     """"scenes": resize stand-in without anti-aliasing (scikit-image <= 0.14); "scenes_aa": with the Gaussian pre-filter of
     scikit-image 0.17 - 0.18 (scipy.ndimage.gaussian_filter itself) and float32 images kept float32 through the warp;
@@ -52,10 +53,14 @@ def test_est_pose_matches_reference(key):
     anti_aliasing=True mode are IDENTICAL to it.
     "skimage015": reference_est_pose_skimage015.json -- the reference's est_pose under the 0.15 / 0.16 generation (what the reference's own
     python-3.5 image resolves to), its resize composed from the REAL scipy 1.7.1 gaussian_filter on every image as passed -- the bool keep
-    mask of recognition.py:103 included -- and the REAL scikit-image 0.18.3 float64 warp: the oracle's generation 2 is IDENTICAL to it."""
+    mask of recognition.py:103 included -- and the REAL scikit-image 0.18.3 float64 warp: the oracle's generation 2 is IDENTICAL to it.
+    "skimage014": reference_est_pose_skimage014.json -- the reference's est_pose under the <= 0.14 generation (generation 0: the DEFAULT of the
+    C ABI, the shim and eval_bop), every resize call site served by the REAL scikit-image 0.18.3 float64 warp without a filter
+    (resize(image.astype(float64), anti_aliasing=False), exact affine map): the oracle's generation 0 is IDENTICAL to it -- the same
+    scenes as "scenes" (where the oracle's own resize stood in for the library) plus general crop sizes."""
     n = 0
-    aa = {"scenes": 0, "skimage015": 2}.get(key, 1)
-    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G15["scenes"] if key == "skimage015" else G[key]):
+    aa = {"scenes": 0, "skimage014": 0, "skimage015": 2}.get(key, 1)
+    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G15["scenes"] if key == "skimage015" else G14["scenes"] if key == "skimage014" else G[key]):
         spec = s["spec"]
         sc = synthetic.make_scene(spec["n_det"], seed=spec["seed"], bbox_side=tuple(spec["bbox_side"]), outlier_frac=spec.get("outlier_frac", 0.2))
         for i, gd in enumerate(s["dets"]):

@@ -16,13 +16,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 G = json.load(open(os.path.join(HERE, "golden", "reference_est_pose.json")))
 GS = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage018.json")))
 G15 = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage015.json")))
+G14 = json.load(open(os.path.join(HERE, "golden", "reference_est_pose_skimage014.json")))
 
 
 def _crc(a):
     return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
 
 
-@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage", "skimage015"])
+@pytest.mark.parametrize("key", ["scenes", "scenes_aa", "real_skimage", "skimage015", "skimage014"])
 def test_est_pose_pipeline_matches_reference_vectors(key):
     """"scenes_aa": p2p_est_pose_opts.resize_anti_aliasing = 1 against the reference run with an anti-aliasing resize
     (scikit-image 0.17 - 0.18 semantics; the Gaussian filter there was scipy.ndimage's own).
@@ -30,15 +31,17 @@ def test_est_pose_pipeline_matches_reference_vectors(key):
     (tests/golden/reference_est_pose_skimage018.json["scenes_exact_matrix"], generated under /opt/conda/bin/python3.9): masks and uint8
     images bit for bit.
     "skimage015": resize_anti_aliasing = 2 against the reference's est_pose under the scikit-image 0.15 / 0.16 generation (REAL scipy filter on
-    every image as passed, the bool keep mask included; REAL 0.18.3 float64 warp; tests/golden/reference_est_pose_skimage015.json)."""
+    every image as passed, the bool keep mask included; REAL 0.18.3 float64 warp; tests/golden/reference_est_pose_skimage015.json).
+    "skimage014": resize_anti_aliasing = 0 -- the DEFAULT -- against the reference's est_pose with every resize call site served by the REAL
+    scikit-image 0.18.3 float64 warp without a filter (the <= 0.14 generation; tests/golden/reference_est_pose_skimage014.json)."""
     import torch
     from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
     ctx = Context(0, max_batch=16)
     gen = Generator(W.synthetic_weights("paper", 1), "paper", ctx)
     spec = ObjectSpec(gen, synthetic.OBJ_PARAM, G["th_outlier"], G["th_inlier"])
     n = n_sens = 0
-    sk_gen = {"scenes": 0, "skimage015": 2}.get(key, 1)
-    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G15["scenes"] if key == "skimage015" else G[key]):
+    sk_gen = {"scenes": 0, "skimage014": 0, "skimage015": 2}.get(key, 1)
+    for s in (GS["scenes_exact_matrix"] if key == "real_skimage" else G15["scenes"] if key == "skimage015" else G14["scenes"] if key == "skimage014" else G[key]):
         sp = s["spec"]
         sc = synthetic.make_scene(sp["n_det"], seed=sp["seed"], bbox_side=tuple(sp["bbox_side"]), outlier_frac=sp.get("outlier_frac", 0.2))
         j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
