@@ -34,11 +34,13 @@ def test_predict_matches_oracle(backbone, precision):
     assert np.abs(prob - p0).max() < XYZ_TOL
 
 
-def test_predict_batch_invariance_and_chunking():
-    """The same crop gives bit-identical output alone, inside a batch, and across workspace chunks."""
+@pytest.mark.parametrize("winograd", ["off", "always"])
+def test_predict_batch_invariance_and_chunking(winograd):
+    """The same crop gives bit-identical output alone, inside a batch, and across workspace chunks -- with the form of the 5x5 decoder layers
+    pinned (the default "auto" runs a ONE-input pass on the direct kernels and every larger one in Winograd form: p2p_ctx_set_winograd)."""
     from pix2pose_amd.runtime import Context, Generator
     w = W.synthetic_weights("resnet50", 2)
-    ctx = Context(0, max_batch=4)
+    ctx = Context(0, max_batch=4, winograd=winograd)
     g = Generator(w, "resnet50", ctx)
     x = _inputs(7, seed=5)
     dec, prob = g.predict(x)               # 7 > max_batch=4 -> two chunks
