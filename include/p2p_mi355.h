@@ -248,6 +248,11 @@ typedef struct {
     float* dbg_x2;
     int* dbg_boxes2;            /* [n_det][12] stage-2 get_boxes result */
     int* dbg_cand;              /* [n_det][K][6]: valid, n_non_gray, n_corr, n_inliers, ransac iters, best iter */
+    /* the generator's raw answers (x, y, z, prob) of both stages: [n_det,128,128,4] and [n_det,K,128,128,4] (slot k of a detection = its
+     * k-th outlier threshold; slots without a stage-2 input hold garbage).  The shim builds the reference's FAILURE returns from them: the
+     * first tuple element of recognition.py:127 / :191 is the stage-1 / last candidate's clipped (decode + 1) / 2 preview. */
+    float* dbg_y1;
+    float* dbg_y2;
     /* score_type 2 support (reference tools/5_evaluation_bop_basic.py:307-316): per-detection
      * detector masks, host pointer [n_det][det_mask_stride] bytes (non-zero = object), same H x W
      * as the detection's frame; mask_stats (host, [n_det][3]) receives

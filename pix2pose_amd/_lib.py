@@ -73,7 +73,7 @@ class EstPoseOpts(C.Structure):
                 ("inject1", C.c_void_p), ("inject2", C.c_void_p), ("inject_slots", C.c_int),
                 ("valid_mask", C.c_void_p), ("mask_stride", C.c_int64), ("img_pred", C.c_void_p),
                 ("pred_stride", C.c_int64), ("dbg_x1", C.c_void_p), ("dbg_x2", C.c_void_p),
-                ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p),
+                ("dbg_boxes2", C.c_void_p), ("dbg_cand", C.c_void_p), ("dbg_y1", C.c_void_p), ("dbg_y2", C.c_void_p),
                 ("det_mask", C.c_void_p), ("det_mask_stride", C.c_int64), ("mask_stats", C.c_void_p),
                 ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int), ("mask_prezeroed", C.c_int)]
 

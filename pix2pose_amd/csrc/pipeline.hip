@@ -1710,7 +1710,7 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         set_error("an asynchronous batch (ticket %d) is in flight: collect it before a blocking call", SL.ticket);
         return P2P_ERR_CAPACITY;
     }
-    if (async && (opt.dbg_x1 || opt.dbg_x2 || opt.dbg_boxes2 || opt.dbg_cand)) {
+    if (async && (opt.dbg_x1 || opt.dbg_x2 || opt.dbg_boxes2 || opt.dbg_cand || opt.dbg_y1 || opt.dbg_y2)) {
         set_error("the debug taps are only available from the blocking call");
         return P2P_ERR_INVALID_ARG;
     }
@@ -1784,12 +1784,14 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
     if ((rc = flush_stage2(X, P, SL, st, false))) return rc;
     // debug taps
     const float *x1h = SL.x1.as<float>(), *x2h = SL.x2.as<float>();
-    std::vector<float> hx1, hx2;
+    std::vector<float> hx1, hx2, hy1, hy2;
     std::vector<Stage1> hs1;
     std::vector<CandStat> hcs;
     std::vector<PnpResult> hres;
     if (opt.dbg_x1) { hx1.resize((size_t)n * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx1.data(), x1h, hx1.size() * 4, hipMemcpyDeviceToHost, st)); }
     if (opt.dbg_x2) { hx2.resize((size_t)n * K * 16384 * 3); HIP_TRY(hipMemcpyAsync(hx2.data(), x2h, hx2.size() * 4, hipMemcpyDeviceToHost, st)); }
+    if (opt.dbg_y1) { hy1.resize((size_t)n * 16384 * 4); HIP_TRY(hipMemcpyAsync(hy1.data(), SL.y1.as<float>(), hy1.size() * 4, hipMemcpyDeviceToHost, st)); }
+    if (opt.dbg_y2) { hy2.resize((size_t)n * K * 16384 * 4); HIP_TRY(hipMemcpyAsync(hy2.data(), SL.y2.as<float>(), hy2.size() * 4, hipMemcpyDeviceToHost, st)); }
     if (opt.dbg_boxes2 || opt.dbg_cand) {
         hs1.resize(n); hcs.resize((size_t)n * K); hres.resize((size_t)n * K);
         HIP_TRY(hipMemcpyAsync(hs1.data(), SL.s1.p, sizeof(Stage1) * n, hipMemcpyDeviceToHost, st));
@@ -1815,6 +1817,8 @@ static int run_est_pose(Ctx& X, const p2p_object* objects, int n_obj, const p2p_
         const int o = SL.perm[i];
         if (opt.dbg_x1) memcpy(opt.dbg_x1 + (size_t)o * 16384 * 3, hx1.data() + (size_t)i * 16384 * 3, 16384 * 3 * 4);
         if (opt.dbg_x2) memcpy(opt.dbg_x2 + (size_t)o * K * 16384 * 3, hx2.data() + (size_t)i * K * 16384 * 3, (size_t)K * 16384 * 3 * 4);
+        if (opt.dbg_y1) memcpy(opt.dbg_y1 + (size_t)o * 16384 * 4, hy1.data() + (size_t)i * 16384 * 4, 16384 * 4 * 4);
+        if (opt.dbg_y2) memcpy(opt.dbg_y2 + (size_t)o * K * 16384 * 4, hy2.data() + (size_t)i * K * 16384 * 4, (size_t)K * 16384 * 4 * 4);
         if (opt.dbg_boxes2) memcpy(opt.dbg_boxes2 + (size_t)o * 12, &hs1[i].b2, sizeof(Boxes));
         if (opt.dbg_cand)
             for (int k = 0; k < K; ++k) {

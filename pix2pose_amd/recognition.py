@@ -8,8 +8,9 @@ Differences a caller can observe (all documented in INTEGRATION.md):
     not a Keras HDF5 file (h5py/Keras are not part of this stack; the converter is tools-side).
   * an unknown ``backbone`` raises ValueError (the reference silently leaves ``generator_train``
     undefined, recognition.py:21-26).
-  * on failure the first tuple element is a placeholder ``np.zeros(1)`` (no caller reads it:
-    tools/5_evaluation_bop_basic.py:303-305 tests ``frac_inlier == -1`` and continues).
+  * on failure the first tuple element is what the reference returns there (np.zeros(1) at :79, the stage-1 / last-candidate preview at
+    :127 / :191) -- fetched by a second debug-tap call on that path only (no caller reads it: tools/5_evaluation_bop_basic.py:303-305
+    tests ``frac_inlier == -1`` and continues).
   * boxes entirely outside the frame (where the reference crashes on a shape mismatch) fail cleanly.
 """
 from __future__ import annotations
@@ -100,11 +101,30 @@ class pix2pose():
         p = poses[0]
         box = np.array(list(p.bbox_t), int)
         if p.status != 0:
-            return np.zeros((1)), -1, -1, -1, -1, box
+            return self._failure_preview(p.status, rgb, bbox, inj), -1, -1, -1, -1, box
         v1, v2, u1, u2 = box
         img_pred = ex["img_pred"][0][:(v2 - v1) * (u2 - u1) * 3].reshape(v2 - v1, u2 - u1, 3).copy()
         mask = ex["valid_mask"][0][:H * Wd].reshape(H, Wd).astype(bool)
         return img_pred, mask, np.array(p.R, float).reshape(3, 3), np.array(p.t, float), p.frac_inlier, box
+
+    def _failure_preview(self, status, rgb, bbox, inj):
+        """First element of the reference's failure returns: np.zeros(1) at recognition.py:79; the stage-1 preview (decode + 1) / 2, clipped, at
+        :127; at :191 `img_pred` is what the candidate loop assigned last (:141-143: the last stage-2 answer, gray pixels zeroed first).  No
+        caller reads it, so it is fetched by a second (debug-tap) call on this path only."""
+        if status == 1:                                    # _lib: P2P_POSE_CROP_TOO_SMALL
+            return np.zeros((1))
+        _, ex = runtime.est_pose_batch(self.ctx, [self._spec()], [rgb], [(0, 0, [int(b) for b in bbox], self.camK)],
+                                       debug=True, anti_aliasing=self.anti_aliasing, **inj)
+        if status == 2:                                    # P2P_POSE_NO_CANDIDATE
+            decode = ex["y1"][0][..., :3].copy()
+        else:                                              # P2P_POSE_PNP_FAILED
+            k = max(i for i in range(ex["cand"].shape[1]) if ex["cand"][0, i, 0])
+            decode = ex["y2"][0, k][..., :3].copy()
+            decode[np.linalg.norm(decode, axis=2) < 0.3] = 0
+        img_pred = (decode + 1) / 2
+        img_pred[img_pred > 1] = 1
+        img_pred[img_pred < 0] = 0
+        return img_pred
 
     def est_pose_batch(self, rgbs, bboxes, camKs=None):
         """Many detections of this object at once (the reason this library exists).

@@ -309,6 +309,9 @@ def est_pose_batch(ctx: Context, objects, images, detections, *, inject1=None, i
         extras["cand"] = np.zeros((n, K, 6), np.int32)
         opts.dbg_x1, opts.dbg_x2 = extras["x1"].ctypes.data, extras["x2"].ctypes.data
         opts.dbg_boxes2, opts.dbg_cand = extras["boxes2"].ctypes.data, extras["cand"].ctypes.data
+        extras["y1"] = np.zeros((n, 128, 128, 4), np.float32)
+        extras["y2"] = np.zeros((n, K, 128, 128, 4), np.float32)
+        opts.dbg_y1, opts.dbg_y2 = extras["y1"].ctypes.data, extras["y2"].ctypes.data
     _lib.check(_lib.lib().p2p_est_pose_batch(ctx.handle, objs, len(objects), imgs, len(images), dets, n, poses,
                                              C.byref(opts)), "p2p_est_pose_batch")
     return [poses[i] for i in range(n)], extras

@@ -268,6 +268,13 @@ def test_shim_surface_matches_reference_tuple(rig):
     assert box.shape == (4,) and box.dtype.kind == "i"
     if isinstance(frac, int) and frac == -1:            # failure sentinels (recognition.py:127,191)
         assert mask == -1 and R == -1 and t == -1
+        # ... and the reference's first element there: the clipped (decode + 1) / 2 preview of stage 1 (:127) / of the last candidate (:191)
+        assert img_pred.shape == (128, 128, 3) and img_pred.dtype == np.float32 and img_pred.min() >= 0 and img_pred.max() <= 1
+        _, ex = __import__("pix2pose_amd.runtime", fromlist=["x"]).est_pose_batch(ctx, [p._spec()], [rgb], [(0, 0, [100, 200, 186, 286], synth.LM_K)], debug=True)
+        d1 = p.generator_train.predict(ex["x1"])[0][0]
+        st1 = np.clip((d1 + 1) / 2, 0, 1)
+        if not ex["cand"][0, :, 0].any():               # no stage-2 input at all: the stage-1 preview, bit for bit
+            np.testing.assert_array_equal(img_pred, st1)
     else:
         assert img_pred.dtype == np.uint8 and mask.dtype == bool and mask.shape == (480, 640)
         assert R.shape == (3, 3) and t.shape == (3,)

@@ -2,12 +2,11 @@
 # Same-lease regression gate under the headline: the previous round's head against HEAD (and HEAD without the operand-range guard),
 # INTERLEAVED on one GPU lease, so that box-to-box and power variance cancel out of every ratio that DESIGN.md quotes.
 #
-#   tools/ab_round.sh build [prev-commit]   build container: `git archive` of the previous round's head (default 7d38502 = round 3's, the best
-#                                           driver line so far) into tools/ab/prev/ + its library; HEAD's sources with -DP2P_NO_RANGE_GUARD
-#                                           into tools/ab/noguard/libp2p_mi355.so.  tools/ab/ is git-ignored and DOES travel with gpurun.
-#   tools/ab_round.sh run [rounds]          GPU box: `rounds` (default 3) interleaved passes of bench.py --steps 20 over prev / head / noguard,
+#   tools/ab_round.sh build [prev-commit]   build container: `git archive` of the previous round's head (default 4f9273c = round 5's) into tools/ab/prev/ + its library.
+#                                           tools/ab/ is git-ignored and listed in .gpurunignore: take that line out for the `run` call.
+#   tools/ab_round.sh run [rounds]          GPU box: `rounds` (default 3) interleaved passes of bench.py --steps 20 over prev / head / nowino (= head with --winograd off),
 #                                           shader clock + power sampled with rocm-smi during each, then a rocprofv3 kernel trace of one blocking
-#                                           step of prev and head -> per-layer table with ratios.  Output: gpurun_out/r05_vs_prev.txt
+#                                           step of prev and head -> per-layer table with ratios.  Output: gpurun_out/r06_vs_prev.txt
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 AB=$ROOT/tools/ab
@@ -15,24 +14,13 @@ MODE=${1:-run}
 
 if [ "$MODE" == "build" ]; then
     set -e
-    PREV=${2:-7d38502}
-    rm -rf $AB/prev && mkdir -p $AB/prev $AB/noguard
+    PREV=${2:-4f9273c}
+    rm -rf $AB/prev && mkdir -p $AB/prev
     (cd $ROOT && git archive $PREV) | tar -x -C $AB/prev
     echo $PREV > $AB/prev/.commit
     (cd $AB/prev && python pix2pose_amd/build.py > /dev/null)
     echo "prev ($PREV): $AB/prev/pix2pose_amd/libp2p_mi355.so"
-    C=$ROOT/pix2pose_amd/csrc
-    python $ROOT/pix2pose_amd/build.py > /dev/null          # HEAD's own library (and _build_id / _exports.map)
-    OBJS=""
-    for s in $(python -c "import sys; sys.path.insert(0, '$ROOT'); from pix2pose_amd import build; print(' '.join(build.SOURCES))"); do
-        o=$AB/noguard/${s%.hip}.o
-        if [ ! -f $o ] || [ $C/$s -nt $o ] || [ $C/kernels.h -nt $o ]; then
-            /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DP2P_NO_RANGE_GUARD -c $C/$s -o $o 2>&1 | grep -E "error" || true
-        fi
-        OBJS="$OBJS $o"
-    done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$C/_exports.map -o $AB/noguard/libp2p_mi355.so $OBJS $C/_build_id.o -ldl
-    echo "noguard: $AB/noguard/libp2p_mi355.so"
+    python $ROOT/pix2pose_amd/build.py > /dev/null          # HEAD's own library
     exit 0
 fi
 
@@ -40,11 +28,11 @@ fi
 ROUNDS=${2:-3}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
-REP=$OUT/r05_vs_prev.txt
+REP=$OUT/r06_vs_prev.txt
 cd /tmp && export TMPDIR=/tmp
 PREV_COMMIT=$(cat $AB/prev/.commit 2>/dev/null || echo "?")
 {
-    echo "# same-lease A/B: prev = $PREV_COMMIT (tools/ab/prev), head = this tree, noguard = this tree built with -DP2P_NO_RANGE_GUARD"
+    echo "# same-lease A/B: prev = $PREV_COMMIT (tools/ab/prev), head = this tree, nowino = this tree with bench.py --winograd off (the 5x5 decoder layers on the direct kernels)"
     echo "# bench.py --steps 20 --warmup 3 --no-legs, $ROUNDS interleaved rounds; sclk / power = mean of rocm-smi samples (0.25 s) while the bench ran"
     rocm-smi --showproductname 2>/dev/null | grep -i "card series\|gfx" | head -2
 } > $REP
@@ -63,7 +51,7 @@ one_bench() {       # $1 = label, $2 = tree, $3 = P2P_LIB or "", $4 = extra envi
     local sp=$!
     local line
     if [ -n "$3" ]; then line=$(cd $2 && env P2P_LIB=$3 ${4:-P2P_AB=1} python bench.py --steps 20 --warmup 3 --no-legs 2>/dev/null | tail -1)
-    else line=$(cd $2 && python bench.py --steps 20 --warmup 3 --no-legs 2>/dev/null | tail -1); fi
+    else line=$(cd $2 && python bench.py --steps 20 --warmup 3 --no-legs ${5:-} 2>/dev/null | tail -1); fi
     touch $f.stop; wait $sp 2>/dev/null
     python - "$1" "$line" $f <<'EOF'
 import json, sys, re
@@ -103,18 +91,17 @@ for r in $(seq 1 $ROUNDS); do
     echo "## round $r" >> $REP
     one_bench prev $AB/prev "" >> $REP
     one_bench head $ROOT "" >> $REP
-    one_bench noguard $ROOT $AB/noguard/libp2p_mi355.so >> $REP
-    one_bench nofuse $ROOT $ROOT/pix2pose_amd/libp2p_mi355_dev.so "P2P_NO_FUSED_BLOCK=1 P2P_NO_FUSED_PROJ=1" >> $REP      # head with the identity blocks as three launches (round 4's route)
+    one_bench nowino $ROOT "" "" "--winograd off" >> $REP      # head with the 5x5 decoder layers on the direct kernels (round 5's arithmetic)
 done
 
 # per-layer times of one blocking step: prev, head, and head with the three-launch blocks -- two interleaved traces each, the smaller time of
 # a layer counts (one trace of a 10-us launch, or of a whole run that met a power excursion, is noise)
 for rep in 1 2; do
-for v in prev head nofuse; do
+for v in prev head nowino; do
     tree=$ROOT; [ $v == prev ] && tree=$AB/prev
     rm -rf $OUT/ab_prof_$v
-    if [ $v == nofuse ]; then
-        (cd $tree && P2P_LIB=$ROOT/pix2pose_amd/libp2p_mi355_dev.so P2P_NO_FUSED_BLOCK=1 P2P_NO_FUSED_PROJ=1 rocprofv3 --kernel-trace -d $OUT/ab_prof_$v -o t -- python bench.py --steps 2 --warmup 1 --blocking --no-legs > /dev/null 2>&1)
+    if [ $v == nowino ]; then
+        (cd $tree && rocprofv3 --kernel-trace -d $OUT/ab_prof_$v -o t -- python bench.py --steps 2 --warmup 1 --blocking --no-legs --winograd off > /dev/null 2>&1)
     else
     (cd $tree && rocprofv3 --kernel-trace -d $OUT/ab_prof_$v -o t -- python bench.py --steps 2 --warmup 1 --blocking --no-legs > /dev/null 2>&1)
     fi
@@ -123,7 +110,7 @@ for v in prev head nofuse; do
     rm -rf $OUT/ab_prof_$v
 done
 done
-python - $OUT/ab_layers_prev $OUT/ab_layers_head $OUT/ab_layers_nofuse >> $REP <<'EOF'
+python - $OUT/ab_layers_prev $OUT/ab_layers_head $OUT/ab_layers_nowino >> $REP <<'EOF'
 import sys
 def load1(f):
     d, order = {}, []
@@ -131,6 +118,7 @@ def load1(f):
         p = ln.split()
         if len(p) > 3 and "us" in p:
             k = p[0].split("_")[0] if p[0].startswith("res") else p[0]        # ResNet blocks compare as blocks (head runs the identity blocks as ONE launch)
+            if p[0].startswith("deconv") and p[1] in ("V", "gemm"): k = p[0]       # Winograd layers: input transform + GEMM launch summed per layer
             if k not in d:
                 d[k] = 0.0; order.append(k)
             d[k] += float(p[p.index("us") - 1])
@@ -144,10 +132,10 @@ def load(stem):           # the smaller time of the two traces, layer by layer (
     return d, o1
 a, oa = load(sys.argv[1]); b, ob = load(sys.argv[2]); c, oc = load(sys.argv[3])
 print("## per-layer times of one blocking 256-input pass (rocprofv3 kernel trace, us; two interleaved traces per variant, the smaller time per layer; ResNet blocks summed per block):")
-print("## %-12s %9s %9s %9s   %s" % ("layer", "prev", "head", "nofuse", "head/prev  nofuse/prev"))
+print("## %-12s %9s %9s %9s   %s" % ("layer", "prev", "head", "nowino", "head/prev  nowino/prev"))
 for k in ob:
     if k in a:
-        flag = "   <-- nofuse (= this round's code on last round's route) > 2 % slower than prev" if k in c and c[k] / a[k] > 1.02 and k != "total" else ""
+        flag = "   <-- nowino (= this round's code on last round's route) > 2 % slower than prev" if k in c and c[k] / a[k] > 1.02 and k != "total" else ""
         print("%-14s %9.1f %9.1f %9.1f   %5.3f  %5.3f%s" % (k, a[k], b[k], c.get(k, float("nan")), b[k] / a[k], c.get(k, float("nan")) / a[k], flag))
     else:
         print("%-14s %9s %9.1f" % (k, "-", b[k]))
