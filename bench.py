@@ -540,6 +540,53 @@ def main():
                 it = np.array([q.ransac_iters for q in gp if q.status == 0])
                 out["general_crops"]["ransac_iters_selected_le16_le32_le64_le100"] = [int((it <= 16).sum()), int(((it > 16) & (it <= 32)).sum()),
                                                                                        int(((it > 32) & (it <= 64)).sum()), int((it > 64).sum())]
+            # Roofline entries of the bandwidth- / latency-leaning kernels of this leg: HIP-event times of two extra blocking
+            # steps (p2p_profile_read slots 12-19) over bytes computed from the batch's own counts -- the correspondences of every candidate and
+            # how far its RANSAC ran come from one extra debug-tap call.
+            try:
+                _, exg = est_pose_batch(ctx, specs, gimg, scg["dets"], debug=True, anti_aliasing=aa, **gkw)
+                cand = exg["cand"].astype(np.int64)                       # [n, K, 6]: valid, n_non_gray, n_corr, n_inliers, ransac iters, best iter
+                vmask = cand[..., 0] > 0
+                ncorr, iters = cand[..., 2] * vmask, cand[..., 4] * vmask
+                hyp = np.where(iters <= 16, 16, np.where(iters <= 64, 64, 100)) * vmask      # hypotheses are counted in rounds [0,16), [16,64), [64,100)
+                passes = (hyp + 7) // 8                                    # pnp_count_kernel: one pass over a candidate's points per 8 models
+                S2 = np.array([sd * sd for sd in sides], np.float64)
+                Kc = cand.shape[1]
+                big = np.array([sd > 128 for sd in sides])
+                ctx.profile(True); ctx.profile_read(reset=True)
+                for _ in range(2):
+                    est_pose_batch(ctx, specs, gimg, scg["dets"], anti_aliasing=aa, **gkw)
+                gst = ctx.profile_read(reset=True); ctx.profile(False)
+                n_corr_total = float(ncorr.sum())
+                byt = {13: (float((ncorr * passes).sum()) * 20.0, float((ncorr * passes).sum()) * 4.0, "a candidate's correspondences (X Y Z U V float32 = 20 B; floor: u8 XYZ + mask = 4 B) once per 8 hypotheses of the rounds its RANSAC reached"),
+                       14: (n_corr_total * 20.0 * float(np.mean(np.where(iters <= 16, 1, np.where(iters <= 64, 2, 3))[vmask])) if vmask.any() else 0.0, n_corr_total * 4.0, "the correspondences once per round (Gram sums of the best model's inliers)"),
+                       15: (n_corr_total * 20.0, n_corr_total * 4.0, "the correspondences once (final inlier mask); the refit itself is a fp64 dependency chain"),
+                       18: (float(vmask.sum()) * 16384 * 16.0 + n_corr_total * 20.0, float(vmask.sum()) * 16384 * 16.0 + n_corr_total * 4.0, "the candidate's 128x128x4 float map read once, its correspondences written once"),
+                       19: (float((S2[:, None] * vmask).sum()) * 3.0 + float(vmask.sum()) * 16384 * 12.0, None, "the crop's u8 pixels read once, the 128x128x3 float32 network input written once")}
+                if aa:
+                    fb = float(S2[big].sum()) * (1 + Kc) * 3 * 8 * 2 + float((~big).sum()) * Kc * 5 * 16384 * 8 * 2
+                    byt[16] = (fb, None, "every float64 canvas / plane read and written once per axis pass (full canvases: the region-of-interest skip lowers the real traffic)")
+                    byt[17] = (fb, None, byt[16][2])
+                rl = []
+                for slot in sorted(byt):
+                    stq = gst[slot]
+                    if not stq["launches"] or stq["total_ms"] <= 0:
+                        continue
+                    b_now, b_floor, what = byt[slot]
+                    ms = stq["total_ms"] / 2.0                             # per step
+                    rl.append({"kernel": _lib.PROFILE_KERNELS[slot][1], "bound": "hbm", "ms_per_step": ms, "launches_per_step": stq["launches"] / 2.0,
+                               "algo_MB_per_step": b_now / 1e6, "achieved_TBps": b_now / (ms * 1e-3) / 1e12, "peak_TBps": PEAK_HBM_TBPS,
+                               "frac": b_now / (ms * 1e-3) / 1e12 / PEAK_HBM_TBPS,
+                               "floor_MB_per_step": (b_floor / 1e6 if b_floor is not None else None), "bytes": what})
+                hy = gst[12]
+                out["general_crops"]["roofline_hbm" + ("_anti_aliasing" if aa else "")] = rl
+                out["general_crops"]["pnp_ms_per_step" + ("_anti_aliasing" if aa else "")] = {
+                    _lib.PROFILE_KERNELS[k][1]: gst[k]["total_ms"] / 2.0 for k in (12, 13, 14, 15) if gst[k]["launches"]}
+                out["general_crops"]["correspondences_per_step"] = n_corr_total
+                out["general_crops"]["note_rooflines"] = ("pnp_hypotheses_kernel / pnp_fit_solve_kernel are fp64 dependency chains of a few waves (latency-bound: "
+                                                          "%.2f ms per step for %d hypothesis launches), not priced against a bandwidth" % (hy["total_ms"] / 2.0, int(hy["launches"] / 2)))
+            except Exception as e:                                         # noqa: BLE001 -- a reporting leg must not take the bench line down
+                out["general_crops"]["roofline_error"] = repr(e)
         del gj1, gj2, gfr
     # -- BASELINE.json configs[1]: batch = 64 synthetic crops, one object model, generator forward ONLY (p2p_forward_async on device buffers,
     #    HIP events on the context's stream).  Passes of 256 and 768 inputs beside it: a 64-input pass under-fills the short-K layers' launches.

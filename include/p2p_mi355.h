@@ -382,10 +382,14 @@ P2P_API int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double*
  *   9  resblock_kernel (a ResNet identity bottleneck block -- 1x1, 3x3, 1x1 + residual -- in one launch, intermediates in LDS)
  *   10 wino_gemm_kernel (the 5x5 stride-1 decoder layers in Winograd F(4,5) form along the row axis: 2.5x fewer MFMA products; algo_flops
  *      stays the DIRECT form's 2 x MACs of the layer)     11 wino_input_kernel (its input transform: x -> split-f16 V in HBM; algo_flops 0)
+ *   12..19 the bandwidth- / latency-leaning kernels around the generator, time and launches only (their work depends on device-side counts:
+ *      bench.py prices them on the batch's correspondence / pixel counts):  12 pnp_hypotheses_kernel   13 pnp_count_kernel   14 pnp_score_kernel
+ *      15 pnp_fit_solve_kernel + pnp_fit_select_kernel   16 aa_filter_kernel<0>   17 aa_filter_kernel<1>
+ *      18 cand_eval_kernel + cand_compact_kernel (or cand_corr_kernel)   19 stage2_input_kernel
  * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md
  * section 8a-L), not padded work and not the 3 MFMA products per MAC of the split-f16 arithmetic.
  * ---------------------------------------------------------------------------------------- */
-#define P2P_PROFILE_SLOTS 12
+#define P2P_PROFILE_SLOTS 20
 typedef struct {
     int64_t launches;
     double total_ms;

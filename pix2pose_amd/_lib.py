@@ -78,7 +78,7 @@ class EstPoseOpts(C.Structure):
                 ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int), ("mask_prezeroed", C.c_int)]
 
 
-PROFILE_SLOTS = 12    # P2P_PROFILE_SLOTS
+PROFILE_SLOTS = 20    # P2P_PROFILE_SLOTS
 # kernel family of each slot: (label, substring of the rocprofv3 kernel name; %d = precision template argument)
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
                    ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
@@ -91,7 +91,15 @@ PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"
                    ("igemm_stream_kernel (small launches: one wave per 32x32 output tile, operands streamed to registers)", "igemm_stream_kernel"),
                    ("resblock_kernel (ResNet identity bottleneck block in one launch: 1x1 -> 3x3 -> 1x1 + residual, intermediates in LDS)", "resblock_kernel"),
                    ("wino_gemm_kernel (5x5 stride-1 decoder layers, Winograd F(4,5) along the row axis: eight position GEMMs + inverse transform)", "wino_gemm_kernel"),
-                   ("wino_input_kernel (input transform of the Winograd layers: x -> split-f16 V)", "wino_input_kernel")]
+                   ("wino_input_kernel (input transform of the Winograd layers: x -> split-f16 V)", "wino_input_kernel"),
+                   ("pnp_hypotheses_kernel (5-point EPnP models, fp64)", "pnp_hypotheses_kernel"),
+                   ("pnp_count_kernel (inlier counts of 8 models per pass over the correspondences)", "pnp_count_kernel"),
+                   ("pnp_score_kernel (OpenCV's rule on the counts + Gram sums of the best model's inliers)", "pnp_score_kernel"),
+                   ("pnp_fit_solve_kernel + pnp_fit_select_kernel (refit on the inliers, final inlier mask)", "pnp_fit_"),
+                   ("aa_filter_kernel<0> (Gaussian pre-filter, first axis)", "aa_filter_kernel<0>"),
+                   ("aa_filter_kernel<1> (Gaussian pre-filter, second axis)", "aa_filter_kernel<1>"),
+                   ("cand_eval_kernel + cand_compact_kernel / cand_corr_kernel (stage-2 decode: back-resizes, masks, correspondences)", "cand_"),
+                   ("stage2_input_kernel (stage-2 crops: masked re-crop + resize to 128x128)", "stage2_input_kernel")]
 
 
 class KernelStats(C.Structure):

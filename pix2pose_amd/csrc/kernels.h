@@ -15,6 +15,21 @@ inline const char* dev_env(const char* name) { return getenv(name); }
 inline const char* dev_env(const char*) { return nullptr; }
 #endif
 
+// Measurement hook of the glue / PnP launches (p2p_profile_*, slots 12..19 of p2p_mi355.h): the entry points of the pipeline set it while
+// profiling is enabled on their context; a ProfScope around a launch then brackets it with HIP events on the stream it is launched on.
+struct ProfHook {
+    void* ctx;
+    void (*begin)(void* ctx, int slot, hipStream_t s);
+    void (*end)(void* ctx, hipStream_t s);
+};
+extern thread_local ProfHook g_prof_hook;
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(int slot, hipStream_t st) : s(st), on(g_prof_hook.ctx != nullptr) { if (on) g_prof_hook.begin(g_prof_hook.ctx, slot, s); }
+    ~ProfScope() { if (on) g_prof_hook.end(g_prof_hook.ctx, s); }
+};
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum EpiMode { EPI_NORMAL = 0, EPI_HEAD = 1 };
 enum Prec { PREC_F32 = 0, PREC_F16X3 = 1 };   // igemm arithmetic: fp32 MFMA, or fp32 emulated with 3 split-f16 MFMAs

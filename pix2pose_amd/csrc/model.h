@@ -97,6 +97,13 @@ struct Ctx {
     ~Ctx();
 };
 
+// Sets the glue / PnP measurement hook (kernels.h: ProfHook) for the calling thread while the context is profiling.
+struct ProfHookGuard {
+    ProfHook prev;
+    explicit ProfHookGuard(Ctx& X);
+    ~ProfHookGuard();
+};
+
 int forward_chunk(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp_dev);
 int forward_async(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp_dev);
 // one generator pass over the detections of several objects (same backbone), sorted by object:

@@ -1221,6 +1221,27 @@ int forward_async(Ctx& X, const Model& M, const float* x_dev, int n, float* xyzp
     return P2P_OK;
 }
 
+thread_local ProfHook g_prof_hook = {nullptr, nullptr, nullptr};
+static thread_local Ctx::ProfEvent g_open_ev;
+static void prof_hook_begin(void* c, int slot, hipStream_t s)
+{
+    Ctx& X = *static_cast<Ctx*>(c);
+    g_open_ev = Ctx::ProfEvent{X.prof_get_event(), X.prof_get_event(), slot, 0.0, 0.0};
+    if (g_open_ev.a) (void)hipEventRecord(g_open_ev.a, s);
+}
+static void prof_hook_end(void* c, hipStream_t s)
+{
+    Ctx& X = *static_cast<Ctx*>(c);
+    if (!g_open_ev.a || !g_open_ev.b) return;
+    (void)hipEventRecord(g_open_ev.b, s);
+    X.prof_pending.push_back(g_open_ev);
+}
+ProfHookGuard::ProfHookGuard(Ctx& X) : prev(g_prof_hook)
+{
+    if (X.profiling) g_prof_hook = ProfHook{&X, prof_hook_begin, prof_hook_end};
+}
+ProfHookGuard::~ProfHookGuard() { g_prof_hook = prev; }
+
 hipEvent_t Ctx::prof_get_event()
 {
     if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
@@ -1236,6 +1257,7 @@ int Ctx::prof_harvest()
     for (Lane& ln : lane)
         if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipDeviceSynchronize());      // the glue / PnP slots are recorded on the pipeline's tail streams
     for (const ProfEvent& ev : prof_pending) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));

@@ -1580,7 +1580,10 @@ static int enqueue_mid(Ctx& X, Slot& SL, hipStream_t st, float* y1)
         hipLaunchKernelGGL(keep_filter_kernel, dim3(n * K), dim3(256), 0, st, d_det, d_s1, y1, K, aat, const_cast<unsigned char*>(SL.aa.keepf));
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, SL.x2.as<float>(), SL.aa);
+    {
+        ProfScope ps(19, st);
+        hipLaunchKernelGGL(stage2_input_kernel, dim3(n * K * 64), dim3(256), 0, st, d_det, d_s1, y1, K, SL.x2.as<float>(), SL.aa);
+    }
     HIP_TRY(hipGetLastError());
     return P2P_OK;
 }
@@ -1613,6 +1616,8 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
 
     // -- correspondences, PnP-RANSAC, selection
     static const bool corr_split = dev_env("P2P_CORR_SPLIT") == nullptr || atoi(dev_env("P2P_CORR_SPLIT")) != 0;      // development switch (A/B)
+    {
+    ProfScope ps_corr(18, st);
     if ((n * K <= 16 || SL.max_side > 192) && corr_split) {        // evaluate on CORR_SEG CUs per candidate, then compact (see cand_eval_kernel)
         hipLaunchKernelGGL(cand_eval_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, y2, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(), d_cr, aa);
         hipLaunchKernelGGL(cand_compact_kernel, dim3(CORR_SEG, n * K), dim3(256), 0, st, d_det, d_s1, K, SL.crec.as<unsigned>(), SL.cseg.as<CorrSeg>(),
@@ -1620,6 +1625,7 @@ static int enqueue_tail(Pipeline& P, Slot& SL, hipStream_t st, bool async)
     } else
         hipLaunchKernelGGL(cand_corr_kernel, dim3(n * K), dim3(glue_nt), 0, st, d_det, d_s1, y2, K, SL.corr.as<float>(),
                            SL.cand.as<CandStat>(), SL.probs.as<PnpProblem>(), d_cr, aa);
+    }
     HIP_TRY(hipGetLastError());
     const int iters = opt.ransac_iterations > 0 ? opt.ransac_iterations : 100;
     const double rerr = opt.reprojection_error > 0 ? opt.reprojection_error : 5.0;
@@ -1901,6 +1907,7 @@ int p2p_est_pose_submit(p2p_ctx* ctx, const p2p_object* objects, int n_objects, 
         return P2P_ERR_INVALID_ARG;
     }
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    ProfHookGuard prof_guard(*c);
     HIP_TRY(hipSetDevice(c->device));
     p2p_est_pose_opts o;
     memset(&o, 0, sizeof(o));
@@ -1912,6 +1919,7 @@ int p2p_est_pose_collect(p2p_ctx* ctx, int ticket, p2p_pose* poses)
 {
     if (!ctx || !poses) { set_error("p2p_est_pose_collect: bad arguments"); return P2P_ERR_INVALID_ARG; }
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    ProfHookGuard prof_guard(*c);
     HIP_TRY(hipSetDevice(c->device));
     return collect_est_pose(*c, ticket, poses);
 }
@@ -1921,6 +1929,7 @@ int p2p_est_pose_collect_gathered(p2p_ctx* ctx, p2p_comm* comm, int ticket, p2p_
     // (argument errors are local: nothing was enqueued and the caller's peers are its own to unblock; poses may be null for an empty shard)
     if (!ctx || !comm || !gathered || n_max < 1 || (!poses && ticket != P2P_TICKET_NONE)) { set_error("p2p_est_pose_collect_gathered: bad arguments"); return P2P_ERR_INVALID_ARG; }
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    ProfHookGuard prof_guard(*c);
     HIP_TRY(hipSetDevice(c->device));
     return collect_est_pose(*c, ticket, poses, reinterpret_cast<Comm*>(comm), n_max, gathered);
 }
@@ -2004,6 +2013,7 @@ int p2p_est_pose_batch(p2p_ctx* ctx, const p2p_object* objects, int n_objects, c
     }
     if (n_dets == 0) return P2P_OK;
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    ProfHookGuard prof_guard(*c);
     HIP_TRY(hipSetDevice(c->device));
     p2p_est_pose_opts o;
     memset(&o, 0, sizeof(o));
@@ -2025,6 +2035,7 @@ int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double* obj_pts
     }
     if (n_problems == 0) return P2P_OK;
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    ProfHookGuard prof_guard(*c);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int N = offsets[n_problems];

@@ -1664,8 +1664,11 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
     for (int r = 0; r < 3; ++r) {
         const int ppb = 1;          // a wave per problem: 16 hypotheses x 4 lanes
         const int wpp = (std::min(stops[r], iterations) - h_begin + pnp::HYP_ROUND0 - 1) / pnp::HYP_ROUND0;      // waves per problem: 16 hypotheses each
-        hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems * wpp + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
-                           min_points, h_begin, stops[r], ppb, act, r, wpp);
+        {
+            ProfScope ps(12, s);
+            hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems * wpp + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
+                               min_points, h_begin, stops[r], ppb, act, r, wpp);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // counts of the round's hypotheses: work items (problem, chunk of 8 hypotheses, slice of the points) walked by a bounded grid.
         // Slices: 16 384 points each (the 128-px crop), more of them when the launch would not fill the chip otherwise
@@ -1675,15 +1678,22 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
         int slices = std::max((max_points + 8 * per_trip - 1) / (8 * per_trip), 512 / std::max(1, n_problems * nchunks));
         slices = std::max(1, std::min(slices, (max_points + per_trip - 1) / per_trip));
         const long long items = (long long)n_problems * nchunks * slices;
-        hipLaunchKernelGGL(pnp::pnp_count_kernel, dim3((unsigned)std::min<long long>(items, 8192)), dim3(pnp::COUNT_NT), 0, s, probs, workspace, fits, act,
-                           iterations, reproj_err, min_points, h_begin, stops[r], nchunks, slices, r, n_problems);
+        {
+            ProfScope ps(13, s);
+            hipLaunchKernelGGL(pnp::pnp_count_kernel, dim3((unsigned)std::min<long long>(items, 8192)), dim3(pnp::COUNT_NT), 0, s, probs, workspace, fits, act,
+                               iterations, reproj_err, min_points, h_begin, stops[r], nchunks, slices, r, n_problems);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(pnp::SCORE_NT), 0, s, probs, workspace, results, fits, iterations,
-                           reproj_err, confidence, min_points, h_begin, stops[r], r == 0 ? 1 : 0, act, r, n_problems);
+        {
+            ProfScope ps(14, s);
+            hipLaunchKernelGGL(pnp::pnp_score_kernel, dim3(n_problems), dim3(pnp::SCORE_NT), 0, s, probs, workspace, results, fits, iterations,
+                               reproj_err, confidence, min_points, h_begin, stops[r], r == 0 ? 1 : 0, act, r, n_problems);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         h_begin = stops[r];
         if (iterations <= h_begin) break;
     }
+    ProfScope ps(15, s);
     hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((12 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);

@@ -261,8 +261,8 @@ hipError_t launch_aa_filter(AaItem* items, int n_items, int max_elems, hipStream
     const int bx = std::max(1, std::min(256, (max_elems / AA_V1 + 255) / 256));      // a thread takes AA_V1 .. AA_V0 outputs (grid-stride loop: any grid is complete)
     for (int i0 = 0; i0 < n_items; i0 += 65535) {        // gridDim.y limit
         const int ni = std::min(65535, n_items - i0);
-        hipLaunchKernelGGL((aa_filter_kernel<0>), dim3(bx, ni), dim3(256), 0, s, items + i0);
-        hipLaunchKernelGGL((aa_filter_kernel<1>), dim3(bx, ni), dim3(256), 0, s, items + i0);
+        { ProfScope ps(16, s); hipLaunchKernelGGL((aa_filter_kernel<0>), dim3(bx, ni), dim3(256), 0, s, items + i0); }
+        { ProfScope ps(17, s); hipLaunchKernelGGL((aa_filter_kernel<1>), dim3(bx, ni), dim3(256), 0, s, items + i0); }
     }
     hipLaunchKernelGGL(aa_range_finish_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, items, n_items);
     return hipGetLastError();
