@@ -393,7 +393,8 @@ def main():
         # algorithmic MAC, so its ceiling is the dense f16 peak / 3; the fp32 mode is priced against the fp32-MFMA peak
         # The Winograd form of the 5x5 layers (profile slot 10) forms 10 products where the direct form has 25: 3 x 10 / 25 = 1.2 MFMA FLOPs
         # per algorithmic FLOP (algo_flops stays the DIRECT form's 2 x MACs of the layer)
-        mfma_per_algo = (1.2 if dom == 10 else 3.0) if precision == "f16x3" else 1.0
+        # (the F(4,3) form of the transposed convolutions, slot 20: 15 position-products per input pixel where the four phases have 25: 1.8)
+        mfma_per_algo = {10: 1.2, 20: 1.8}.get(dom, 3.0) if precision == "f16x3" else 1.0
         peak = PEAK_F16_MFMA_TFLOPS / mfma_per_algo if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         r = {"bound": "mfma", "kernel": "%s: %s" % (dom_name, dom_label),
              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
@@ -428,6 +429,7 @@ def main():
         for i, label in ((5, "decoder output heads"), (9, "ResNet identity bottleneck blocks, fused: 1x1 -> 3x3 -> 1x1 + residual in one launch (block input read once + "
                                                           "its 3x3 halo, output written once; the three-launch route moved 2x these bytes)"),
                          (11, "input transform of the Winograd layers (x read once, the split-f16 V -- two positions per input column, 8 bytes per element -- written once)"),
+                         (21, "input transform of the Winograd transposed convolutions up2 / up3 (x read once, the split-f16 V -- 6 bytes per element -- written once)"),
                          (0, "1x1 layers of the projection blocks res2a / res3a (+ dense_dec)"), (1, "Cout = 64 1x1 layers (res2a 2a)")):
             st = stats[i]
             if not st["launches"] or st["total_ms"] <= 0:

@@ -386,10 +386,12 @@ P2P_API int p2p_pnp_ransac_batch(p2p_ctx* ctx, const double* camK, const double*
  *      bench.py prices them on the batch's correspondence / pixel counts):  12 pnp_hypotheses_kernel   13 pnp_count_kernel   14 pnp_score_kernel
  *      15 pnp_fit_solve_kernel + pnp_fit_select_kernel   16 aa_filter_kernel<0>   17 aa_filter_kernel<1>
  *      18 cand_eval_kernel + cand_compact_kernel (or cand_corr_kernel)   19 stage2_input_kernel
+ *   20 wino3_gemm_kernel (the transposed convolutions up2 / up3 in Winograd F(4,3) form along the row axis: 15 position-products per input
+ *      pixel instead of 25; algo_flops = the DIRECT form's 2 x MACs)     21 wino3_input_kernel (its input transform; algo_flops 0)
  * algo_flops counts the layers' algorithmic FLOPs (2 x MACs of the reference layer, SURVEY.md
  * section 8a-L), not padded work and not the 3 MFMA products per MAC of the split-f16 arithmetic.
  * ---------------------------------------------------------------------------------------- */
-#define P2P_PROFILE_SLOTS 20
+#define P2P_PROFILE_SLOTS 22
 typedef struct {
     int64_t launches;
     double total_ms;

@@ -210,5 +210,94 @@ def main():
             json.dump(report, f, indent=1)
 
 
+# ------------------------------------------------------------------ round 6, second study: the stride-2 transposed convolutions
+# (`up1/2/3`, reference pix2pose_model/ae_model.py:201-204,212-215,222-225) as four sub-pixel phases, each a (2|3) x (2|3)-tap correlation on
+# the INPUT grid; along the row axis the 3-tap (or zero-extended 2-tap) filter in F(4, 3) form: 6 products per 4 outputs and vertical
+# tap instead of 12 (8).  `python -m oracle.wino_study --up` reports the network error with deconv1/2/3 in their shipped F(4,5) form and
+# the three transposed layers in F(4,3) form on top.
+def deconv_phases_wino(x, k, mats):
+    """x [N,Cin,H,W] fp32, k (kh,kw,Cout,Cin) fp32 -> [N,Cout,2H,2W] (no bias).  mats = cook_toom(4, 3, ...) or None = direct phases."""
+    n, c, h, w = x.shape
+    cout = k.shape[2]
+    out = torch.zeros(n, cout, 2 * h, 2 * w, dtype=torch.float32)
+    for py in (0, 1):
+        for px in (0, 1):
+            g = torch.zeros(3, 3, c, cout, dtype=torch.float64)       # [dy + 1][dx + 1][ci][co]
+            for dy in (-1, 0, 1):
+                kh = py + 1 - 2 * dy
+                if not 0 <= kh < 5:
+                    continue
+                for dx in (-1, 0, 1):
+                    kw = px + 1 - 2 * dx
+                    if 0 <= kw < 5:
+                        g[dy + 1, dx + 1] = k[kh, kw].double().t()
+            xp = F.pad(x, (1, 1, 1, 1))
+            if mats is None:
+                cols = xp.unfold(2, 3, 1).unfold(3, 3, 1)            # [N,C,H,W,3,3]
+                gs, inv = prescale_cout(g.float())
+                y = mm3(cols, gs, "nchwyx,yxco->nohw") * inv.view(1, -1, 1, 1)
+            else:
+                AT, G, BT = mats
+                tiles = xp.unfold(3, 6, 4)                             # [N,C,H+2,T,6]
+                v = torch.einsum("nchtp,jp->nchtj", tiles, torch.from_numpy(BT).float())
+                rows = v.unfold(2, 3, 1)                               # [N,C,H,T,6,3(dy)]
+                u = torch.einsum("jx,yxco->jyco", torch.from_numpy(G), g).float()
+                us, inv = prescale_cout(u)
+                mm = mm3(rows, us, "nchtjy,jyco->nohtj")
+                y = torch.einsum("nohtj,ij->nohti", mm, torch.from_numpy(AT).float()).reshape(n, cout, h, w) * inv.view(1, -1, 1, 1)
+            out[:, :, py::2, px::2] = y
+    return out
+
+
+def main_up():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pix2pose_amd import weights as W
+    torch.set_num_threads(8)
+    rs = np.random.RandomState(0)
+    x = ((rs.randint(0, 256, (2, 128, 128, 3)).astype(np.float32)) - 128) / 128
+    conv5 = make_conv("1d_F4_pm1_pm2_pmhalf")
+    f43 = cook_toom(4, 3, [0, 1, -1, 2, -2])
+    report = {}
+    for backbone in ("resnet50", "paper"):
+        for fam, w in (("synthetic", W.synthetic_weights(backbone, 3)), ("trained_like", W.trained_like_weights(backbone, 5))):
+            d0, p0, _ = ae_torch.forward(w, x, backbone, torch.float64)
+            for label, ups, mats in (("deconv F(4,5) only", (), None), ("+ up2/up3 direct phases (split-f16)", ("up2", "up3"), None),
+                                     ("+ up2/up3 F(4,3)", ("up2", "up3"), f43), ("+ up1/up2/up3 F(4,3)", ("up1", "up2", "up3"), f43)):
+                orig_c, orig_d = ae_torch._conv, ae_torch._deconv
+                layer_err = {}
+
+                def pc(xx, ww, name, stride, same, dt):
+                    if name in ("deconv1", "deconv2", "deconv3"):
+                        y = conv5(xx.float(), torch.from_numpy(ww[name + ".kernel"]).float())
+                        return y.double() + torch.from_numpy(ww[name + ".bias"]).double().view(1, -1, 1, 1)
+                    return orig_c(xx, ww, name, stride, same, dt)
+
+                def pd(xx, ww, name, dt):
+                    if name in ups:
+                        ref = orig_d(xx, ww, name, dt)
+                        y = deconv_phases_wino(xx.float(), torch.from_numpy(ww[name + ".kernel"]).float(), mats)
+                        y = y.double() + torch.from_numpy(ww[name + ".bias"]).double().view(1, -1, 1, 1)
+                        layer_err[name] = float((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+                        return y
+                    return orig_d(xx, ww, name, dt)
+
+                ae_torch._conv, ae_torch._deconv = pc, pd
+                try:
+                    dec, prob, _ = ae_torch.forward(w, x, backbone, torch.float64)
+                finally:
+                    ae_torch._conv, ae_torch._deconv = orig_c, orig_d
+                e = max(float(np.abs(dec - d0).max()), float(np.abs(prob - p0).max()))
+                report["%s/%s/%s" % (backbone, fam, label)] = {"net_out_max_abs_err": e, "layer_rel_rms": layer_err}
+                print("%-9s %-13s %-40s net |d|max %.3e  %s" % (backbone, fam, label, e, "  ".join("%s %.1e" % kv for kv in layer_err.items())), flush=True)
+    return report
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if "--up" in sys.argv:
+        rep = main_up()
+        with open("profiles/r06_wino_up_error_study.json", "w") as f:
+            json.dump(rep, f, indent=1)
+    else:
+        main()

@@ -78,7 +78,7 @@ class EstPoseOpts(C.Structure):
                 ("resize_anti_aliasing", C.c_int), ("merge_stream_passes", C.c_int), ("mask_prezeroed", C.c_int)]
 
 
-PROFILE_SLOTS = 20    # P2P_PROFILE_SLOTS
+PROFILE_SLOTS = 22    # P2P_PROFILE_SLOTS
 # kernel family of each slot: (label, substring of the rocprofv3 kernel name; %d = precision template argument)
 PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"),
                    ("igemm_kernel 128x64 tiles", "igemm_kernel<2, 2, 2, 1, %d>"),
@@ -99,7 +99,9 @@ PROFILE_KERNELS = [("igemm_kernel 128x128 tiles", "igemm_kernel<2, 2, 2, 2, %d>"
                    ("aa_filter_kernel<0> (Gaussian pre-filter, first axis)", "aa_filter_kernel<0>"),
                    ("aa_filter_kernel<1> (Gaussian pre-filter, second axis)", "aa_filter_kernel<1>"),
                    ("cand_eval_kernel + cand_compact_kernel / cand_corr_kernel (stage-2 decode: back-resizes, masks, correspondences)", "cand_"),
-                   ("stage2_input_kernel (stage-2 crops: masked re-crop + resize to 128x128)", "stage2_input_kernel")]
+                   ("stage2_input_kernel (stage-2 crops: masked re-crop + resize to 128x128)", "stage2_input_kernel"),
+                   ("wino3_gemm_kernel (transposed convolutions up2 / up3, Winograd F(4,3) along the row axis: six position GEMMs for the four phases + inverse transform)", "wino3_gemm_kernel"),
+                   ("wino3_input_kernel (input transform of the Winograd transposed convolutions: x -> split-f16 V)", "wino3_input_kernel")]
 
 
 class KernelStats(C.Structure):

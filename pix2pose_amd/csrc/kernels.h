@@ -204,6 +204,31 @@ int wino_gemm_grid(const WinoParams& p);
 hipError_t launch_wino_input(const WinoParams& p, hipStream_t s);
 hipError_t launch_wino_gemm(const WinoParams& p, hipStream_t s);
 
+// Winograd F(4,3) along the row axis for Conv2DTranspose 5x5 stride 2 'SAME' (wino3.hip): the four sub-pixel phases as 3-tap correlations on
+// the input grid sharing ONE input transform -- 15 position-products per input pixel instead of 25.  Two launches like wino.hip: the input
+// transform writes V (split-f16, 6 bytes per input element), the GEMM kernel serves all four phases.  U (model.hip: pack_wino3), fragment order:
+//   [py 2][px 2][Cout / 64][position 6][Cin / 16][ky 2 + py][(32-channel half 0 hi, half 0 lo, half 1 hi, half 1 lo)][lane 64][8 halves]
+struct Wino3Params {
+    const float* in;       // [N, H, W, Cin]
+    unsigned in_bytes;
+    int N, H, W, Cin, Cout;
+    float* V;              // wino3_v_bytes(N, H, W, Cin)
+    const float* U;
+    const float* scale;    // [4 phases][Cout]: folded BatchNorm times the inverse of the phase panel's per-channel pre-scale
+    const float* shift;    // [Cout]
+    int act;
+    float alpha;
+    float* out;            // [N, 2H, 2W, out_cstride], channels [out_coff, out_coff + Cout)
+    int out_cstride, out_coff;
+    unsigned* range_acc;
+    int n_groups;          // mixed-object batches, as in WinoParams (grp[g].scale = that object's [4][Cout] array)
+    WinoGroup grp[IGEMM_MAX_GROUPS + 1];
+};
+bool wino3_supported(int H, int W, int Cin, int Cout);
+size_t wino3_v_bytes(int N, int H, int W, int Cin);
+hipError_t launch_wino3_input(const Wino3Params& p, hipStream_t s);
+hipError_t launch_wino3_gemm(const Wino3Params& p, hipStream_t s);
+
 // Small-batch variant (igemm_stream.hip): one wave per 32x32 / 64x32 output tile, operands streamed global -> registers with a deep
 // software pipeline.  Bit-identical to the batched kernel that serves the layer: every output element is the same chain of MFMAs over
 // the same K-step order, which StreamOrder describes as that kernel's loop nest -- for g in groups: for slice: for tap in group g.

@@ -321,6 +321,81 @@ static int pack_wino(const TensorMap& T, const std::string& name, int Cin, int C
     return P2P_OK;
 }
 
+// Winograd F(4,3) panel of a Conv2DTranspose 5x5 stride-2 layer (wino3.hip), beside the four direct phase panels: for phase (py, px)
+//   U_j[ky][ci][co] = sum_dx G[j][dx + 1] k[py + 1 - 2 (ky - 1)][px + 1 - 2 dx][co][ci]      (taps outside the 5x5 kernel are zero)
+// computed in double, rounded to fp32, pre-scaled per (phase, output channel) by a power of two, split hi / lo, stored in the order the
+// GEMM kernel's waves stream it: [py][px][Cout / 64][position 6][Cin / 16][ky 2 + py][fragment 4][lane 64][8 halves].
+static const double kWino3G[6][3] = {
+    {1.0 / 4, 0.0, 0.0},
+    {-1.0 / 6, -1.0 / 6, -1.0 / 6},
+    {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+    {1.0 / 24, 1.0 / 12, 1.0 / 6},
+    {1.0 / 24, -1.0 / 12, 1.0 / 6},
+    {0.0, 0.0, 1.0}};
+
+static int pack_wino3(const TensorMap& T, const std::string& name, int Cin, int Cout, ConvLayer& L)
+{
+    if (L.prec != PREC_F16X3 || Cin % 32 || Cout % 64) return P2P_OK;       // strict-fp32 models keep the direct phases only
+    const float* k = T.get(name + ".kernel", (int64_t)25 * Cin * Cout);      // (kh, kw, Cout, Cin)
+    if (!k) return P2P_ERR_WEIGHTS;
+    const int S = Cin / 16, NT = Cout / 64;
+    const size_t per_co = (size_t)6 * 3 * Cin;                               // [j][ky][ci]; ky >= 2 + py stays zero
+    std::vector<float> U((size_t)4 * Cout * per_co, 0.f);
+    std::vector<float> rs((size_t)4 * Cout, 1.f);
+    parallel_rows((size_t)4 * Cout, per_co * 3, [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const int ph = (int)(r / Cout), co = (int)(r % Cout), py = ph >> 1, px = ph & 1;
+            float* u = U.data() + r * per_co;
+            for (int j = 0; j < 6; ++j)
+                for (int ky = 0; ky < 2 + py; ++ky) {
+                    const int kh = py + 1 - 2 * (ky - 1);
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        double a = 0.0;
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int kw = px + 1 - 2 * dx;
+                            if (kw >= 0 && kw < 5) a += kWino3G[j][dx + 1] * (double)k[(((size_t)kh * 5 + kw) * Cout + co) * Cin + ci];
+                        }
+                        u[((size_t)j * 3 + ky) * Cin + ci] = (float)a;
+                    }
+                }
+            rs[r] = f16x3_row_scale(u, per_co);
+        }
+    });
+    const size_t stream0 = (size_t)S * 2 * 4 * 512, stream1 = (size_t)S * 3 * 4 * 512;      // halves of one (phase, channel tile, position) stream
+    const size_t halves = (size_t)2 * NT * 6 * (stream0 + stream1) + 4 * 512;                // + one K-step of padding (the kernel loads one ahead)
+    std::vector<float> panel((halves + 1) / 2, 0.f);
+    uint16_t* o = reinterpret_cast<uint16_t*>(panel.data());
+    parallel_rows((size_t)4 * NT * 6, stream1, [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const int j = (int)(r % 6), nt = (int)((r / 6) % NT), ph = (int)(r / 6 / NT), py = ph >> 1, px = ph & 1, nky = 2 + py;
+            uint16_t* base = o + (py ? (size_t)2 * NT * 6 * stream0 : 0) + (size_t)((px * NT + nt) * 6 + j) * (py ? stream1 : stream0);
+            for (int s = 0; s < S; ++s)
+                for (int ky = 0; ky < nky; ++ky)
+                    for (int f = 0; f < 4; ++f)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = nt * 64 + (f >> 1) * 32 + (lane & 31);
+                            const float sc = rs[(size_t)ph * Cout + co];
+                            const float* u = U.data() + ((size_t)ph * Cout + co) * per_co + ((size_t)j * 3 + ky) * Cin + s * 16 + (lane >> 5) * 8;
+                            uint16_t* dst = base + ((((size_t)s * nky + ky) * 4 + f) * 64 + lane) * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = u[e] * sc;
+                                const uint16_t hi = f32_to_f16(v);
+                                dst[e] = (f & 1) ? f32_to_f16(v - f16_to_f32(hi)) : hi;
+                            }
+                        }
+        }
+    });
+    std::vector<float> scale, shift, scale4((size_t)4 * Cout);
+    int rc = fold_bn(T, name, Cout, true, scale, shift);
+    if (rc) return rc;
+    for (int ph = 0; ph < 4; ++ph)
+        for (int c = 0; c < Cout; ++c) scale4[(size_t)ph * Cout + c] = scale[c] * (1.f / rs[(size_t)ph * Cout + c]);      // exact: a power of two
+    if ((rc = upload(panel, &L.wino_u))) return rc;
+    if ((rc = upload(scale4, &L.wino_scale))) return rc;
+    L.wino_bytes = panel.size() * sizeof(float);
+    return P2P_OK;
+}
+
 // First-layer (Cin=3) direct-conv panel: [kh*kw*3][Cout] (branches concatenated along Cout).
 static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& names, int KH, int cout_each,
                            ConvLayer& L)
@@ -508,6 +583,8 @@ static int build_decoder(const TensorMap& T, Model& M, int skip3, int skip2, int
             ConvLayer& L = M.L[std::string(u.n) + "_p" + std::to_string(ph)];
             if ((rc = pack_deconv_phase(T, u.n, u.cin, u.cout, ph >> 1, ph & 1, L, true))) return rc;
         }
+    for (int i = 1; i < 3; ++i)          // Winograd F(4,3) panel of up2 / up3, kept with the layer's phase-0 entry (wino3.hip serves the 16x16 and 32x32 input grids)
+        if ((rc = pack_wino3(T, ups[i].n, ups[i].cin, ups[i].cout, M.L[std::string(ups[i].n) + "_p0"]))) return rc;
     if ((rc = pack_conv(T, {"deconv1"}, 5, 256 + skip3, 256, 2, true, M.L["deconv1"]))) return rc;
     if ((rc = pack_conv(T, {"deconv2"}, 5, 128 + skip2, 256, 2, true, M.L["deconv2"]))) return rc;
     if ((rc = pack_conv(T, {"deconv3"}, 5, 64 + skip1, 128, 2, true, M.L["deconv3"]))) return rc;
@@ -914,9 +991,58 @@ static int concat_conv(Ctx& X, const ConvLayer& L, const float* a, int Ca, const
 }
 
 // Conv2DTranspose 5x5/2 + BN + LeakyReLU as four phase convolutions
+// The transposed convolutions of split-f16 models on 16x16 / 32x32 input grids in Winograd F(4,3) form (wino3.hip), same switch as the
+// stride-1 layers (p2p_ctx_set_winograd).  0 = not for this route, 1 = done, < 0 = error.
+constexpr int WINO3_MIN_INPUTS = 8;
+static bool wino3_route() { static const bool on = dev_env("P2P_NO_WINO3") == nullptr; return on; }     // development builds: A/B against the direct phases
+
+static int try_wino3(Ctx& X, const ConvLayer& L, const float* in, int N, int H, int C, float* out)
+{
+    if (!L.wino_u || L.prec != PREC_F16X3 || X.wino_mode == P2P_WINOGRAD_OFF || !specialised_kernels() || !wino3_route() || !wino3_supported(H, H, C, L.Cout)) return 0;
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < WINO3_MIN_INPUTS) return 0;
+    const size_t px = (size_t)N * H * H;
+    const size_t b0 = px * C * sizeof(float);
+    if (b0 >= 0xFFFFFFF0ull || L.wino_bytes >= 0xFFFFFFF0ull) return 0;
+    Wino3Params p;
+    memset(&p, 0, sizeof(p));
+    p.in = in; p.in_bytes = (unsigned)b0;
+    p.N = N; p.H = H; p.W = H; p.Cin = C; p.Cout = L.Cout;
+    p.V = X.cur->act["wv"];
+    p.U = L.wino_u; p.scale = L.wino_scale; p.shift = L.shift;
+    p.act = ACT_LEAKY; p.alpha = LEAKY;
+    p.out = out; p.out_cstride = L.Cout; p.out_coff = 0;
+    p.range_acc = X.range_cur;
+    if (X.grp && X.grp->models.size() > 1) {
+        const GroupCtx& G = *X.grp;
+        const int ng = (int)G.models.size();
+        if (ng > IGEMM_MAX_GROUPS) { set_error("deconv_layer: %d object groups exceed IGEMM_MAX_GROUPS", ng); return P2P_ERR_CAPACITY; }
+        int unit0 = 0;                  // 16x16 grids: two samples per workgroup, every object paired up on its own
+        for (int g = 0; g < ng; ++g) {
+            const ConvLayer& Lg = G.models[g]->L.at(L.name);
+            if (!Lg.wino_u || Lg.prec != PREC_F16X3) { set_error("deconv_layer: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
+            p.grp[g] = {Lg.wino_u, Lg.wino_scale, Lg.shift, G.start[g], unit0};
+            unit0 += (G.start[g + 1] - G.start[g] + 1) / 2;
+        }
+        p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng], unit0};
+        p.n_groups = ng;
+    }
+    hipStream_t st = X.cur->stream;
+    const double in_el = (double)px * C, out_el = 4.0 * (double)px * L.Cout;
+    int rc = timed_launch(X, 21, 0.0, 4.0 * in_el + 6.0 * in_el, [&]() { return launch_wino3_input(p, st); });
+    if (rc) return rc;
+    // algorithmic work of the LAYER: 25 taps over the four phases = 6.25 MACs per output element and input channel
+    rc = timed_launch(X, 20, 2.0 * out_el * 6.25 * C, 6.0 * in_el + (double)L.wino_bytes + 4.0 * out_el, [&]() { return launch_wino3_gemm(p, st); });
+    return rc ? rc : 1;
+}
+
 static int deconv_layer(Ctx& X, const Model& M, const char* name, const float* in, int N, int H, int C,
                         float* out)
 {
+    {
+        const int rc = try_wino3(X, M.L.at(std::string(name) + "_p0"), in, N, H, C, out);
+        if (rc < 0) return rc;
+        if (rc == 1) return P2P_OK;
+    }
     PreparedConv pc[4];
     bool all_stream = true;
     for (int ph = 0; ph < 4; ++ph) {

@@ -1,0 +1,402 @@
+// Winograd / Cook-Toom minimal filtering F(4, 3) ALONG THE ROW AXIS for the stride-2 transposed convolutions up2 / up3 (gfx950, PREC_F16X3).
+//
+// Conv2DTranspose 5x5 / 2 'SAME' (reference pix2pose_model/ae_model.py:212-215,222-225) is four sub-pixel phases: phase
+// (py, px) is a correlation ON THE INPUT GRID with (2 + py) x (2 + px) taps at offsets dy, dx in {-1, 0, +1}:
+//
+//     out[2y + py][2x + px] = sum_{dy, dx, c} x[y + dy][x + dx][c] * w[py + 1 - 2 dy][px + 1 - 2 dx][c][co]
+//
+// Along a row both column phases are 3-tap filters (the 2-tap one zero-extended), so ONE input transform serves all four phases:
+//
+//     out[2y + py][2 (4t + i) + px] = sum_j AT[i][j] * ( sum_{dy, c} V_j[y + dy][t][c] * U^{py,px}_j[dy][c][co] ),
+//     V_j = sum_p BT[j][p] x[4t - 1 + p],   U_j = sum_dx G[j][dx + 1] w[..][px + 1 - 2 dx]          points {0, +-1, +-2, inf}
+//
+// 6 products per 4 outputs and vertical tap instead of 12 (8): 15 position-products per input pixel for the four phases instead of 25.
+// Arithmetic as in wino.hip: transforms in fp32, the 22-bit hi/lo f16 split AFTER the transform, three MFMA products per block, fp32
+// accumulation, fp32 inverse transform.  Error study: profiles/r06_wino_up_error_study.json (layer 8e-7 relative rms against 3.4e-7 of the
+// direct phases; the network output moves from 3.2e-5 to 4.0e-5 of the fp64 graph in the worst weight family).
+//
+// Two kernels:
+//   wino3_input_kernel  x -> V in HBM, split, plane layout [n][patch column][16-channel slice][plane = (j, hi/lo, k half)][row][tile 0..3][8 halves]
+//                       (6 bytes per input element).
+//   wino3_gemm_kernel   768 threads = 12 waves: wave (j, ch) owns position j and 32 of the tile's 64 output channels: 128 (y, t) pairs x 32
+//                       channels = 64 accumulator registers -- six positions on four SIMDs need a multiple of four waves, and three waves per
+//                       SIMD leave 168 registers each.  Per K-step (one vertical tap of a 16-channel slice): 8 V fragments from LDS, 2 U
+//                       fragments straight from global (the same 4 KB per 24 MFMAs of L2 traffic as wino.hip), 12 MFMAs.  The two waves of
+//                       a position stage its four planes together (hi planes / lo planes), so the slices are separated by a workgroup
+//                       barrier.  A tile = (patch, phase, 64-channel tile); a phase with py = 0 walks 2 K-steps per slice, py = 1 three --
+//                       the phase a workgroup serves rotates with the sweep so that every CU gets the same mix.
+#include "kernels.h"
+
+#include <type_traits>
+
+namespace p2p {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// input transform.  Thread = (row of an 8-row block, tile t of the 16-column patch, channel quad of a 32-channel group), quads fastest.
+// ------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino3_input_kernel(const Wino3Params p)
+{
+    const int tid = threadIdx.x;
+    const int quad = tid & 7, t = (tid >> 3) & 3, r = tid >> 5;
+    int b = blockIdx.x;
+    const int rblocks = p.H >> 3;
+    const int rb = b % rblocks; b /= rblocks;
+    const int cgroups = p.Cin >> 5;
+    const int cg = b % cgroups; b /= cgroups;
+    const int PC = p.W >> 4;
+    const int pc = b % PC;
+    const int n = b / PC;
+    const int y = rb * 8 + r;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const unsigned c0 = (unsigned)(cg * 32 + quad * 4);
+    const int x0 = pc * 16 + t * 4 - 1;
+    const unsigned rowpix = (unsigned)((n * p.H + y) * p.W);
+    f32x4 d[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int x = x0 + k;
+        const unsigned off = (unsigned)x < (unsigned)p.W ? ((rowpix + (unsigned)x) * (unsigned)p.Cin + c0) * 4u : OOB;
+        d[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+    f32x4 v[6];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d0 = d[0][e], d1 = d[1][e], d2 = d[2][e], d3 = d[3][e], d4 = d[4][e], d5 = d[5][e];
+        // BT of F(4,3) at {0, 1, -1, 2, -2, inf}: integer coefficients, the order of operations is fixed
+        const float a12 = __builtin_fmaf(-4.f, d2, d4), b12 = __builtin_fmaf(-4.f, d1, d3);
+        const float a34 = d4 - d2, b34 = 2.f * (d3 - d1);
+        v[0][e] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+        v[1][e] = a12 + b12; v[2][e] = a12 - b12;
+        v[3][e] = a34 + b34; v[4][e] = a34 - b34;
+        v[5][e] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    }
+    const int S = p.Cin >> 4;
+    const int slice = cg * 2 + (quad >> 2), lk = (quad >> 1) & 1;
+    const size_t plane_bytes = (size_t)p.H * 64;
+    char* dst = reinterpret_cast<char*>(p.V) + ((((size_t)n * PC + pc) * S + slice) * 24 + lk) * plane_bytes + (size_t)y * 64 + t * 16 + (quad & 1) * 8;
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const f32x4 w = v[j];
+        amax = range_note4(amax, w);
+        const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(w[0], w[1]), h23 = __builtin_amdgcn_cvt_pkrtz(w[2], w[3]);
+        fp16x2 l01, l23;              // residuals are exact in fp32; round them to nearest
+        l01[0] = (__fp16)(w[0] - (float)h01[0]); l01[1] = (__fp16)(w[1] - (float)h01[1]);
+        l23[0] = (__fp16)(w[2] - (float)h23[0]); l23[1] = (__fp16)(w[3] - (float)h23[1]);
+        *reinterpret_cast<uint2*>(dst + (size_t)(j * 4) * plane_bytes) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+        *reinterpret_cast<uint2*>(dst + (size_t)(j * 4 + 2) * plane_bytes) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    }
+    range_commit(p.range_acc, amax);       // the transformed operand is what the split sees: up to 10x the activation
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// the six position GEMMs + inverse transform + epilogue
+// ------------------------------------------------------------------------------------------------------------------------------------
+// LDS image of one 16-channel slice: 24 planes [R rows][4 tiles][16 B].  Single: R = 34 = rows y0 - 1 .. y0 + 32 of one sample.
+// DUAL (16x16 grids, two samples per workgroup): R = 35 = [zero row | sample A's 16 | zero row | sample B's 16 | zero row].
+// m-tile i = 8 output rows x 4 tiles; its tap ky (dy = ky - 1) reads image rows base_i + ky + (0..7): base = 8 i, or {0, 8, 17, 25}.
+template <bool DUAL>
+__global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
+{
+    constexpr int R = DUAL ? 35 : 34;
+    constexpr int PLANE = R * 64;
+    constexpr int BUF = 24 * PLANE;
+    constexpr int XLD = 68;                         // exchange image: [position 6][pair 32][64 channels + 4] floats
+    constexpr int XBUF = 6 * 32 * XLD * 4;
+    static_assert(XBUF <= BUF, "two exchange images fit the two slice buffers");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = wv >> 1, ch = wv & 1;              // position, 32-channel half of the tile (and the hi / lo planes this wave stages)
+    const int li = lane & 31, lk = lane >> 5;
+
+    const int S = p.Cin >> 4;
+    const int PC = p.W >> 4;
+    const int RB = DUAL ? 1 : p.H >> 5;
+    const int NT = p.Cout >> 6;
+    const int G4 = 4 * NT;                           // tiles of one patch: (py, px, channel tile)
+    const int units = DUAL ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) >> 1) : p.N;
+    const int ntiles = units * PC * RB * G4;
+    const unsigned plane_bytes = (unsigned)p.H * 64u;
+    const unsigned slice_bytes = 24u * plane_bytes;
+    const size_t unit_block = (size_t)S * slice_bytes;           // bytes of one (sample, patch column)
+
+    // XCD-aware order (block b runs on XCD b % 8): every sweep of gridDim.x tiles is cut into contiguous runs per XCD, the tiles of one
+    // patch next to each other: the workgroups that share a V patch run on one XCD at the same time
+    int tl0;
+    {
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        tl0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int pair = tid >> 4, cq = tid & 15;       // epilogue role (threads 0..511)
+    float amax = 0.f;
+
+    for (int tl = tl0; tl < ntiles; tl += gridDim.x) {
+    int rest = tl / G4;
+    // the phase rotates with the sweep: a workgroup's tiles would otherwise all be of one phase (gridDim.x is a multiple of G4), and the
+    // phases with py = 1 are 1.5x the work of the others
+    const int ph = (tl % G4 + (rest * G4) / (int)gridDim.x) % G4;
+    const int ntile = ph % NT, pyx = ph / NT;
+    const int py = pyx >> 1, px = pyx & 1;
+    const int rb = rest % RB; rest /= RB;
+    const int pc = rest % PC;
+    const int unit = rest / PC;
+    int n0 = DUAL ? unit * 2 : unit;
+    int n_end = p.N;                                 // first sample that is not this object's
+    const int y0 = rb * 32;
+    const float* gu = p.U;
+    const float* gscale = p.scale;
+    const float* gshift = p.shift;
+    if (p.n_groups > 1) {                            // groups are runs of samples; DUAL: every group is paired up on its own (unit0)
+        int g = 0;
+        if (DUAL) {
+            while (g + 1 < p.n_groups && p.grp[g + 1].unit0 <= unit) ++g;
+            n0 = p.grp[g].sample0 + 2 * (unit - p.grp[g].unit0);
+            n_end = p.grp[g + 1].sample0;
+        } else {
+            while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= n0) ++g;
+        }
+        gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
+    }
+    const bool has_b = DUAL && n0 + 1 < n_end;
+
+    // ---- V: global -> registers -> LDS.  This wave: the planes (j, hl = ch, lk = 0 / 1) in 1 KB pieces (16 rows x 4 tiles).
+    //      Single: piece q < 4 = rows [16 (q & 1), +16) of the image of plane lk = q >> 1; piece 4 = image rows 32, 33 of both planes (16 lanes).
+    //      DUAL:   piece q < 4 = sample q & 1 of plane lk = q >> 1.
+    const char* vbase = reinterpret_cast<const char*>(p.V) + ((size_t)n0 * PC + pc) * unit_block;
+    const unsigned vrange = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(has_b ? 2 * unit_block : unit_block));
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vrange, 0x00020000);
+    unsigned vo_a, vo_b, vo_c;
+    if (DUAL) {
+        vo_a = vo_b = vo_c = (unsigned)lane * 16u;
+    } else {
+        const int row = lane >> 2, t = lane & 3;
+        vo_b = (unsigned)((y0 + 15 + row) * 64 + t * 16);                                   // rows y0 + 15 .. y0 + 30: always inside
+        vo_a = y0 - 1 + row >= 0 ? vo_b - 1024u : OOB;                                      // rows y0 - 1 .. y0 + 14
+        const int yc = y0 + 31 + ((lane & 7) >> 2);                                         // rows y0 + 31, y0 + 32 of plane lk = lane >> 3
+        vo_c = (lane < 16 && yc < p.H) ? (unsigned)(lane >> 3) * plane_bytes + (unsigned)(yc * 64 + t * 16) : OOB;
+    }
+    char* wreg = smem + (j * 4 + ch * 2) * PLANE + lane * 16;
+    char* wreg_c = smem + (j * 4 + ch * 2 + ((lane >> 3) & 1)) * PLANE + 32 * 64 + (lane & 7) * 16;       // single: the tail piece
+    constexpr int NPIECE = DUAL ? 4 : 5;
+    f32x4 rv[NPIECE];
+    const unsigned so_w = (unsigned)(j * 4 + ch * 2) * plane_bytes;
+    auto vload_all = [&](int slice, bool on) {          // `on` is wave-uniform: off = out of range = no traffic
+        const unsigned so = (unsigned)slice * slice_bytes + so_w;
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) {
+            unsigned vo, sq = so;
+            bool o = on;
+            if (DUAL) {
+                sq += (unsigned)(q >> 1) * plane_bytes + ((q & 1) ? (unsigned)unit_block : 0u);
+                vo = vo_a;
+                if ((q & 1) && !has_b) o = false;
+            } else if (q < 4) {
+                sq += (unsigned)(q >> 1) * plane_bytes;
+                vo = (q & 1) ? vo_b : vo_a;
+            } else vo = vo_c;
+            rv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo | (o ? 0u : OOB), sq, 0));
+        }
+    };
+    auto vstore_all = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) {
+            if (DUAL) *reinterpret_cast<f32x4*>(wreg + buf * BUF + (q >> 1) * PLANE + ((q & 1) ? 18 : 1) * 64) = rv[q];
+            else if (q < 4) *reinterpret_cast<f32x4*>(wreg + buf * BUF + (q >> 1) * PLANE + (q & 1) * 1024) = rv[q];
+            else if (lane < 16) *reinterpret_cast<f32x4*>(wreg_c + buf * BUF) = rv[q];
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // V fragment of m-tile i, tap ky, half hl: plane (j, hl, lk), image row base_i + ky + (li >> 2), tile li & 3
+    const char* img0 = smem + (j * 4 + lk) * PLANE + (li >> 2) * 64 + (li & 3) * 16;
+
+    lds_barrier();                                   // (persistent loop) the previous tile's exchange image has been read
+    if (DUAL && lane < 48) {
+        // the three zero rows of this wave's two planes in both buffers (the exchange image overwrites them every tile)
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int bf = lane / 24, r2 = lane - bf * 24;
+        const int pl = r2 / 12, r3 = r2 - pl * 12;
+        const int zr = r3 >> 2, t = r3 & 3;
+        *reinterpret_cast<f32x4*>(smem + bf * BUF + (j * 4 + ch * 2 + pl) * PLANE + zr * 17 * 64 + t * 16) = z;      // rows 0, 17, 34
+    }
+
+    auto body = [&](auto nky_c) {
+        constexpr int NKY = decltype(nky_c)::value;
+        // U: this wave's stream (py, px, channel tile, position j): K-step kb = 4 fragments of 1 KB (tile half 0 hi, lo, half 1 hi, lo), of
+        // which this wave reads its half's two.  Panel: [py][px][channel tile][position][slice][ky][4 KB]; one K-step of padding at its end.
+        const size_t py_base = py ? (size_t)2 * NT * 6 * S * 2 * 4096 : 0;
+        const size_t stream = (size_t)((px * NT + ntile) * 6 + j) * S * NKY * 4096;
+        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(gu) + py_base + stream), 0,
+                                                                              (unsigned)((S * NKY + 1) * 4096), 0x00020000);
+        const unsigned uoff = (unsigned)lane * 16u + (unsigned)ch * 2048u;
+        f16x8 u[2][2];                               // (hi, lo) of the even / odd K-steps
+        auto uload = [&](int set, int kb) {
+            u[set][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff, kb * 4096, 0));
+            u[set][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + 1024u, kb * 4096, 0));
+        };
+        // prologue: slice 0 -> buffer 0
+        vload_all(0, true);
+        uload(0, 0);
+        vstore_all(0);
+        lds_barrier();
+        // two slices per iteration: buffer and weight register set of every K-step are compile-time
+        for (int s2 = 0; s2 < S; s2 += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int s = s2 + half;
+                vload_all(s + 1, s + 1 < S);                             // lands during this slice's matrix work
+#pragma unroll
+                for (int ky = 0; ky < NKY; ++ky) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int kk = half * NKY + ky;
+                    uload((kk + 1) & 1, s * NKY + ky + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const char* img = img0 + half * BUF;
+                    f16x8 vh[4], vl[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (DUAL ? (i < 2 ? 8 * i : 8 * i + 1) : 8 * i) + ky;
+                        vh[i] = *reinterpret_cast<const f16x8*>(img + row * 64);
+                        vl[i] = *reinterpret_cast<const f16x8*>(img + row * 64 + 2 * PLANE);
+                    }
+                    const f16x8* uc = u[kk & 1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[1], vh[i], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[0], vl[i], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[0], vh[i], acc[i], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                vstore_all(half ^ 1);                                    // (a slice past the last one: zeros nobody reads)
+                lds_barrier();
+            }
+        }
+    };
+    if (py) body(std::integral_constant<int, 3>{});
+    else body(std::integral_constant<int, 2>{});
+    // (the last slice's barrier: every wave is done with the planes, the exchange image may overwrite them)
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA with U as the A operand: row = channel (r & 3) + 8 (r >> 2) + 4 lk of the wave's 32,
+    //      column li = pair.  Pass i: the twelve waves put m-tile i into the exchange image, then thread (pair = tid >> 4, channel quad =
+    //      tid & 15) of the first eight waves combines the six positions into four output pixels of the phase.
+    const int col = ntile * 64 + cq * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 512) {
+        if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + pyx * p.Cout + col);
+        if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* X = reinterpret_cast<float*>(smem + (i & 1) * XBUF);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(X + (j * 32 + li) * XLD + ch * 32 + 8 * q + 4 * lk) = v;
+        }
+        lds_barrier();
+        if (tid < 512) {
+            f32x4 m[6];
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) m[jj] = *reinterpret_cast<const f32x4*>(X + (jj * 32 + pair) * XLD + cq * 4);
+            int n, y;
+            if (DUAL) { n = n0 + (i >> 1); y = (i & 1) * 8 + (pair >> 2); }
+            else { n = n0; y = y0 + i * 8 + (pair >> 2); }
+            if (!DUAL || n == n0 || has_b) {
+                const size_t pix = ((size_t)n * (2 * p.H) + (2 * y + py)) * (2 * p.W) + 2 * (pc * 16 + (pair & 3) * 4) + px;
+                float* o = p.out + pix * p.out_cstride + p.out_coff + col;
+                f32x4 yv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // AT of F(4,3): rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
+                    const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
+                    const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+                    yv[0][e] = (m[0][e] + s12) + s34;
+                    yv[1][e] = __builtin_fmaf(2.f, d34, d12);
+                    yv[2][e] = __builtin_fmaf(4.f, s34, s12);
+                    yv[3][e] = __builtin_fmaf(8.f, d34, d12) + m[5][e];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 v = yv[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
+                    } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                    }
+                    amax = range_note4(amax, v);
+                    *reinterpret_cast<f32x4*>(o + (size_t)(2 * k) * p.out_cstride) = v;
+                }
+            }
+        }
+    }
+    }   // tiles
+    range_commit(p.range_acc, amax);
+}
+
+}  // namespace
+
+bool wino3_supported(int H, int W, int Cin, int Cout)
+{
+    if (Cin % 32 || Cout % 64 || W % 16) return false;
+    return (H == 16 && W == 16) || H % 32 == 0;
+}
+
+// bytes of V for N samples
+size_t wino3_v_bytes(int N, int H, int W, int Cin) { return (size_t)N * H * W * Cin * 6; }
+
+hipError_t launch_wino3_input(const Wino3Params& p, hipStream_t s)
+{
+    const int grid = p.N * (p.W / 16) * (p.Cin / 32) * (p.H / 8);
+    hipLaunchKernelGGL(wino3_input_kernel, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino3_gemm(const Wino3Params& p, hipStream_t s)
+{
+    // persistent: one workgroup per CU walks the tiles; the grid is kept a multiple of the tiles of one patch (the phase rotation counts on it)
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const bool dual = p.H == 16;
+    const int g4 = 4 * (p.Cout / 64);
+    const int units = dual ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) / 2) : p.N * (p.H / 32);
+    const int tiles = units * (p.W / 16) * g4;
+    int grid = tiles < n_cu ? tiles : n_cu / g4 * g4;
+    if (grid < 1) grid = tiles < g4 ? tiles : g4;
+    if (dual) hipLaunchKernelGGL((wino3_gemm_kernel<true>), dim3(grid), dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((wino3_gemm_kernel<false>), dim3(grid), dim3(768), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace p2p

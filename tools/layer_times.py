@@ -65,9 +65,21 @@ def main(path, batch=256):
         out.append((nm, mmac))
         i += 1
     layers = out
-    # 5x5 stride-1 layers in Winograd form (wino.hip): two launches per layer -- the input transform, then the position GEMMs
-    out, i = [], 0
+    # 5x5 stride-1 layers in Winograd form (wino.hip) and transposed convolutions in Winograd F(4,3) form (wino3.hip): two launches per layer --
+    # the input transform, then the position GEMMs (all four phases of a transposed convolution in one launch)
+    out, i, skip = [], 0, ""
     for nm, mmac in layers:
+        if skip and nm.startswith(skip):
+            continue
+        if nm.endswith("_p0") and i < len(ks) and "wino3_input" in ks[i][0]:
+            b = nm.split("_")[0]
+            out.append((b + " V", 0))
+            KF[b + " V"] = {"up2": 66 * 2.5, "up3": 262 * 2.5}.get(b, 0)                              # x read once, V (1.5x the elements) written once
+            out.append((b + " gemm", sum(m for n2, m in layers if n2.startswith(b + "_p"))))
+            KF[b + " gemm"] = {"up2": 66 * 1.5 + 131, "up3": 262 * 1.5 + 262}.get(b, 0)
+            skip = b + "_p"
+            i += 2
+            continue
         if nm.startswith("deconv") and i < len(ks) and "wino_input" in ks[i][0]:
             out.append((nm + " V", 0))
             KF[nm + " V"] = {"deconv1": 3 * 98, "deconv2": 3 * 262, "deconv3": 3 * 393}.get(nm, 0)      # x read once, V (2x the elements) written once

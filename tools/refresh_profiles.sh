@@ -6,7 +6,7 @@
 #      --sys-trace / HIP trace domain) -- and the bench lines (default, 30 objects, strict fp32, 2 ranks on one device)
 #   2. here: summarise the rocpd databases into profiles/
 set -e
-R=${1:-r05}
+R=${1:-r06}
 PROF="--steps 3 --warmup 1 --blocking --no-legs"
 PMC="--steps 1 --warmup 1 --blocking --no-legs"
 /usr/local/graft/bin/gpurun --timeout 2400 -- '
@@ -39,8 +39,8 @@ python bench.py --gpus 2 --backend gloo --same-device --steps 3 --warmup 1 --no-
 python bench.py --steps 20 --warmup 3 --no-legs > gpurun_out/bench_k20.json 2>> gpurun_out/bench_final.err
 python bench.py --backbone paper --steps 20 --warmup 3 --no-legs > gpurun_out/bench_paper.json 2>> gpurun_out/bench_final.err
 timeout 300 tools/probe_kernel.sh resblock 256 > /dev/null 2>&1
-timeout 600 tools/ab_round.sh run 3 > gpurun_out/ab_round.log 2>&1
-timeout 300 tools/general_ab.sh > /dev/null 2>&1
+[ -d tools/ab/prev ] && timeout 600 tools/ab_round.sh run 3 > gpurun_out/ab_round.log 2>&1      # the A/B worktree travels only when .gpurunignore lets it
+[ -d tools/ab/prev ] && timeout 300 tools/general_ab.sh > /dev/null 2>&1
 timeout 200 tools/batch_layers.sh 64 > /dev/null 2>&1
 (python tools/soak_est_pose.py 60 2 7000; python tools/soak_est_pose.py 40 1 7100; python tools/soak_est_pose.py 25 0 7200) 2>/dev/null | grep -E "^soak|MISMATCH" > gpurun_out/soak.txt
 cat gpurun_out/gpu_tests.log; tail -c 300 gpurun_out/bench_final.json
@@ -63,7 +63,7 @@ cp gpurun_out/gpu_tests.log profiles/${R}_gpu_tests.log
 # the real libraries of the image's second interpreter (scikit-image 0.18.3, h5py 3.3.0): HDF5 reader on real files, fixtures re-derived
 (echo "# /opt/conda/bin/python3.9 -m pytest tests/test_convert_keras.py"; PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 -W ignore -m pytest tests/test_convert_keras.py -q -p no:cacheprovider 2>&1 | tail -3
  echo "# python -m pytest tests/test_real_libraries_cpu.py tests/test_external_vectors.py tests/test_reference_vectors_cpu.py"; python -m pytest tests/test_real_libraries_cpu.py tests/test_external_vectors.py tests/test_reference_vectors_cpu.py -q -m "not gpu" 2>&1 | tail -3) > profiles/${R}_real_libraries.log
-for f in layers_b64:layer_times_b64 probe_resblock:resblock_counters r05_vs_prev:vs_prev r05_general_ab:general_ab r05_general_crops_aa_kernel_stats:general_crops_aa_kernel_stats_ab soak:soak; do
+for f in layers_b64:layer_times_b64 probe_resblock:resblock_counters ${R}_vs_prev:vs_prev ${R}_general_ab:general_ab ${R}_general_crops_aa_kernel_stats:general_crops_aa_kernel_stats_ab soak:soak; do
     [ -f gpurun_out/${f%%:*}.txt ] && cp gpurun_out/${f%%:*}.txt profiles/${R}_${f##*:}.txt
 done
 [ -f gpurun_out/pnp_exact_match.json ] && cp gpurun_out/pnp_exact_match.json profiles/${R}_pnp_exact_match.json
