@@ -450,7 +450,7 @@ hipError_t launch_splitk_reduce(const float* partial, int ksplit, int M, int Cou
 // per-object bias of dense_enc).  ONE launch for the batch (a launch per object cost 13 us each: 0.4 ms per 30-object pass); the sum
 // order over the K slabs and the epilogue expression are those of splitk_reduce_kernel, so the bits are the same.
 __global__ __launch_bounds__(256) void splitk_reduce_groups_kernel(const float* __restrict__ partial, int ksplit, int M, int Cout, const Conv1Groups G,
-                                                                    float* __restrict__ out, unsigned* __restrict__ range_acc)
+                                                                    int act, float alpha, float* __restrict__ out, unsigned* __restrict__ range_acc)
 {
     const int m = blockIdx.x;
     int g = 0;
@@ -463,18 +463,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_groups_kernel(const float* 
         const size_t o = (size_t)m * Cout + c;
         float s = 0.f;
         for (int z = 0; z < ksplit; ++z) s += partial[(size_t)z * slab + o];
-        const float v = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+        float v = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+        if (act == ACT_RELU) v = relu_nan(v);
+        else if (act == ACT_LEAKY) v = v > 0.f ? v : v * alpha;
         amax = range_note1(amax, v);
         out[o] = v;
     }
     range_commit(range_acc, amax);
 }
 
-hipError_t launch_splitk_reduce_groups(const float* partial, int ksplit, int M, int Cout, const Conv1Groups& G, float* out, unsigned* range_acc,
-                                       hipStream_t s)
+hipError_t launch_splitk_reduce_groups(const float* partial, int ksplit, int M, int Cout, const Conv1Groups& G, int act, float alpha, float* out,
+                                       unsigned* range_acc, hipStream_t s)
 {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(splitk_reduce_groups_kernel, dim3(M), dim3(256), 0, s, partial, ksplit, M, Cout, G, out, range_acc);
+    hipLaunchKernelGGL(splitk_reduce_groups_kernel, dim3(M), dim3(256), 0, s, partial, ksplit, M, Cout, G, act, alpha, out, range_acc);
     return hipGetLastError();
 }
 

@@ -229,6 +229,34 @@ size_t wino3_v_bytes(int N, int H, int W, int Cin);
 hipError_t launch_wino3_input(const Wino3Params& p, hipStream_t s);
 hipError_t launch_wino3_gemm(const Wino3Params& p, hipStream_t s);
 
+// The same F(4,3) form for the two stride-2 layers on an 8x8 grid (wino3o.hip): mode 0 = Conv2DTranspose 5x5 / 2 (up1: 8x8 -> 16x16, panel of
+// pack_wino3), mode 1 = Conv2D 5x5 / 2 'SAME' (conv4: 16x16 -> 8x8 through the four parity planes, panel of pack_wino3_s2:
+//   [Cout / 64][position 6][K-steps: even rows (column parity, Cin / 16, ky 2), odd rows (column parity, Cin / 16, ky 3)][fragment 4][lane 64][8 halves]).
+// A workgroup tile is eight samples of one object (grp[g].unit0 = first unit of object g).
+struct Wino3oParams {
+    const float* in;       // mode 0: [N, 8, 8, Cin]; mode 1: [N, 16, 16, Cin]
+    unsigned in_bytes;
+    int N, Cin, Cout;
+    float* V;              // wino3o_v_bytes(mode, units, Cin)
+    const float* U;
+    const float* scale;    // mode 0: [4 phases][Cout]; mode 1: [Cout]
+    const float* shift;    // [Cout]
+    int act;
+    float alpha;
+    float* out;            // mode 0: [N, 16, 16, out_cstride]; mode 1: [N, 8, 8, out_cstride]
+    int out_cstride, out_coff;
+    int ksplit;            // mode 1: 1, or 4 = one workgroup per parity plane, raw sums into `partial` [4][N * 64][Cout] (then launch_splitk_reduce)
+    float* partial;
+    unsigned* range_acc;
+    int n_groups;
+    WinoGroup grp[IGEMM_MAX_GROUPS + 1];
+};
+bool wino3o_supported(int mode, int Cin, int Cout);
+size_t wino3o_v_bytes(int mode, int units, int Cin);
+int wino3o_units(const Wino3oParams& p);
+hipError_t launch_wino3o_input(const Wino3oParams& p, int mode, hipStream_t s);
+hipError_t launch_wino3o_gemm(const Wino3oParams& p, int mode, hipStream_t s);
+
 // Small-batch variant (igemm_stream.hip): one wave per 32x32 / 64x32 output tile, operands streamed global -> registers with a deep
 // software pipeline.  Bit-identical to the batched kernel that serves the layer: every output element is the same chain of MFMAs over
 // the same K-step order, which StreamOrder describes as that kernel's loop nest -- for g in groups: for slice: for tap in group g.
@@ -288,9 +316,9 @@ struct Conv1Groups {
     const float* scale[IGEMM_MAX_GROUPS];
     const float* shift[IGEMM_MAX_GROUPS];
 };
-// The split-K reduction of a mixed-object batch: rows [start[g], start[g + 1]) take object g's scale / shift (G.w unused); no activation.
-hipError_t launch_splitk_reduce_groups(const float* partial, int ksplit, int M, int Cout, const Conv1Groups& G, float* out, unsigned* range_acc,
-                                       hipStream_t s);
+// The split-K reduction of a mixed-object batch: rows [start[g], start[g + 1]) take object g's scale / shift (G.w unused).
+hipError_t launch_splitk_reduce_groups(const float* partial, int ksplit, int M, int Cout, const Conv1Groups& G, int act, float alpha, float* out,
+                                       unsigned* range_acc, hipStream_t s);
 hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Conv1Groups& G, int act, float alpha, float* out, float* pool_out,
                               unsigned* range_acc, hipStream_t s);
 

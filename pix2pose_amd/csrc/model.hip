@@ -396,6 +396,86 @@ static int pack_wino3(const TensorMap& T, const std::string& name, int Cin, int 
     return P2P_OK;
 }
 
+// Winograd F(4,3) panel of a Conv2D 5x5 stride-2 'SAME' layer on an 8x8 output grid (wino3o.hip, mode 1), beside the direct panel: on the
+// parity plane (a, b) of the input the layer is a (2 + a) x (2 + b)-tap correlation (odd planes: kernel index 2 (d + 1) at offset d = -1, 0, 1;
+// even planes: 2 d + 1 at d = 0, 1), so
+//   U_j[a][b][ky][ci][co] = sum_dx G[j][dx + 1] k[kh(a, ky)][kw(b, dx)][ci][co],   kh(1, ky) = 2 ky, kh(0, ky) = 2 ky + 1, kw(1, dx) = 2 dx + 2, kw(0, dx) = 2 dx + 1
+// stored [Cout / 64][position 6][a = 0: (b, Cin / 16, ky 2) | a = 1: (b, Cin / 16, ky 3)][fragment 4][lane 64][8 halves].  Branches are concatenated along Cout.
+static int pack_wino3_s2(const TensorMap& T, const std::vector<std::string>& names, int Cin, int cout_each, ConvLayer& L)
+{
+    const int nb = (int)names.size(), Cout = cout_each * nb;
+    if (L.prec != PREC_F16X3 || Cin % 32 || Cout % 64) return P2P_OK;
+    const int S = Cin / 16, NT = Cout / 64;
+    const size_t per_co = (size_t)6 * 10 * Cin;                              // [j][(a, b, ky): 10 combinations][ci]
+    std::vector<float> U((size_t)Cout * per_co, 0.f);
+    std::vector<float> rs((size_t)Cout, 1.f);
+    static const int comb_a[10] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1}, comb_b[10] = {0, 0, 1, 1, 0, 0, 0, 1, 1, 1}, comb_ky[10] = {0, 1, 0, 1, 0, 1, 2, 0, 1, 2};
+    for (int br = 0; br < nb; ++br) {
+        const float* k = T.get(names[br] + ".kernel", (int64_t)25 * Cin * cout_each);      // (kh, kw, Cin, Cout)
+        if (!k) return P2P_ERR_WEIGHTS;
+        parallel_rows((size_t)cout_each, per_co * 3, [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; ++c) {
+                float* u = U.data() + ((size_t)br * cout_each + c) * per_co;
+                for (int j = 0; j < 6; ++j)
+                    for (int q = 0; q < 10; ++q) {
+                        const int a = comb_a[q], b = comb_b[q], ky = comb_ky[q];
+                        const int kh = a ? 2 * ky : 2 * ky + 1;
+                        for (int ci = 0; ci < Cin; ++ci) {
+                            double acc = 0.0;
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                const int kw = b ? 2 * dx + 2 : 2 * dx + 1;
+                                if (kw >= 0 && kw < 5) acc += kWino3G[j][dx + 1] * (double)k[(((size_t)kh * 5 + kw) * Cin + ci) * cout_each + c];
+                            }
+                            u[((size_t)j * 10 + q) * Cin + ci] = (float)acc;
+                        }
+                    }
+                rs[(size_t)br * cout_each + c] = f16x3_row_scale(u, per_co);
+            }
+        });
+    }
+    const size_t stream = (size_t)10 * S * 4 * 512;                          // halves of one (channel tile, position) stream
+    const size_t halves = (size_t)NT * 6 * stream + 4 * 512;                 // + one K-step of padding
+    std::vector<float> panel((halves + 1) / 2, 0.f);
+    uint16_t* o = reinterpret_cast<uint16_t*>(panel.data());
+    parallel_rows((size_t)NT * 6, stream, [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const int j = (int)(r % 6), nt = (int)(r / 6);
+            uint16_t* base = o + r * stream;
+            size_t kb = 0;
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int sl = 0; sl < S; ++sl)
+                        for (int ky = 0; ky < 2 + a; ++ky, ++kb) {
+                            int q = 0;
+                            while (comb_a[q] != a || comb_b[q] != b || comb_ky[q] != ky) ++q;
+                            for (int f = 0; f < 4; ++f)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int co = nt * 64 + (f >> 1) * 32 + (lane & 31);
+                                    const float sc = rs[co];
+                                    const float* u = U.data() + (size_t)co * per_co + ((size_t)j * 10 + q) * Cin + sl * 16 + (lane >> 5) * 8;
+                                    uint16_t* dst = base + ((kb * 4 + f) * 64 + lane) * 8;
+                                    for (int e = 0; e < 8; ++e) {
+                                        const float v = u[e] * sc;
+                                        const uint16_t hi = f32_to_f16(v);
+                                        dst[e] = (f & 1) ? f32_to_f16(v - f16_to_f32(hi)) : hi;
+                                    }
+                                }
+                        }
+        }
+    });
+    std::vector<float> scale, shift;
+    for (int br = 0; br < nb; ++br) {
+        int rc = fold_bn(T, names[br], cout_each, true, scale, shift);
+        if (rc) return rc;
+    }
+    for (int c = 0; c < Cout; ++c) scale[c] *= 1.f / rs[c];          // exact: a power of two
+    int rc;
+    if ((rc = upload(panel, &L.wino_u))) return rc;
+    if ((rc = upload(scale, &L.wino_scale))) return rc;
+    L.wino_bytes = panel.size() * sizeof(float);
+    return P2P_OK;
+}
+
 // First-layer (Cin=3) direct-conv panel: [kh*kw*3][Cout] (branches concatenated along Cout).
 static int pack_conv_first(const TensorMap& T, const std::vector<std::string>& names, int KH, int cout_each,
                            ConvLayer& L)
@@ -583,7 +663,7 @@ static int build_decoder(const TensorMap& T, Model& M, int skip3, int skip2, int
             ConvLayer& L = M.L[std::string(u.n) + "_p" + std::to_string(ph)];
             if ((rc = pack_deconv_phase(T, u.n, u.cin, u.cout, ph >> 1, ph & 1, L, true))) return rc;
         }
-    for (int i = 1; i < 3; ++i)          // Winograd F(4,3) panel of up2 / up3, kept with the layer's phase-0 entry (wino3.hip serves the 16x16 and 32x32 input grids)
+    for (int i = 0; i < 3; ++i)          // Winograd F(4,3) panel of the layer, kept with its phase-0 entry (wino3o.hip serves the 8x8 input grid, wino3.hip 16x16 and 32x32)
         if ((rc = pack_wino3(T, ups[i].n, ups[i].cin, ups[i].cout, M.L[std::string(ups[i].n) + "_p0"]))) return rc;
     if ((rc = pack_conv(T, {"deconv1"}, 5, 256 + skip3, 256, 2, true, M.L["deconv1"]))) return rc;
     if ((rc = pack_conv(T, {"deconv2"}, 5, 128 + skip2, 256, 2, true, M.L["deconv2"]))) return rc;
@@ -616,6 +696,7 @@ static int build_model(const TensorMap& T, Model& M)
             if (b.sc && (rc = pack_conv(T, {n + "_1"}, 1, b.cin, b.f3, 0, true, M.L[n + "_1"]))) return rc;
         }
         if ((rc = pack_conv(T, {"conv4_1", "conv4_2"}, 5, 512, 256, 1, true, M.L["conv4"]))) return rc;
+        if ((rc = pack_wino3_s2(T, {"conv4_1", "conv4_2"}, 512, 256, M.L["conv4"]))) return rc;
         return build_decoder(T, M, 128, 128, 32);
     }
     if (M.backbone == P2P_BACKBONE_PAPER) {
@@ -623,6 +704,7 @@ static int build_model(const TensorMap& T, Model& M)
         if ((rc = pack_conv(T, {"conv2_1", "conv2_2"}, 5, 128, 128, 1, true, M.L["conv2"]))) return rc;
         if ((rc = pack_conv(T, {"conv3_1", "conv3_2"}, 5, 256, 128, 1, true, M.L["conv3"]))) return rc;
         if ((rc = pack_conv(T, {"conv4_1", "conv4_2"}, 5, 256, 256, 1, true, M.L["conv4"]))) return rc;
+        if ((rc = pack_wino3_s2(T, {"conv4_1", "conv4_2"}, 256, 256, M.L["conv4"]))) return rc;
         return build_decoder(T, M, 128, 128, 64);
     }
     set_error("unknown backbone %d", M.backbone);
@@ -993,11 +1075,67 @@ static int concat_conv(Ctx& X, const ConvLayer& L, const float* a, int Ca, const
 // Conv2DTranspose 5x5/2 + BN + LeakyReLU as four phase convolutions
 // The transposed convolutions of split-f16 models on 16x16 / 32x32 input grids in Winograd F(4,3) form (wino3.hip), same switch as the
 // stride-1 layers (p2p_ctx_set_winograd).  0 = not for this route, 1 = done, < 0 = error.
-constexpr int WINO3_MIN_INPUTS = 8;
+constexpr int WINO3_MIN_INPUTS = 8;       // up2 / up3 (measured: 8 inputs 806 vs 834 us per pass, 4 inputs 737 vs 731)
+constexpr int WINO3O_MIN_INPUTS = 16;     // up1 / conv4, eight samples per workgroup (measured with all four layers: 16 inputs 972 vs 1194 us, 8 inputs 840 vs 834)
 static bool wino3_route() { static const bool on = dev_env("P2P_NO_WINO3") == nullptr; return on; }     // development builds: A/B against the direct phases
+
+// The 8x8-grid layers (wino3o.hip): mode 0 = the transposed convolution up1, mode 1 = the stride-2 convolution conv4.
+static int try_wino3o(Ctx& X, const ConvLayer& L, int mode, const float* in, int N, int C, float* out)
+{
+    if (!L.wino_u || L.prec != PREC_F16X3 || X.wino_mode == P2P_WINOGRAD_OFF || !specialised_kernels() || !wino3_route() || !wino3o_supported(mode, C, L.Cout)) return 0;
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < WINO3O_MIN_INPUTS) return 0;
+    const size_t b0 = (size_t)N * (mode ? 256 : 64) * C * sizeof(float);
+    if (b0 >= 0xFFFFFFF0ull || L.wino_bytes >= 0xFFFFFFF0ull) return 0;
+    Wino3oParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = in; p.in_bytes = (unsigned)b0;
+    p.N = N; p.Cin = C; p.Cout = L.Cout;
+    p.V = X.cur->act["wv"];
+    p.U = L.wino_u; p.scale = L.wino_scale; p.shift = L.shift;
+    p.act = ACT_LEAKY; p.alpha = LEAKY;
+    p.out = out; p.out_cstride = L.Cout; p.out_coff = 0;
+    p.ksplit = 1;
+    p.range_acc = X.range_cur;
+    if (X.grp && X.grp->models.size() > 1) {
+        const GroupCtx& G = *X.grp;
+        const int ng = (int)G.models.size();
+        if (ng > IGEMM_MAX_GROUPS) { set_error("wino3o: %d object groups exceed IGEMM_MAX_GROUPS", ng); return P2P_ERR_CAPACITY; }
+        int unit0 = 0;                  // eight samples per workgroup, every object grouped on its own
+        for (int g = 0; g < ng; ++g) {
+            const ConvLayer& Lg = G.models[g]->L.at(L.name);
+            if (!Lg.wino_u || Lg.prec != PREC_F16X3) { set_error("wino3o: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
+            p.grp[g] = {Lg.wino_u, Lg.wino_scale, Lg.shift, G.start[g], unit0};
+            unit0 += (G.start[g + 1] - G.start[g] + 7) / 8;
+        }
+        p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng], unit0};
+        p.n_groups = ng;
+    }
+    const int units = wino3o_units(p);
+    if (wino3o_v_bytes(mode, units, C) > (size_t)X.max_batch * 64 * 64 * 128 * 2 * sizeof(float)) return 0;      // (many objects of a few detections each: the padded units outgrow the V workspace)
+    // conv4 on less than one workgroup per CU: K split over the four parity planes, the four partial sums added after the inverse transform.
+    // The split changes the order of the additions, so "always" -- the mode whose bits do not depend on the pass -- splits at every size.
+    if (mode == 1 && (X.wino_mode == P2P_WINOGRAD_ALWAYS || units * (L.Cout / 64) < 256)) { p.ksplit = 4; p.partial = X.cur->act["c3"]; }
+    hipStream_t st = X.cur->stream;
+    const double in_el = (double)N * (mode ? 256 : 64) * C, out_el = (double)N * (mode ? 64 : 256) * L.Cout;
+    int rc = timed_launch(X, 21, 0.0, 4.0 * in_el + 6.0 * in_el, [&]() { return launch_wino3o_input(p, mode, st); });
+    if (rc) return rc;
+    // algorithmic work of the LAYER: conv4 25 MACs per output element and input channel; up1 25 taps over its four phases = 6.25
+    rc = timed_launch(X, 20, 2.0 * out_el * (mode ? 25.0 : 6.25) * C, 6.0 * in_el + (double)L.wino_bytes + 4.0 * out_el, [&]() { return launch_wino3o_gemm(p, mode, st); });
+    if (rc) return rc;
+    if (p.ksplit > 1 && p.n_groups > 1) {
+        Conv1Groups G;
+        G.n_groups = p.n_groups;
+        for (int g = 0; g < p.n_groups; ++g) { G.start[g] = p.grp[g].sample0 * 64; G.w[g] = nullptr; G.scale[g] = p.grp[g].scale; G.shift[g] = p.grp[g].shift; }
+        G.start[p.n_groups] = N * 64;
+        HIP_TRY(launch_splitk_reduce_groups(p.partial, p.ksplit, N * 64, L.Cout, G, ACT_LEAKY, LEAKY, out, X.range_cur, st));
+    } else if (p.ksplit > 1)
+        HIP_TRY(launch_splitk_reduce(p.partial, p.ksplit, N * 64, L.Cout, L.wino_scale, L.shift, ACT_LEAKY, LEAKY, out, X.range_cur, st));
+    return 1;
+}
 
 static int try_wino3(Ctx& X, const ConvLayer& L, const float* in, int N, int H, int C, float* out)
 {
+    if (H == 8) return try_wino3o(X, L, 0, in, N, C, out);
     if (!L.wino_u || L.prec != PREC_F16X3 || X.wino_mode == P2P_WINOGRAD_OFF || !specialised_kernels() || !wino3_route() || !wino3_supported(H, H, C, L.Cout)) return 0;
     if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < WINO3_MIN_INPUTS) return 0;
     const size_t px = (size_t)N * H * H;
@@ -1253,7 +1391,8 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         if (dev_part() == 1) return P2P_OK;
     after_front:
 #endif
-        if ((rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 512, 2, A["f4"], ACT_LEAKY))) return rc;
+        if ((rc = try_wino3o(X, M.L.at("conv4"), 1, A["f3"], n, 512, A["f4"])) < 0) return rc;
+        if (rc == 0 && (rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 512, 2, A["f4"], ACT_LEAKY))) return rc;
         // ae_model.py:186-188: f1[..., :32], f2[..., :128], f3[..., :128]
         s1 = A["f1"]; s1_stride = 64; s1_off = 0; s1_C = 32;
         s2 = A["f2"]; s2_stride = 256; s2_off = 0;
@@ -1280,7 +1419,8 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
         }
         if ((rc = conv_layer(X, M.L.at("conv2"), A["f1"], n, 64, 64, 128, 2, A["f2"], ACT_LEAKY))) return rc;
         if ((rc = conv_layer(X, M.L.at("conv3"), A["f2"], n, 32, 32, 256, 2, A["f3"], ACT_LEAKY))) return rc;
-        if ((rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 256, 2, A["f4"], ACT_LEAKY))) return rc;
+        if ((rc = try_wino3o(X, M.L.at("conv4"), 1, A["f3"], n, 256, A["f4"])) < 0) return rc;
+        if (rc == 0 && (rc = conv_layer(X, M.L.at("conv4"), A["f3"], n, 16, 16, 256, 2, A["f4"], ACT_LEAKY))) return rc;
         s1 = A["f1"]; s1_stride = 128; s1_off = 64; s1_C = 64;
         s2 = A["f2"]; s2_stride = 256; s2_off = 128;
         s3 = A["f3"]; s3_stride = 256; s3_off = 128;
@@ -1306,7 +1446,7 @@ int forward_chunk(Ctx& X, const Model& M, const float* x, int n, float* xyzp)
                 G.start[g] = g0(g); G.w[g] = nullptr; G.scale[g] = Lg.scale; G.shift[g] = Lg.shift;
             }
             G.start[n_grp] = n;
-            HIP_TRY(launch_splitk_reduce_groups(A["part"], 32, n, 256, G, A["enc"], M.prec == PREC_F16X3 ? X.range_cur : nullptr, st));
+            HIP_TRY(launch_splitk_reduce_groups(A["part"], 32, n, 256, G, ACT_NONE, LEAKY, A["enc"], M.prec == PREC_F16X3 ? X.range_cur : nullptr, st));
         }
     }
     {

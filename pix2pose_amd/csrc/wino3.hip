@@ -198,6 +198,9 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
     f32x4 rv[NPIECE];
     const unsigned so_w = (unsigned)(j * 4 + ch * 2) * plane_bytes;
     auto vload_all = [&](int slice, bool on) {          // `on` is wave-uniform: off = out of range = no traffic
+#ifdef P2P_ABL3_V
+        on = false;
+#endif
         const unsigned so = (unsigned)slice * slice_bytes + so_w;
 #pragma unroll
         for (int q = 0; q < NPIECE; ++q) {
@@ -251,27 +254,36 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
         const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(gu) + py_base + stream), 0,
                                                                               (unsigned)((S * NKY + 1) * 4096), 0x00020000);
         const unsigned uoff = (unsigned)lane * 16u + (unsigned)ch * 2048u;
-        f16x8 u[2][2];                               // (hi, lo) of the even / odd K-steps
+#ifdef P2P_W3_UDIST2
+        constexpr int UD = 2, RING = 4, USL = 4;     // U two K-steps ahead, four register sets, four slices per iteration (8 / 12 K-steps: multiples of the ring)
+#else
+        constexpr int UD = 1, RING = 2, USL = 2;     // U one K-step ahead, two register sets, two slices per iteration
+#endif
+        f16x8 u[RING][2];                            // (hi, lo) of the K-steps in flight
         auto uload = [&](int set, int kb) {
             u[set][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff, kb * 4096, 0));
             u[set][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + 1024u, kb * 4096, 0));
         };
         // prologue: slice 0 -> buffer 0
         vload_all(0, true);
-        uload(0, 0);
+#pragma unroll
+        for (int d = 0; d < UD; ++d) uload(d, d);
         vstore_all(0);
         lds_barrier();
-        // two slices per iteration: buffer and weight register set of every K-step are compile-time
-        for (int s2 = 0; s2 < S; s2 += 2) {
+        // USL slices per iteration: buffer and weight register set of every K-step are compile-time
+        for (int s2 = 0; s2 < S; s2 += USL) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int s = s2 + half;
+            for (int hs = 0; hs < USL; ++hs) {
+                const int half = hs & 1;
+                const int s = s2 + hs;
                 vload_all(s + 1, s + 1 < S);                             // lands during this slice's matrix work
 #pragma unroll
                 for (int ky = 0; ky < NKY; ++ky) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int kk = half * NKY + ky;
-                    uload((kk + 1) & 1, s * NKY + ky + 1);
+                    const int kk = hs * NKY + ky;
+#ifdef P2P_ABL3_U
+                    if (s2 == 0)
+#endif
+                    uload((kk + UD) % RING, s * NKY + ky + UD);          // (the panel's padding covers the K-steps past the stream's end)
                     __builtin_amdgcn_sched_barrier(0);
                     const char* img = img0 + half * BUF;
                     f16x8 vh[4], vl[4];
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
                         vh[i] = *reinterpret_cast<const f16x8*>(img + row * 64);
                         vl[i] = *reinterpret_cast<const f16x8*>(img + row * 64 + 2 * PLANE);
                     }
-                    const f16x8* uc = u[kk & 1];
+                    const f16x8* uc = u[kk % RING];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[1], vh[i], acc[i], 0, 0, 0);
@@ -291,7 +303,9 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 vstore_all(half ^ 1);                                    // (a slice past the last one: zeros nobody reads)
+#ifndef P2P_ABL3_BAR
                 lds_barrier();
+#endif
             }
         }
     };
@@ -308,6 +322,17 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
         if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + pyx * p.Cout + col);
         if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
     }
+#ifdef P2P_ABL3_EPI
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][r];
+        if (t == 123.456f) p.out[tid] = t;
+        continue;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float* X = reinterpret_cast<float*>(smem + (i & 1) * XBUF);
