@@ -18,13 +18,14 @@
 // Two kernels:
 //   wino3_input_kernel  x -> V in HBM, split, plane layout [n][patch column][16-channel slice][plane = (j, hi/lo, k half)][row][tile 0..3][8 halves]
 //                       (6 bytes per input element).
-//   wino3_gemm_kernel   768 threads = 12 waves: wave (j, ch) owns position j and 32 of the tile's 64 output channels: 128 (y, t) pairs x 32
-//                       channels = 64 accumulator registers -- six positions on four SIMDs need a multiple of four waves, and three waves per
-//                       SIMD leave 168 registers each.  Per K-step (one vertical tap of a 16-channel slice): 8 V fragments from LDS, 2 U
-//                       fragments straight from global (the same 4 KB per 24 MFMAs of L2 traffic as wino.hip), 12 MFMAs.  The two waves of
-//                       a position stage its four planes together (hi planes / lo planes), so the slices are separated by a workgroup
-//                       barrier.  A tile = (patch, phase, 64-channel tile); a phase with py = 0 walks 2 K-steps per slice, py = 1 three --
-//                       the phase a workgroup serves rotates with the sweep so that every CU gets the same mix.
+//   wino3_gemm_kernel   768 threads = 12 waves: six positions on four SIMDs need a multiple of four waves, and three waves per SIMD leave 168
+//                       registers each.  Wave (j, mh) owns position j of one of the tile's two 16-row units and all 64 output channels
+//                       (2 x 2 x 16 accumulators), stages its unit's rows of its position's planes itself (no workgroup barrier in the K
+//                       loop) and reads, per K-step (one vertical tap of a 16-channel slice), 4 V fragments from LDS and 4 U fragments
+//                       straight from global for 12 MFMAs.  A tile = (patch, phase, 64-channel tile); a phase with py = 0 walks 2 K-steps
+//                       per slice, py = 1 three -- the phase a workgroup serves rotates with the sweep so that every CU gets the same mix.
+//                       (First form, measured equal: wave = (position, 32-channel half) sharing the planes of a position through a
+//                       workgroup barrier per slice; timing ablations of both: tools/experiments/README.md.)
 #include "kernels.h"
 
 #include <type_traits>
@@ -104,33 +105,35 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const Wino3Params p)
 // ------------------------------------------------------------------------------------------------------------------------------------
 // the six position GEMMs + inverse transform + epilogue
 // ------------------------------------------------------------------------------------------------------------------------------------
-// LDS image of one 16-channel slice: 24 planes [R rows][4 tiles][16 B].  Single: R = 34 = rows y0 - 1 .. y0 + 32 of one sample.
-// DUAL (16x16 grids, two samples per workgroup): R = 35 = [zero row | sample A's 16 | zero row | sample B's 16 | zero row].
-// m-tile i = 8 output rows x 4 tiles; its tap ky (dy = ky - 1) reads image rows base_i + ky + (0..7): base = 8 i, or {0, 8, 17, 25}.
-template <bool DUAL>
+// Wave (j, mh) owns position j of one UNIT = 16 output rows x 16 columns of one sample (two m-tiles of 8 rows x 4 tiles) and all 64
+// channels of the tile: 2 x 2 x 16 accumulator registers.  A workgroup tile = two units: the two 16-row halves of a 32-row block (H >= 32)
+// or two samples (H = 16).  The wave stages ITS unit's rows of ITS position's four planes itself -- 18 rows (one halo row above and below:
+// out-of-image rows load as zeros) x 4 tiles x 16 B per plane, double-buffered -- so the K loop has no workgroup barrier; per K-step
+// (one vertical tap of a 16-channel slice) it reads 4 V fragments from LDS and 4 U fragments straight from global (4 KB per 12 MFMAs: the
+// L2 traffic per MFMA of wino.hip) for 12 MFMAs.
 __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
 {
-    constexpr int R = DUAL ? 35 : 34;
-    constexpr int PLANE = R * 64;
-    constexpr int BUF = 24 * PLANE;
+    constexpr int WPLANE = 18 * 64;                 // one plane of a wave's image
+    constexpr int WIMG = 4 * WPLANE;                // the four planes (hl, lk) of its position
+    constexpr int BUF = 12 * WIMG;
     constexpr int XLD = 68;                         // exchange image: [position 6][pair 32][64 channels + 4] floats
     constexpr int XBUF = 6 * 32 * XLD * 4;
-    static_assert(XBUF <= BUF, "two exchange images fit the two slice buffers");
+    static_assert(2 * XBUF <= 2 * BUF, "two exchange images fit the two slice buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = wv >> 1, ch = wv & 1;              // position, 32-channel half of the tile (and the hi / lo planes this wave stages)
+    const int j = wv >> 1, mh = wv & 1;              // position, unit of the workgroup tile
     const int li = lane & 31, lk = lane >> 5;
 
     const int S = p.Cin >> 4;
     const int PC = p.W >> 4;
-    const int RB = DUAL ? 1 : p.H >> 5;
+    const int UPS = p.H >> 4;                        // units per sample
     const int NT = p.Cout >> 6;
     const int G4 = 4 * NT;                           // tiles of one patch: (py, px, channel tile)
-    const int units = DUAL ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) >> 1) : p.N;
-    const int ntiles = units * PC * RB * G4;
+    const int wunits = UPS == 1 ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) >> 1) : p.N * (UPS >> 1);
+    const int ntiles = wunits * PC * G4;
     const unsigned plane_bytes = (unsigned)p.H * 64u;
     const unsigned slice_bytes = 24u * plane_bytes;
     const size_t unit_block = (size_t)S * slice_bytes;           // bytes of one (sample, patch column)
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
     }
     const int pair = tid >> 4, cq = tid & 15;       // epilogue role (threads 0..511)
     float amax = 0.f;
+    char* const wimg = smem + wv * WIMG;             // this wave's image in buffer 0
 
     for (int tl = tl0; tl < ntiles; tl += gridDim.x) {
     int rest = tl / G4;
@@ -154,168 +158,143 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
     const int ph = (tl % G4 + (rest * G4) / (int)gridDim.x) % G4;
     const int ntile = ph % NT, pyx = ph / NT;
     const int py = pyx >> 1, px = pyx & 1;
-    const int rb = rest % RB; rest /= RB;
     const int pc = rest % PC;
-    const int unit = rest / PC;
-    int n0 = DUAL ? unit * 2 : unit;
-    int n_end = p.N;                                 // first sample that is not this object's
-    const int y0 = rb * 32;
+    const int wunit = rest / PC;
+    // the two units of the tile: unit u = (sample tn0 + u, rows 0..15) on 16-row grids, (sample tn0, rows ty0 + 16 u ..) otherwise
+    int tn0, tn_end = p.N, ty0 = 0;
     const float* gu = p.U;
     const float* gscale = p.scale;
     const float* gshift = p.shift;
-    if (p.n_groups > 1) {                            // groups are runs of samples; DUAL: every group is paired up on its own (unit0)
-        int g = 0;
-        if (DUAL) {
-            while (g + 1 < p.n_groups && p.grp[g + 1].unit0 <= unit) ++g;
-            n0 = p.grp[g].sample0 + 2 * (unit - p.grp[g].unit0);
-            n_end = p.grp[g + 1].sample0;
-        } else {
-            while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= n0) ++g;
+    if (UPS == 1) {
+        tn0 = wunit * 2;
+        if (p.n_groups > 1) {                        // groups are runs of samples; every group is paired up on its own (unit0)
+            int g = 0;
+            while (g + 1 < p.n_groups && p.grp[g + 1].unit0 <= wunit) ++g;
+            tn0 = p.grp[g].sample0 + 2 * (wunit - p.grp[g].unit0);
+            tn_end = p.grp[g + 1].sample0;
+            gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
         }
-        gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
-    }
-    const bool has_b = DUAL && n0 + 1 < n_end;
-
-    // ---- V: global -> registers -> LDS.  This wave: the planes (j, hl = ch, lk = 0 / 1) in 1 KB pieces (16 rows x 4 tiles).
-    //      Single: piece q < 4 = rows [16 (q & 1), +16) of the image of plane lk = q >> 1; piece 4 = image rows 32, 33 of both planes (16 lanes).
-    //      DUAL:   piece q < 4 = sample q & 1 of plane lk = q >> 1.
-    const char* vbase = reinterpret_cast<const char*>(p.V) + ((size_t)n0 * PC + pc) * unit_block;
-    const unsigned vrange = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(has_b ? 2 * unit_block : unit_block));
-    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, vrange, 0x00020000);
-    unsigned vo_a, vo_b, vo_c;
-    if (DUAL) {
-        vo_a = vo_b = vo_c = (unsigned)lane * 16u;
     } else {
-        const int row = lane >> 2, t = lane & 3;
-        vo_b = (unsigned)((y0 + 15 + row) * 64 + t * 16);                                   // rows y0 + 15 .. y0 + 30: always inside
-        vo_a = y0 - 1 + row >= 0 ? vo_b - 1024u : OOB;                                      // rows y0 - 1 .. y0 + 14
-        const int yc = y0 + 31 + ((lane & 7) >> 2);                                         // rows y0 + 31, y0 + 32 of plane lk = lane >> 3
-        vo_c = (lane < 16 && yc < p.H) ? (unsigned)(lane >> 3) * plane_bytes + (unsigned)(yc * 64 + t * 16) : OOB;
+        const int hb = UPS >> 1;                     // 32-row blocks per sample
+        tn0 = wunit / hb; ty0 = (wunit % hb) * 32;
+        if (p.n_groups > 1) {
+            int g = 0;
+            while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= tn0) ++g;
+            gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
+        }
     }
-    char* wreg = smem + (j * 4 + ch * 2) * PLANE + lane * 16;
-    char* wreg_c = smem + (j * 4 + ch * 2 + ((lane >> 3) & 1)) * PLANE + 32 * 64 + (lane & 7) * 16;       // single: the tail piece
-    constexpr int NPIECE = DUAL ? 4 : 5;
-    f32x4 rv[NPIECE];
-    const unsigned so_w = (unsigned)(j * 4 + ch * 2) * plane_bytes;
+    const int n_me = UPS == 1 ? tn0 + mh : tn0;     // this wave's unit
+    const int y0 = UPS == 1 ? 0 : ty0 + mh * 16;
+    const bool have = n_me < tn_end;
+
+    // ---- V: global -> registers -> LDS, this wave's image: planes (j, hl, lk), rows y0 - 1 .. y0 + 16.
+    //      Piece q < 4 = image rows 0..15 of plane q (1 KB); piece 4 = image rows 16, 17 of the four planes (32 lanes).
+    const char* vbase = reinterpret_cast<const char*>(p.V) + ((size_t)(have ? n_me : 0) * PC + pc) * unit_block;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)unit_block, 0x00020000);
+    unsigned vo_a, vo_c;
+    {
+        const int row = lane >> 2, t = lane & 3;
+        const int ya = y0 - 1 + row;
+        vo_a = (have && ya >= 0) ? (unsigned)(ya * 64 + t * 16) : OOB;                       // (ya <= y0 + 14 < H)
+        const int yc = y0 + 15 + ((lane >> 2) & 1);
+        vo_c = (have && lane < 32 && yc < p.H) ? (unsigned)(lane >> 3) * plane_bytes + (unsigned)(yc * 64 + t * 16) : OOB;
+    }
+    char* wreg = wimg + lane * 16;
+    char* wreg_c = wimg + (lane >> 3) * WPLANE + 1024 + (lane & 7) * 16;
+    f32x4 rv[5];
+    const unsigned so_w = (unsigned)(j * 4) * plane_bytes;
     auto vload_all = [&](int slice, bool on) {          // `on` is wave-uniform: off = out of range = no traffic
 #ifdef P2P_ABL3_V
         on = false;
 #endif
+#ifdef P2P_ABL3_VHOT
+        slice = 0;                                   // timing experiment: every slice reads slice 0 again (L2-resident)
+#endif
         const unsigned so = (unsigned)slice * slice_bytes + so_w;
 #pragma unroll
-        for (int q = 0; q < NPIECE; ++q) {
-            unsigned vo, sq = so;
-            bool o = on;
-            if (DUAL) {
-                sq += (unsigned)(q >> 1) * plane_bytes + ((q & 1) ? (unsigned)unit_block : 0u);
-                vo = vo_a;
-                if ((q & 1) && !has_b) o = false;
-            } else if (q < 4) {
-                sq += (unsigned)(q >> 1) * plane_bytes;
-                vo = (q & 1) ? vo_b : vo_a;
-            } else vo = vo_c;
-            rv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo | (o ? 0u : OOB), sq, 0));
-        }
+        for (int q = 0; q < 5; ++q)
+            rv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, (q < 4 ? vo_a : vo_c) | (on ? 0u : OOB), q < 4 ? so + (unsigned)q * plane_bytes : so, 0));
     };
     auto vstore_all = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NPIECE; ++q) {
-            if (DUAL) *reinterpret_cast<f32x4*>(wreg + buf * BUF + (q >> 1) * PLANE + ((q & 1) ? 18 : 1) * 64) = rv[q];
-            else if (q < 4) *reinterpret_cast<f32x4*>(wreg + buf * BUF + (q >> 1) * PLANE + (q & 1) * 1024) = rv[q];
-            else if (lane < 16) *reinterpret_cast<f32x4*>(wreg_c + buf * BUF) = rv[q];
-        }
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(wreg + buf * BUF + q * WPLANE) = rv[q];
+        if (lane < 32) *reinterpret_cast<f32x4*>(wreg_c + buf * BUF) = rv[4];
     };
 
-    f32x16 acc[4];
+    f32x16 acc[2][2];                                // [m-tile of the unit][32-channel half]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
 
-    // V fragment of m-tile i, tap ky, half hl: plane (j, hl, lk), image row base_i + ky + (li >> 2), tile li & 3
-    const char* img0 = smem + (j * 4 + lk) * PLANE + (li >> 2) * 64 + (li & 3) * 16;
+    // V fragment of m-tile i, tap ky, half hl: plane (hl, lk) of the wave's image, row 8 i + ky + (li >> 2), tile li & 3
+    const char* img0 = wimg + lk * WPLANE + (li >> 2) * 64 + (li & 3) * 16;
 
-    lds_barrier();                                   // (persistent loop) the previous tile's exchange image has been read
-    if (DUAL && lane < 48) {
-        // the three zero rows of this wave's two planes in both buffers (the exchange image overwrites them every tile)
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const int bf = lane / 24, r2 = lane - bf * 24;
-        const int pl = r2 / 12, r3 = r2 - pl * 12;
-        const int zr = r3 >> 2, t = r3 & 3;
-        *reinterpret_cast<f32x4*>(smem + bf * BUF + (j * 4 + ch * 2 + pl) * PLANE + zr * 17 * 64 + t * 16) = z;      // rows 0, 17, 34
-    }
+    lds_barrier();                                   // (persistent loop) the previous tile's exchange images have been read
 
     auto body = [&](auto nky_c) {
         constexpr int NKY = decltype(nky_c)::value;
-        // U: this wave's stream (py, px, channel tile, position j): K-step kb = 4 fragments of 1 KB (tile half 0 hi, lo, half 1 hi, lo), of
-        // which this wave reads its half's two.  Panel: [py][px][channel tile][position][slice][ky][4 KB]; one K-step of padding at its end.
+        // U: the stream (py, px, channel tile, position j): K-step kb = 4 fragments of 1 KB (channel half 0 hi, lo, half 1 hi, lo).
+        // Panel: [py][px][channel tile][position][slice][ky][4 KB]; one K-step of padding at its end.
         const size_t py_base = py ? (size_t)2 * NT * 6 * S * 2 * 4096 : 0;
         const size_t stream = (size_t)((px * NT + ntile) * 6 + j) * S * NKY * 4096;
         const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(gu) + py_base + stream), 0,
                                                                               (unsigned)((S * NKY + 1) * 4096), 0x00020000);
-        const unsigned uoff = (unsigned)lane * 16u + (unsigned)ch * 2048u;
-#ifdef P2P_W3_UDIST2
-        constexpr int UD = 2, RING = 4, USL = 4;     // U two K-steps ahead, four register sets, four slices per iteration (8 / 12 K-steps: multiples of the ring)
-#else
-        constexpr int UD = 1, RING = 2, USL = 2;     // U one K-step ahead, two register sets, two slices per iteration
-#endif
-        f16x8 u[RING][2];                            // (hi, lo) of the K-steps in flight
+        const unsigned uoff = (unsigned)lane * 16u;
+        f16x8 u[2][4];                               // (half 0 hi, lo, half 1 hi, lo) of the even / odd K-steps
         auto uload = [&](int set, int kb) {
-            u[set][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff, kb * 4096, 0));
-            u[set][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + 1024u, kb * 4096, 0));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) u[set][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + f * 1024, kb * 4096, 0));
         };
         // prologue: slice 0 -> buffer 0
         vload_all(0, true);
-#pragma unroll
-        for (int d = 0; d < UD; ++d) uload(d, d);
+        uload(0, 0);
         vstore_all(0);
-        lds_barrier();
-        // USL slices per iteration: buffer and weight register set of every K-step are compile-time
-        for (int s2 = 0; s2 < S; s2 += USL) {
+        // two slices per iteration: buffer and weight register set of every K-step are compile-time
+        for (int s2 = 0; s2 < S; s2 += 2) {
 #pragma unroll
-            for (int hs = 0; hs < USL; ++hs) {
-                const int half = hs & 1;
-                const int s = s2 + hs;
+            for (int half = 0; half < 2; ++half) {
+                const int s = s2 + half;
                 vload_all(s + 1, s + 1 < S);                             // lands during this slice's matrix work
 #pragma unroll
                 for (int ky = 0; ky < NKY; ++ky) {
-                    const int kk = hs * NKY + ky;
+                    const int kk = half * NKY + ky;
 #ifdef P2P_ABL3_U
                     if (s2 == 0)
 #endif
-                    uload((kk + UD) % RING, s * NKY + ky + UD);          // (the panel's padding covers the K-steps past the stream's end)
+                    uload((kk + 1) & 1, s * NKY + ky + 1);               // (the panel's padding covers the K-step past the stream's end)
                     __builtin_amdgcn_sched_barrier(0);
-                    const char* img = img0 + half * BUF;
-                    f16x8 vh[4], vl[4];
+                    const char* img = img0 + half * BUF + ky * 64;
+                    f16x8 vh[2], vl[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int row = (DUAL ? (i < 2 ? 8 * i : 8 * i + 1) : 8 * i) + ky;
-                        vh[i] = *reinterpret_cast<const f16x8*>(img + row * 64);
-                        vl[i] = *reinterpret_cast<const f16x8*>(img + row * 64 + 2 * PLANE);
+                    for (int i = 0; i < 2; ++i) {
+                        vh[i] = *reinterpret_cast<const f16x8*>(img + i * 512);
+                        vl[i] = *reinterpret_cast<const f16x8*>(img + i * 512 + 2 * WPLANE);
                     }
-                    const f16x8* uc = u[kk % RING];
+                    const f16x8* uc = u[kk & 1];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[1], vh[i], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[0], vl[i], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[0], vh[i], acc[i], 0, 0, 0);
-                    }
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c + 1], vh[i], acc[i][c], 0, 0, 0);
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vl[i], acc[i][c], 0, 0, 0);
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vh[i], acc[i][c], 0, 0, 0);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 vstore_all(half ^ 1);                                    // (a slice past the last one: zeros nobody reads)
-#ifndef P2P_ABL3_BAR
-                lds_barrier();
-#endif
             }
         }
     };
     if (py) body(std::integral_constant<int, 3>{});
     else body(std::integral_constant<int, 2>{});
-    // (the last slice's barrier: every wave is done with the planes, the exchange image may overwrite them)
+    lds_barrier();                                   // every wave is done with its image: the exchange images may overwrite them
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA with U as the A operand: row = channel (r & 3) + 8 (r >> 2) + 4 lk of the wave's 32,
-    //      column li = pair.  Pass i: the twelve waves put m-tile i into the exchange image, then thread (pair = tid >> 4, channel quad =
-    //      tid & 15) of the first eight waves combines the six positions into four output pixels of the phase.
+    // ---- epilogue.  C/D layout of the 32x32 MFMA with U as the A operand: row = channel (r & 3) + 8 (r >> 2) + 4 lk of the 32-channel
+    //      half, column li = pair.  Pass i: every wave puts m-tile i of its unit into exchange image mh, then thread (pair = tid >> 4,
+    //      channel quad = tid & 15) of the first eight waves combines the six positions of both images into four output pixels each.
     const int col = ntile * 64 + cq * 4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (tid < 512) {
@@ -326,57 +305,67 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
     {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t += acc[i][r];
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][c][r];
         if (t == 123.456f) p.out[tid] = t;
         continue;
     }
 #endif
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float* X = reinterpret_cast<float*>(smem + (i & 1) * XBUF);
+    for (int i = 0; i < 2; ++i) {
+        if (i) lds_barrier();                        // pass 0's images have been read
+        float* Xw = reinterpret_cast<float*>(smem + mh * XBUF);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(X + (j * 32 + li) * XLD + ch * 32 + 8 * q + 4 * lk) = v;
-        }
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(Xw + (j * 32 + li) * XLD + c * 32 + 8 * q + 4 * lk) = v;
+            }
         lds_barrier();
         if (tid < 512) {
-            f32x4 m[6];
 #pragma unroll
-            for (int jj = 0; jj < 6; ++jj) m[jj] = *reinterpret_cast<const f32x4*>(X + (jj * 32 + pair) * XLD + cq * 4);
-            int n, y;
-            if (DUAL) { n = n0 + (i >> 1); y = (i & 1) * 8 + (pair >> 2); }
-            else { n = n0; y = y0 + i * 8 + (pair >> 2); }
-            if (!DUAL || n == n0 || has_b) {
-                const size_t pix = ((size_t)n * (2 * p.H) + (2 * y + py)) * (2 * p.W) + 2 * (pc * 16 + (pair & 3) * 4) + px;
-                float* o = p.out + pix * p.out_cstride + p.out_coff + col;
-                f32x4 yv[4];
+            for (int im = 0; im < 2; ++im) {
+                // unit `im` of the tile
+                const int n = UPS == 1 ? tn0 + im : tn0, yb = UPS == 1 ? 0 : ty0 + im * 16;
+                const bool hv = n < tn_end;
+                const float* X = reinterpret_cast<const float*>(smem + im * XBUF);
+                f32x4 m[6];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // AT of F(4,3): rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
-                    const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
-                    const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
-                    yv[0][e] = (m[0][e] + s12) + s34;
-                    yv[1][e] = __builtin_fmaf(2.f, d34, d12);
-                    yv[2][e] = __builtin_fmaf(4.f, s34, s12);
-                    yv[3][e] = __builtin_fmaf(8.f, d34, d12) + m[5][e];
-                }
+                for (int jj = 0; jj < 6; ++jj) m[jj] = *reinterpret_cast<const f32x4*>(X + (jj * 32 + pair) * XLD + cq * 4);
+                const int y = yb + i * 8 + (pair >> 2);
+                if (hv) {
+                    const size_t pix = ((size_t)n * (2 * p.H) + (2 * y + py)) * (2 * p.W) + 2 * (pc * 16 + (pair & 3) * 4) + px;
+                    float* o = p.out + pix * p.out_cstride + p.out_coff + col;
+                    f32x4 yv[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f32x4 v = yv[k];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
-                    if (p.act == ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
-                    } else if (p.act == ACT_LEAKY) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                    for (int e = 0; e < 4; ++e) {
+                        // AT of F(4,3): rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
+                        const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
+                        const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+                        yv[0][e] = (m[0][e] + s12) + s34;
+                        yv[1][e] = __builtin_fmaf(2.f, d34, d12);
+                        yv[2][e] = __builtin_fmaf(4.f, s34, s12);
+                        yv[3][e] = __builtin_fmaf(8.f, d34, d12) + m[5][e];
                     }
-                    amax = range_note4(amax, v);
-                    *reinterpret_cast<f32x4*>(o + (size_t)(2 * k) * p.out_cstride) = v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f32x4 v = yv[k];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+                        if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
+                        } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                        }
+                        amax = range_note4(amax, v);
+                        *reinterpret_cast<f32x4*>(o + (size_t)(2 * k) * p.out_cstride) = v;
+                    }
                 }
             }
         }
@@ -413,14 +402,13 @@ hipError_t launch_wino3_gemm(const Wino3Params& p, hipStream_t s)
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const bool dual = p.H == 16;
     const int g4 = 4 * (p.Cout / 64);
-    const int units = dual ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) / 2) : p.N * (p.H / 32);
-    const int tiles = units * (p.W / 16) * g4;
+    const int ups = p.H / 16;
+    const int wunits = ups == 1 ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) / 2) : p.N * (ups / 2);
+    const int tiles = wunits * (p.W / 16) * g4;
     int grid = tiles < n_cu ? tiles : n_cu / g4 * g4;
     if (grid < 1) grid = tiles < g4 ? tiles : g4;
-    if (dual) hipLaunchKernelGGL((wino3_gemm_kernel<true>), dim3(grid), dim3(768), 0, s, p);
-    else hipLaunchKernelGGL((wino3_gemm_kernel<false>), dim3(grid), dim3(768), 0, s, p);
+    hipLaunchKernelGGL(wino3_gemm_kernel, dim3(grid), dim3(768), 0, s, p);
     return hipGetLastError();
 }
 

@@ -1,8 +1,9 @@
 // Winograd F(4, 3) along the row axis for the two stride-2 layers on an 8x8 grid (gfx950, PREC_F16X3): the transposed convolution up1
 // (8x8 -> 16x16; reference pix2pose_model/ae_model.py:201-204) and the 5x5 / 2 'SAME' convolution conv4 (16x16 -> 8x8; ae_model.py:190-195,
 // resnet50 and paper encoders alike).  Same arithmetic and kernel structure as wino3.hip (which serves the 16x16 and 32x32 grids): six position
-// GEMMs on a 12-wave workgroup, wave (j, ch) = position j x 32 of the tile's 64 output channels; what differs is the geometry -- an 8x8 grid
-// is two 4-column tiles wide, so a 32-pair m-tile is TWO samples and a workgroup tile EIGHT samples -- and, for conv4, where K comes from:
+// GEMMs on a 12-wave workgroup, wave (j, mh) = position j of one half of the tile's rows x all 64 output channels, staging its own planes;
+// what differs is the geometry -- an 8x8 grid is two 4-column tiles wide, so a 32-pair m-tile is TWO samples, a wave's unit FOUR samples and a
+// workgroup tile EIGHT samples -- and, for conv4, where K comes from:
 //
 //   MODE 0 (up1)    the four sub-pixel phases as (2 + py) x 3-tap correlations on the input grid, as in wino3.hip.
 //   MODE 1 (conv4)  y[i][k] = sum x[2i + kh - 1][2k + kw - 1] w[kh][kw]: on the four parity planes P(a, b)[r][s] = x[2r + a][2s + b] this is a
@@ -121,21 +122,24 @@ __global__ __launch_bounds__(256) void wino3o_input_kernel(const Wino3oParams p)
 // ------------------------------------------------------------------------------------------------------------------------------------
 // the six position GEMMs + inverse transform + epilogue
 // ------------------------------------------------------------------------------------------------------------------------------------
+// Wave (j, mh) owns position j of FOUR samples (two m-tiles) and all 64 channels of the tile, stages its own image -- its position's four
+// planes of those samples -- and double-buffers it privately: no workgroup barrier in the K loop (see wino3_gemm_kernel).
 template <int MODE>
 __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
 {
     constexpr int SROW = 320;                       // LDS bytes of one sample of a plane: 10 rows x 2 tiles x 16 B
-    constexpr int PLANE = 8 * SROW;
-    constexpr int BUF = 24 * PLANE;
+    constexpr int WPLANE = 4 * SROW;                // one plane of a wave's image (four samples)
+    constexpr int WIMG = 4 * WPLANE;
+    constexpr int BUF = 12 * WIMG;
     constexpr int XLD = 68;                         // exchange image: [position 6][pair 32][64 channels + 4] floats
     constexpr int XBUF = 6 * 32 * XLD * 4;
-    static_assert(XBUF <= BUF, "two exchange images fit the two slice buffers");
+    static_assert(2 * XBUF <= 2 * BUF, "two exchange images fit the two slice buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = wv >> 1, ch = wv & 1;
+    const int j = wv >> 1, mh = wv & 1;
     const int li = lane & 31, lk = lane >> 5;
 
     const int S = p.Cin >> 4;
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
     }
     const int pair = tid >> 4, cq = tid & 15;       // epilogue role (threads 0..511)
     float amax = 0.f;
+    char* const wimg = smem + wv * WIMG;             // this wave's image in buffer 0
 
     for (int tl = tl0; tl < ntiles; tl += gridDim.x) {
     const int unit = tl / G4;
@@ -175,45 +180,45 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
     }
     const int nvalid = n_end - n0 < 8 ? n_end - n0 : 8;
 
-    // ---- V: global -> registers -> LDS.  This wave: the planes (j, hl = ch, lk = 0 / 1), 2 KB each = two pieces of four samples.
+    // ---- V: global -> registers -> LDS: piece q = plane (hl, lk) = q of this wave's position, its four samples (1 KB).
     const char* vbase = reinterpret_cast<const char*>(p.V) + (size_t)unit * unit_block;
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)unit_block, 0x00020000);
-    const unsigned so_w = (unsigned)(j * 4 + ch * 2) * VPLANE;
-    unsigned vo[2];                                  // a missing sample (the last unit of an object) reads zeros
-    vo[0] = (lane >> 4) < nvalid ? (unsigned)lane * 16u : OOB;
-    vo[1] = 4 + (lane >> 4) < nvalid ? 1024u + (unsigned)lane * 16u : OOB;
-    // LDS: sample (lane >> 4) [+ 4], row ((lane >> 1) & 7) + 1, tile lane & 1
-    char* wreg = smem + (j * 4 + ch * 2) * PLANE + (lane >> 4) * SROW + (((lane >> 1) & 7) + 1) * 32 + (lane & 1) * 16;
+    const unsigned so_w = (unsigned)(j * 4) * VPLANE + (unsigned)mh * 1024u;
+    const unsigned vo = 4 * mh + (lane >> 4) < nvalid ? (unsigned)lane * 16u : OOB;      // a missing sample (the last unit of an object) reads zeros
+    // LDS: sample lane >> 4, row ((lane >> 1) & 7) + 1, tile lane & 1
+    char* wreg = wimg + (lane >> 4) * SROW + (((lane >> 1) & 7) + 1) * 32 + (lane & 1) * 16;
     f32x4 rv[4];
     auto vload_all = [&](int sq, bool on) {
         const unsigned so = (unsigned)sq * VSLICE + so_w;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            rv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo[q & 1] | (on ? 0u : OOB), so + (unsigned)(q >> 1) * VPLANE, 0));
+            rv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo | (on ? 0u : OOB), so + (unsigned)q * VPLANE, 0));
     };
     auto vstore_all = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(wreg + buf * BUF + (q >> 1) * PLANE + (q & 1) * 4 * SROW) = rv[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(wreg + buf * BUF + q * WPLANE) = rv[q];
     };
 
-    f32x16 acc[4];
+    f32x16 acc[2][2];                                // [m-tile of the wave's four samples][32-channel half]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
 
-    // V fragment of m-tile i, image row offset ro: plane (j, hl, lk), sample 2i + (li >> 4), image row ro + ((li >> 1) & 7), tile li & 1
-    const char* img0 = smem + (j * 4 + lk) * PLANE + (li >> 4) * SROW + ((li >> 1) & 7) * 32 + (li & 1) * 16;
+    // V fragment of m-tile i, image row offset ro: plane (hl, lk), sample 2i + (li >> 4) of the wave's four, image row ro + ((li >> 1) & 7), tile li & 1
+    const char* img0 = wimg + lk * WPLANE + (li >> 4) * SROW + ((li >> 1) & 7) * 32 + (li & 1) * 16;
 
-    lds_barrier();                                   // (persistent loop) the previous tile's exchange image has been read
+    lds_barrier();                                   // (persistent loop) the previous tile's exchange images have been read
     {
-        // the zero rows (image rows 0 and 9 of every sample) of this wave's two planes in both buffers: 2 x 2 x 8 x 2 rows x 2 slots = 128
+        // the zero rows (image rows 0 and 9 of every sample) of this wave's image in both buffers: 2 x 4 planes x 4 samples x 2 rows x 2 slots = 128
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int sl = lane + 64 * k;
-            const int bf = sl >> 6, pl = (sl >> 5) & 1, smp = (sl >> 2) & 7, zr = (sl >> 1) & 1, t = sl & 1;
-            *reinterpret_cast<f32x4*>(smem + bf * BUF + (j * 4 + ch * 2 + pl) * PLANE + smp * SROW + zr * 9 * 32 + t * 16) = z;
+            const int bf = sl >> 6, pl = (sl >> 4) & 3, smp = (sl >> 2) & 3, zr = (sl >> 1) & 1, t = sl & 1;
+            *reinterpret_cast<f32x4*>(wimg + bf * BUF + pl * WPLANE + smp * SROW + zr * 9 * 32 + t * 16) = z;
         }
     }
 
@@ -221,16 +226,15 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
     auto body = [&](auto nky_c, auto ro_c, int sq0, int sq1, int kb0, const __amdgpu_buffer_rsrc_t rs_u) {
         constexpr int NKY = decltype(nky_c)::value;
         constexpr int RO = decltype(ro_c)::value;
-        const unsigned uoff = (unsigned)lane * 16u + (unsigned)ch * 2048u;
-        f16x8 u[2][2];
+        const unsigned uoff = (unsigned)lane * 16u;
+        f16x8 u[2][4];
         auto uload = [&](int set, int kb) {
-            u[set][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff, kb * 4096, 0));
-            u[set][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + 1024u, kb * 4096, 0));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) u[set][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + f * 1024, kb * 4096, 0));
         };
         vload_all(sq0, true);
         uload(0, kb0);
         vstore_all(0);
-        lds_barrier();
         for (int s2 = sq0; s2 < sq1; s2 += 2) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -242,23 +246,24 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
                     uload((kk + 1) & 1, kb0 + (s - sq0) * NKY + ky + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     const char* img = img0 + half * BUF + (RO + ky) * 32;
-                    f16x8 vh[4], vl[4];
+                    f16x8 vh[2], vl[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < 2; ++i) {
                         vh[i] = *reinterpret_cast<const f16x8*>(img + i * 2 * SROW);
-                        vl[i] = *reinterpret_cast<const f16x8*>(img + i * 2 * SROW + 2 * PLANE);
+                        vl[i] = *reinterpret_cast<const f16x8*>(img + i * 2 * SROW + 2 * WPLANE);
                     }
                     const f16x8* uc = u[kk & 1];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[1], vh[i], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[0], vl[i], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[0], vh[i], acc[i], 0, 0, 0);
-                    }
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c + 1], vh[i], acc[i][c], 0, 0, 0);
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vl[i], acc[i][c], 0, 0, 0);
+                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vh[i], acc[i][c], 0, 0, 0);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 vstore_all(half ^ 1);
-                lds_barrier();
             }
         }
     };
@@ -286,8 +291,10 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
         } else if (pyx < 2) body(I2{}, I1{}, pyx * S, (pyx + 1) * S, pyx * 2 * S, rs_u);
         else body(I3{}, I0{}, pyx * S, (pyx + 1) * S, 4 * S + (pyx - 2) * 3 * S, rs_u);
     }
+    lds_barrier();                                   // every wave is done with its image: the exchange images may overwrite them
 
-    // ---- epilogue (see wino3.hip).  Pair (of m-tile i) = sample 2i + (pair >> 4), row (pair >> 1) & 7, tile pair & 1.
+    // ---- epilogue (see wino3.hip).  Pass i: every wave puts m-tile i of its four samples into exchange image mh; pair = sample
+    //      4 im + 2 i + (pair >> 4), row (pair >> 1) & 7, tile pair & 1 of image im.
     const int col = ntile * 64 + cq * 4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     const bool raw = MODE == 1 && KS > 1;           // partial sums: BatchNorm and the activation happen in the reduction
@@ -296,58 +303,67 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
         if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float* X = reinterpret_cast<float*>(smem + (i & 1) * XBUF);
+    for (int i = 0; i < 2; ++i) {
+        if (i) lds_barrier();                        // pass 0's images have been read
+        float* Xw = reinterpret_cast<float*>(smem + mh * XBUF);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(X + (j * 32 + li) * XLD + ch * 32 + 8 * q + 4 * lk) = v;
-        }
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(Xw + (j * 32 + li) * XLD + c * 32 + 8 * q + 4 * lk) = v;
+            }
         lds_barrier();
-        if (tid < 512 && 2 * i + (pair >> 4) < nvalid) {
-            f32x4 m[6];
+        if (tid < 512) {
 #pragma unroll
-            for (int jj = 0; jj < 6; ++jj) m[jj] = *reinterpret_cast<const f32x4*>(X + (jj * 32 + pair) * XLD + cq * 4);
-            const int n = n0 + 2 * i + (pair >> 4), y = (pair >> 1) & 7, x0 = (pair & 1) * 4;
-            float* o;
-            size_t ostep;
-            if (MODE == 0) {
-                const size_t pix = ((size_t)n * 16 + (2 * y + py)) * 16 + 2 * x0 + px;
-                o = p.out + pix * p.out_cstride + p.out_coff + col;
-                ostep = (size_t)2 * p.out_cstride;
-            } else if (raw) {
-                o = p.partial + ((size_t)pyx * p.N * 64 + ((size_t)n * 8 + y) * 8 + x0) * p.Cout + col;
-                ostep = (size_t)p.Cout;
-            } else {
-                o = p.out + (((size_t)n * 8 + y) * 8 + x0) * p.out_cstride + p.out_coff + col;
-                ostep = (size_t)p.out_cstride;
-            }
-            f32x4 yv[4];
+            for (int im = 0; im < 2; ++im) {
+                const int smp = 4 * im + 2 * i + (pair >> 4);
+                if (smp >= nvalid) continue;
+                const float* X = reinterpret_cast<const float*>(smem + im * XBUF);
+                f32x4 m[6];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
-                const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
-                yv[0][e] = (m[0][e] + s12) + s34;
-                yv[1][e] = __builtin_fmaf(2.f, d34, d12);
-                yv[2][e] = __builtin_fmaf(4.f, s34, s12);
-                yv[3][e] = __builtin_fmaf(8.f, d34, d12) + m[5][e];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                f32x4 v = yv[k];
-                if (!raw) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
-                    if (p.act == ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
-                    } else if (p.act == ACT_LEAKY) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
-                    }
-                    amax = range_note4(amax, v);
+                for (int jj = 0; jj < 6; ++jj) m[jj] = *reinterpret_cast<const f32x4*>(X + (jj * 32 + pair) * XLD + cq * 4);
+                const int n = n0 + smp, y = (pair >> 1) & 7, x0 = (pair & 1) * 4;
+                float* o;
+                size_t ostep;
+                if (MODE == 0) {
+                    const size_t pix = ((size_t)n * 16 + (2 * y + py)) * 16 + 2 * x0 + px;
+                    o = p.out + pix * p.out_cstride + p.out_coff + col;
+                    ostep = (size_t)2 * p.out_cstride;
+                } else if (raw) {
+                    o = p.partial + ((size_t)pyx * p.N * 64 + ((size_t)n * 8 + y) * 8 + x0) * p.Cout + col;
+                    ostep = (size_t)p.Cout;
+                } else {
+                    o = p.out + (((size_t)n * 8 + y) * 8 + x0) * p.out_cstride + p.out_coff + col;
+                    ostep = (size_t)p.out_cstride;
                 }
-                *reinterpret_cast<f32x4*>(o + (size_t)k * ostep) = v;
+                f32x4 yv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e];
+                    const float s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+                    yv[0][e] = (m[0][e] + s12) + s34;
+                    yv[1][e] = __builtin_fmaf(2.f, d34, d12);
+                    yv[2][e] = __builtin_fmaf(4.f, s34, s12);
+                    yv[3][e] = __builtin_fmaf(8.f, d34, d12) + m[5][e];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 v = yv[k];
+                    if (!raw) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+                        if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
+                        } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+                        }
+                        amax = range_note4(amax, v);
+                    }
+                    *reinterpret_cast<f32x4*>(o + (size_t)k * ostep) = v;
+                }
             }
         }
     }
