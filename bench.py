@@ -182,8 +182,8 @@ def main():
     ap.add_argument("--general", type=int, default=-1, help="steps of the general-crop-size legs (N=1; -1 = as many as --steps, 0 = skip)")
     ap.add_argument("--latency", type=int, default=100, help="calls of the single-detection latency leg (N=1; 0 = skip)")
     ap.add_argument("--winograd", default="auto", choices=["auto", "off", "always"],
-                    help="form of the 5x5 stride-1 decoder layers (p2p_ctx_set_winograd): auto = Winograd F(4,5) for passes of two or more inputs (default), "
-                         "off = the direct kernels (the previous rounds' arithmetic)")
+                    help="form of the 5x5 layers deconv1-3 / up1-3 / conv4 (p2p_ctx_set_winograd): auto = the fastest form per pass size, i.e. Winograd F(4,5) / F(4,3) "
+                         "for every pass of this workload (default), off = the direct kernels (the arithmetic of rounds 1-5)")
     ap.add_argument("--merge", action="store_true", help="stream mode: merge step i's stage-2 generator pass with step i+1's stage-1 pass (p2p_est_pose_opts.merge_stream_passes)")
     ap.add_argument("--anti-aliasing", action="store_true", help="scikit-image 0.17 - 0.18 resize semantics (Gaussian pre-filter whenever a resize shrinks)")
     ap.add_argument("--bbox-side", default="86,86", help="range of detection box sides in px (default 86 = 128-px crops, the headline workload; "

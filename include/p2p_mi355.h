@@ -126,16 +126,20 @@ P2P_API int p2p_model_precision(const p2p_model* model);
  * largest offending magnitude in *max_abs (0 = none) and clears the flag.  No reference counterpart (TensorFlow computes in fp32). */
 P2P_API int p2p_ctx_range_event(p2p_ctx* ctx, float* max_abs);
 
-/* Form of the 5x5 stride-1 decoder convolutions deconv1 / deconv2 / deconv3 (reference ae_model.py:207-211,217-220,227-230; 67 % of the
- * generator's multiplications) in P2P_PREC_F16X3 passes of this context.  The Winograd form F(4,5) along the row axis needs 2.5x fewer
- * matrix-core products; it forms different products than the direct convolution, so the two forms do not give the same bits: both are
- * held to the same bar against the oracle (network output within 1e-4; measured 3e-5 / 2.6e-5; tests/test_wino_gpu.py), 3e-5 apart.
- *   P2P_WINOGRAD_AUTO (default)  Winograd form for passes of two or more inputs, direct form for one-input passes (the stage-1 pass of a
- *                                single est_pose call: 5 % faster there) -- the fastest choice at every batch size; a sample's bits then
- *                                depend on whether it travels ALONE (never on the content, size or order of a batch of two or more)
- *   P2P_WINOGRAD_OFF             direct form always   } either way a sample's output bits do not depend on the batch it travels in
- *   P2P_WINOGRAD_ALWAYS          Winograd form always }
- * Strict-fp32 objects (P2P_PREC_F32, the twin of P2P_PREC_AUTO) always use the direct form.  No reference counterpart. */
+/* Form of the 5x5 layers of the generator in P2P_PREC_F16X3 passes of this context: the stride-1 decoder convolutions deconv1 / deconv2 /
+ * deconv3 (reference ae_model.py:207-211,217-220,227-230; 67 % of the generator's multiplications), the transposed convolutions up1 / up2 /
+ * up3 (ae_model.py:201-204,212-215,222-225) and the stride-2 convolution conv4 (ae_model.py:190-195).  The Winograd forms along the row
+ * axis -- F(4,5) for the stride-1 layers (2.5x fewer matrix-core products), F(4,3) on the sub-pixel phases / parity planes of the stride-2
+ * layers (1.67x fewer) -- form different products than the direct convolutions, so the forms do not give the same bits: all are held to the
+ * same bar against the oracle (network output within 1e-4; measured 4e-5 with every layer in Winograd form, 2.6e-5 direct;
+ * tests/test_wino_gpu.py), 6e-5 apart at most.
+ *   P2P_WINOGRAD_AUTO (default)  the fastest form at every pass size: direct for a one-input pass (the stage-1 pass of a single est_pose
+ *                                call), F(4,5) from two inputs, F(4,3) for up2 / up3 from 8 and for conv4 / up1 from 16 inputs; conv4 adds
+ *                                its four parity-plane sums in a separate step while the launch is under one workgroup per CU.  A sample's
+ *                                bits then depend on the SIZE of the pass it travels in (never on its content or order)
+ *   P2P_WINOGRAD_OFF             direct forms always   } either way a sample's output bits do not depend on the pass it travels in
+ *   P2P_WINOGRAD_ALWAYS          Winograd forms always }  (conv4 split over its parity planes at every size)
+ * Strict-fp32 objects (P2P_PREC_F32, the twin of P2P_PREC_AUTO) always use the direct forms.  No reference counterpart. */
 typedef enum { P2P_WINOGRAD_OFF = 0, P2P_WINOGRAD_AUTO = 1, P2P_WINOGRAD_ALWAYS = 2 } p2p_winograd_mode;
 P2P_API int p2p_ctx_set_winograd(p2p_ctx* ctx, int mode);
 

@@ -23,8 +23,9 @@ class Context:
             self.set_winograd(winograd)
 
     def set_winograd(self, mode: str):
-        """Form of the 5x5 stride-1 decoder layers in split-f16 passes (p2p_ctx_set_winograd): "auto" (default) = Winograd F(4,5) for launches
-        that fill the chip, direct below -- fastest, a sample's bits depend on the batch SIZE; "off" / "always" = one form at every size."""
+        """Form of the 5x5 layers (deconv1-3, up1-3, conv4) in split-f16 passes (p2p_ctx_set_winograd): "auto" (default) = the fastest form at
+        every pass size (Winograd F(4,5) / F(4,3) from 2 / 8 / 16 inputs up, direct below) -- a sample's bits depend on the pass SIZE;
+        "off" / "always" = one form at every size."""
         _lib.check(_lib.lib().p2p_ctx_set_winograd(self._h, self.WINOGRAD[mode]), "p2p_ctx_set_winograd")
 
     @property
