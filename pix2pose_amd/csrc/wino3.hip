@@ -111,20 +111,26 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const Wino3Params p)
 // out-of-image rows load as zeros) x 4 tiles x 16 B per plane, double-buffered -- so the K loop has no workgroup barrier; per K-step
 // (one vertical tap of a 16-channel slice) it reads 4 V fragments from LDS and 4 U fragments straight from global (4 KB per 12 MFMAs: the
 // L2 traffic per MFMA of wino.hip) for 12 MFMAs.
-__global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
+// NU = units per workgroup: 2 (shipped) = one 12-wave workgroup per CU; 1 (A/B builds, -DP2P_W3_NU1) = 6-wave workgroups, two per CU
+// (55 KB of LDS each), meant to interleave one workgroup's prologue / exchange / store phases with the other's K loop -- with 32-48
+// K-steps per tile those phases are a quarter of a tile's time (MFMA busy 50 % for up2 / up3 against 67 % for conv4's 320-K-step tiles).
+// Measured SLOWER (up2 + up3 + conv4 + up1: 1118 vs 1022 us per 256 inputs): six waves do not spread evenly over four SIMDs.
+template <int NU>
+__global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino3Params p)
 {
+    constexpr int NTHR = NU * 384;
     constexpr int WPLANE = 18 * 64;                 // one plane of a wave's image
     constexpr int WIMG = 4 * WPLANE;                // the four planes (hl, lk) of its position
-    constexpr int BUF = 12 * WIMG;
+    constexpr int BUF = 6 * NU * WIMG;
     constexpr int XLD = 68;                         // exchange image: [position 6][pair 32][64 channels + 4] floats
     constexpr int XBUF = 6 * 32 * XLD * 4;
-    static_assert(2 * XBUF <= 2 * BUF, "two exchange images fit the two slice buffers");
+    static_assert(NU * XBUF <= 2 * BUF, "the exchange images fit the two slice buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = wv >> 1, mh = wv & 1;              // position, unit of the workgroup tile
+    const int j = NU == 2 ? wv >> 1 : wv, mh = NU == 2 ? wv & 1 : 0;      // position, unit of the workgroup tile
     const int li = lane & 31, lk = lane >> 5;
 
     const int S = p.Cin >> 4;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
     const int UPS = p.H >> 4;                        // units per sample
     const int NT = p.Cout >> 6;
     const int G4 = 4 * NT;                           // tiles of one patch: (py, px, channel tile)
-    const int wunits = UPS == 1 ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) >> 1) : p.N * (UPS >> 1);
+    const int wunits = NU == 1 ? p.N * UPS : UPS == 1 ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) >> 1) : p.N * (UPS >> 1);
     const int ntiles = wunits * PC * G4;
     const unsigned plane_bytes = (unsigned)p.H * 64u;
     const unsigned slice_bytes = 24u * plane_bytes;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
         const int xcd = b & 7, idx = b >> 3;
         tl0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int pair = tid >> 4, cq = tid & 15;       // epilogue role (threads 0..511)
+    const int cq = tid & 15;                         // epilogue role: (pair = role >> 4, channel quad), roles 0..511
     float amax = 0.f;
     char* const wimg = smem + wv * WIMG;             // this wave's image in buffer 0
 
@@ -165,7 +171,14 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
     const float* gu = p.U;
     const float* gscale = p.scale;
     const float* gshift = p.shift;
-    if (UPS == 1) {
+    if (NU == 1) {
+        tn0 = wunit / UPS; ty0 = (wunit % UPS) * 16;
+        if (p.n_groups > 1) {
+            int g = 0;
+            while (g + 1 < p.n_groups && p.grp[g + 1].sample0 <= tn0) ++g;
+            gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
+        }
+    } else if (UPS == 1) {
         tn0 = wunit * 2;
         if (p.n_groups > 1) {                        // groups are runs of samples; every group is paired up on its own (unit0)
             int g = 0;
@@ -183,8 +196,8 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
             gu = p.grp[g].U; gscale = p.grp[g].scale; gshift = p.grp[g].shift;
         }
     }
-    const int n_me = UPS == 1 ? tn0 + mh : tn0;     // this wave's unit
-    const int y0 = UPS == 1 ? 0 : ty0 + mh * 16;
+    const int n_me = (NU == 2 && UPS == 1) ? tn0 + mh : tn0;     // this wave's unit
+    const int y0 = NU == 1 ? ty0 : UPS == 1 ? 0 : ty0 + mh * 16;
     const bool have = n_me < tn_end;
 
     // ---- V: global -> registers -> LDS, this wave's image: planes (j, hl, lk), rows y0 - 1 .. y0 + 16.
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
     //      channel quad = tid & 15) of the first eight waves combines the six positions of both images into four output pixels each.
     const int col = ntile * 64 + cq * 4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 512) {
+    if (tid < 512) {                                // (6-wave workgroups: a thread's second role has the same channel quad, 384 % 16 == 0)
         if (gscale) sc = *reinterpret_cast<const f32x4*>(gscale + pyx * p.Cout + col);
         if (gshift) sh = *reinterpret_cast<const f32x4*>(gshift + col);
     }
@@ -326,11 +339,12 @@ __global__ __launch_bounds__(768) void wino3_gemm_kernel(const Wino3Params p)
                 *reinterpret_cast<f32x4*>(Xw + (j * 32 + li) * XLD + c * 32 + 8 * q + 4 * lk) = v;
             }
         lds_barrier();
-        if (tid < 512) {
+        for (int role = tid; role < 512; role += NTHR) {
+            const int pair = role >> 4;
 #pragma unroll
-            for (int im = 0; im < 2; ++im) {
+            for (int im = 0; im < NU; ++im) {
                 // unit `im` of the tile
-                const int n = UPS == 1 ? tn0 + im : tn0, yb = UPS == 1 ? 0 : ty0 + im * 16;
+                const int n = (NU == 2 && UPS == 1) ? tn0 + im : tn0, yb = NU == 1 ? ty0 : UPS == 1 ? 0 : ty0 + im * 16;
                 const bool hv = n < tn_end;
                 const float* X = reinterpret_cast<const float*>(smem + im * XBUF);
                 f32x4 m[6];
@@ -394,7 +408,7 @@ hipError_t launch_wino3_input(const Wino3Params& p, hipStream_t s)
 
 hipError_t launch_wino3_gemm(const Wino3Params& p, hipStream_t s)
 {
-    // persistent: one workgroup per CU walks the tiles; the grid is kept a multiple of the tiles of one patch (the phase rotation counts on it)
+    // persistent: the workgroups of a full chip walk the tiles; the grid is kept a multiple of the tiles of one patch (the phase rotation counts on it)
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -402,13 +416,19 @@ hipError_t launch_wino3_gemm(const Wino3Params& p, hipStream_t s)
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+#ifdef P2P_W3_NU1
+    constexpr int NU = 1;                            // A/B builds: 6-wave workgroups, two per CU -- measured 9 % slower (tools/experiments/README.md)
+#else
+    constexpr int NU = 2;
+#endif
     const int g4 = 4 * (p.Cout / 64);
     const int ups = p.H / 16;
-    const int wunits = ups == 1 ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) / 2) : p.N * (ups / 2);
+    const int wunits = NU == 1 ? p.N * ups : ups == 1 ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) / 2) : p.N * (ups / 2);
     const int tiles = wunits * (p.W / 16) * g4;
-    int grid = tiles < n_cu ? tiles : n_cu / g4 * g4;
+    const int slots = n_cu * (2 / NU);
+    int grid = tiles < slots ? tiles : slots / g4 * g4;
     if (grid < 1) grid = tiles < g4 ? tiles : g4;
-    hipLaunchKernelGGL(wino3_gemm_kernel, dim3(grid), dim3(768), 0, s, p);
+    hipLaunchKernelGGL((wino3_gemm_kernel<NU>), dim3(grid), dim3(NU * 384), 0, s, p);
     return hipGetLastError();
 }
 

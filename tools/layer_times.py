@@ -71,14 +71,25 @@ def main(path, batch=256):
     for nm, mmac in layers:
         if skip and nm.startswith(skip):
             continue
-        if nm.endswith("_p0") and i < len(ks) and "wino3_input" in ks[i][0]:
+        if nm.endswith("_p0") and i < len(ks) and ("wino3_input" in ks[i][0] or "wino3o_input" in ks[i][0]):
             b = nm.split("_")[0]
             out.append((b + " V", 0))
-            KF[b + " V"] = {"up2": 66 * 2.5, "up3": 262 * 2.5}.get(b, 0)                              # x read once, V (1.5x the elements) written once
+            KF[b + " V"] = {"up1": 16 * 2.5, "up2": 66 * 2.5, "up3": 262 * 2.5}.get(b, 0)             # x read once, V (1.5x the elements) written once
             out.append((b + " gemm", sum(m for n2, m in layers if n2.startswith(b + "_p"))))
-            KF[b + " gemm"] = {"up2": 66 * 1.5 + 131, "up3": 262 * 1.5 + 262}.get(b, 0)
+            KF[b + " gemm"] = {"up1": 16 * 1.5 + 66, "up2": 66 * 1.5 + 131, "up3": 262 * 1.5 + 262}.get(b, 0)
             skip = b + "_p"
             i += 2
+            continue
+        if nm == "conv4" and i < len(ks) and "wino3o_input" in ks[i][0]:                                # conv4 in Winograd F(4,3) form on its parity planes (wino3o.hip)
+            out.append(("conv4 V", 0))
+            KF["conv4 V"] = 131 * 2.5
+            out.append(("conv4 gemm", mmac))
+            KF["conv4 gemm"] = 131 * 1.5 + 33
+            i += 2
+            if i < len(ks) and "splitk_reduce" in ks[i][0]:                                          # small launches: K split over the four planes
+                out.append(("conv4 reduce", 0))
+                KF["conv4 reduce"] = 5 * 33
+                i += 1
             continue
         if nm.startswith("deconv") and i < len(ks) and "wino_input" in ks[i][0]:
             out.append((nm + " V", 0))
