@@ -155,6 +155,8 @@ struct ResBlockGroup {
     const float* ss;       // folded BatchNorm of the three layers: [scale 2a F1 | shift 2a F1 | scale 2b F1 | shift 2b F1 | scale 2c C | shift 2c C]
     int sample0;
     int pad_;
+    const float* w2b_frag; // the 2b panel once more in MFMA fragment order [F1 / 32][9 F1 / 32 K-steps (tap, slice)][k half 2][hi, lo][lane 64][8 halves]:
+                           // phase B reads its weight operand straight from global (L2) into registers, no LDS staging, no barrier in its K loop
 };
 struct ResBlockParams {
     const float* x;        // [N, H, W, C] block input (C = 4 F1) -- also the residual

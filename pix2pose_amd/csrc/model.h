@@ -29,6 +29,8 @@ struct ConvLayer {
     float* wino_u = nullptr;
     float* wino_scale = nullptr;   // folded BatchNorm scale times the inverse of the Winograd panel's per-channel pre-scale
     size_t wino_bytes = 0;
+    // 3x3 layers of the fused bottleneck blocks (split-f16 models): the panel `w` once more in MFMA fragment order (resblock.hip, phase B)
+    float* w_frag = nullptr;
 };
 
 struct Model {

@@ -645,8 +645,9 @@ static void free_layer(ConvLayer& L)
     if (L.scale) hipFree(L.scale);
     if (L.shift) hipFree(L.shift);
     if (L.wino_u) hipFree(L.wino_u);
+    if (L.w_frag) hipFree(L.w_frag);
     if (L.wino_scale) hipFree(L.wino_scale);
-    L.w = L.scale = L.shift = L.wino_u = L.wino_scale = nullptr;
+    L.w = L.scale = L.shift = L.wino_u = L.wino_scale = L.w_frag = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -726,6 +727,26 @@ static int pack_block_ss(Model& M)
         float* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, (size_t)(4 * F1 + 2 * C) * sizeof(float)));
         M.block_ss[n] = d;
+        if (!M.L.at(n + "_2b").w_frag) {
+            // fragment-ordered copy of the 2b panel: the same halves, regrouped per (32-row tile, K-step, k half, hi / lo) into 1 KB lane images
+            ConvLayer& Lb = M.L.at(n + "_2b");
+            const int K = Lb.K, KS = K / 32, NTL = Lb.Cout / 32;
+            std::vector<float> host((size_t)round_up(Lb.Cout, 128) * K), frag((size_t)Lb.Cout * K);
+            HIP_TRY(hipMemcpy(host.data(), Lb.w, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+            const uint16_t* sh = reinterpret_cast<const uint16_t*>(host.data());
+            uint16_t* dh = reinterpret_cast<uint16_t*>(frag.data());
+            for (int nt = 0; nt < NTL; ++nt)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int f = 0; f < 4; ++f)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int row = nt * 32 + (lane & 31), kb = f >> 1, hf = f & 1;
+                            const uint16_t* sp = sh + ((size_t)row * K + (size_t)ks * 32) * 2 + hf * 32 + kb * 16 + (lane >> 5) * 8;
+                            uint16_t* dp = dh + ((((size_t)nt * KS + ks) * 4 + f) * 64 + lane) * 8;
+                            for (int e = 0; e < 8; ++e) dp[e] = sp[e];
+                        }
+            int rcu = upload(frag, &Lb.w_frag);
+            if (rcu) return rcu;
+        }
         const float* src[6] = {a.scale, a.shift, b.scale, b.shift, c.scale, c.shift};
         const int len[6] = {F1, F1, F1, F1, C, C};
         size_t off = 0;
@@ -1231,13 +1252,13 @@ static int run_resblock(const Model& M, Ctx& X, const std::string& n, const floa
         for (int g = 0; g < ng; ++g) {
             const Model& Mg = *G.models[g];
             if (Mg.prec != PREC_F16X3 || !Mg.block_ss.count(n)) { set_error("run_resblock: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
-            p.grp[g] = {Mg.L.at(n + "_2a").w, Mg.L.at(n + "_2b").w, Mg.L.at(n + "_2c").w, Mg.block_ss.at(n), G.start[g], 0};
+            p.grp[g] = {Mg.L.at(n + "_2a").w, Mg.L.at(n + "_2b").w, Mg.L.at(n + "_2c").w, Mg.block_ss.at(n), G.start[g], 0, Mg.L.at(n + "_2b").w_frag};
         }
-        p.grp[ng] = {nullptr, nullptr, nullptr, nullptr, G.start[ng], 0};
+        p.grp[ng] = {nullptr, nullptr, nullptr, nullptr, G.start[ng], 0, nullptr};
         p.n_groups = ng;
     } else {
-        p.grp[0] = {a.w, b.w, c.w, M.block_ss.at(n), 0, 0};
-        p.grp[1] = {nullptr, nullptr, nullptr, nullptr, N, 0};
+        p.grp[0] = {a.w, b.w, c.w, M.block_ss.at(n), 0, 0, b.w_frag};
+        p.grp[1] = {nullptr, nullptr, nullptr, nullptr, N, 0, nullptr};
         p.n_groups = 1;
     }
     hipStream_t st = X.cur->stream;
@@ -1278,13 +1299,13 @@ static int run_resproj(const Model& M, Ctx& X, const std::string& n, const float
         for (int g = 0; g < ng; ++g) {
             const Model& Mg = *G.models[g];
             if (Mg.prec != PREC_F16X3 || !Mg.block_ss.count(n)) { set_error("run_resproj: objects of one grouped pass must share a precision"); return P2P_ERR_INVALID_ARG; }
-            p.grp[g] = {Mg.L.at(n + "_2a").w, Mg.L.at(n + "_2b").w, Mg.L.at(n + "_2c1").w, Mg.block_ss.at(n), G.start[g], 0};
+            p.grp[g] = {Mg.L.at(n + "_2a").w, Mg.L.at(n + "_2b").w, Mg.L.at(n + "_2c1").w, Mg.block_ss.at(n), G.start[g], 0, Mg.L.at(n + "_2b").w_frag};
         }
-        p.grp[ng] = {nullptr, nullptr, nullptr, nullptr, G.start[ng], 0};
+        p.grp[ng] = {nullptr, nullptr, nullptr, nullptr, G.start[ng], 0, nullptr};
         p.n_groups = ng;
     } else {
-        p.grp[0] = {a.w, b.w, c.w, M.block_ss.at(n), 0, 0};
-        p.grp[1] = {nullptr, nullptr, nullptr, nullptr, N, 0};
+        p.grp[0] = {a.w, b.w, c.w, M.block_ss.at(n), 0, 0, b.w_frag};
+        p.grp[1] = {nullptr, nullptr, nullptr, nullptr, N, 0, nullptr};
         p.n_groups = 1;
     }
     hipStream_t st = X.cur->stream;

@@ -59,7 +59,15 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo)
 // PROJ: the projection blocks res2a / res3a (resnet50_mod.py:76-118): the block input has CIN channels on a grid STRIDE times finer than the output
 // (the 1x1 layers of a stride-2 block sample its even pixels), and the block's last 1x1 convolution carries the projection shortcut as a second K
 // segment [t_b (F1) | x (CIN)] (model.hip: pack_merged_shortcut) instead of a residual add.
-template <int F1, int PY, int HPX, int DA, int DB, int KA, bool PRIV, int ABL = 0, int CIN = 4 * F1, int STRIDE = 1, bool PROJ = false>
+// WDIR: phase B takes its weight operand straight from global (the fragment-ordered copy of the 2b panel, ResBlockGroup::w2b_frag) into
+// registers, DB K-steps ahead: no weight tile in LDS, no barrier in the K loop of phase B (the t_a image is read-only).  Same fragments, same
+// MFMA order: same bits.
+#ifdef P2P_RB_NO_WDIR
+constexpr bool RB_WDIR = false;
+#else
+constexpr bool RB_WDIR = true;
+#endif
+template <int F1, int PY, int HPX, int DA, int DB, int KA, bool PRIV, int ABL = 0, int CIN = 4 * F1, int STRIDE = 1, bool PROJ = false, bool WDIR = RB_WDIR>
 __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p)
 {
     constexpr int C = 4 * F1;                     // output channels
@@ -263,8 +271,19 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
 #pragma unroll
         for (int j = 0; j < NWB; ++j) *reinterpret_cast<f32x4*>(Wbs + wb_dst[j]) = qw[j];
     };
+    const __amdgpu_buffer_rsrc_t rs_wbf = __builtin_amdgcn_make_buffer_rsrc((void*)p.grp[g].w2b_frag, 0, (unsigned)(F1 * 9 * F1 * 4), 0x00020000);
+    f16x8 rwf[DB][4];                             // WDIR: (k half 0 hi, lo, k half 1 hi, lo) of the K-steps in flight
+    auto wfload = [&](int ks, f16x8 (&q)[4]) {
+        const int chunk = ks / 9, tap = ks - chunk * 9;                       // K order (slice, tap); the panel's is (tap, slice)
+        const unsigned base = (unsigned)((ntB * TOTAL + tap * SB + chunk) * 4096);
 #pragma unroll
-    for (int d = 0; d < DB; ++d) wbload(d, rwb[d]);
+        for (int f = 0; f < 4; ++f) q[f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wbf, (unsigned)lane * 16u + f * 1024u, base, 0));
+    };
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        if (WDIR) wfload(d, rwf[d]);
+        else wbload(d, rwb[d]);
+    }
 
     // ---- epilogue A: lane = halo pixel mt * 32 + li, channels ntA * 32 + 8 g + 4 lk + {0..3}; the image replaces the staging buffers
     //      (everyone left the K loop through its last barrier)
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             }
         }
     }
-    wbstore(rwb[0]);
+    if (!WDIR) wbstore(rwb[0]);
     __syncthreads();                              // the t_a image is complete
 
     // =========================================================================================== phase B: t_b = relu(bn(W2b * t_a)), 3x3
@@ -321,7 +340,12 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             for (int d = 0; d < DB; ++d) {
                 const int ks = k0 + d;
                 const int chunk = ks / 9, tap = ks - chunk * 9;
-                if (ks + DB < TOTAL) wbload(ks + DB, rwb[d]);
+                f16x8 wq[4];
+                if (WDIR) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) wq[f] = rwf[d][f];
+                    if (ks + DB < TOTAL) wfload(ks + DB, rwf[d]);
+                } else if (ks + DB < TOTAL) wbload(ks + DB, rwb[d]);
                 const int ky = tap / 3, kx = tap - ky * 3;                    // tap t = kh * 3 + kw at (kh - 1, kw - 1)   (pack_conv)
                 const int shift = chunk * TSLICE + ky * PITCH + (kx - 1 + HX0) * REC;
                 int xo[2];
@@ -336,8 +360,11 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
                 f16x8 wh[2], wl[2], xh[2][2], xl[2][2];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    wh[kb] = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][0]);
-                    wl[kb] = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][1]);
+                    if (WDIR) { wh[kb] = wq[2 * kb]; wl[kb] = wq[2 * kb + 1]; }
+                    else {
+                        wh[kb] = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][0]);
+                        wl[kb] = *reinterpret_cast<const f16x8*>(Wf + w_sw[kb][1]);
+                    }
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         xh[kb][i] = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32);
@@ -345,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
                     }
                 }
                 // PRIV: the private tile's fragments are in flight (LDS serves a wave in order): the next K-step's tile may follow them
-                if (PRIV && ks + 1 < TOTAL) wbstore(rwb[(d + 1) % DB]);
+                if (PRIV && !WDIR && ks + 1 < TOTAL) wbstore(rwb[(d + 1) % DB]);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
                         accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kb], xh[kb][i], accB[i], 0, 0, 0);
                         accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kb], xh[kb][i], accB[i], 0, 0, 0);
                     }
-                if (!PRIV) {
+                if (!PRIV && !WDIR) {
                     __syncthreads();              // everyone is done reading the shared weight tile
                     if (ks + 1 < TOTAL) {
                         wbstore(rwb[(d + 1) % DB]);
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             }
         }
     }
-    if (PRIV) __syncthreads();                    // every wave is done with the t_a image (the t_b image and the 2c stage replace it)
+    if (PRIV || WDIR) __syncthreads();            // every wave is done with the t_a image (the t_b image and the 2c stage replace it)
 
     // weight loader of the last convolution.  Identity blocks: a stage = K-steps (2 st, 2 st + 1) of the 128 rows of chunk q: 8 float4 per thread.
     // Projection blocks: a stage = ONE K-step of chunk q (its K runs over [t_b | x]: row stride F1 + CIN), and the x slice of the K-step beside it.
