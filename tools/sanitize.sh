@@ -13,17 +13,24 @@ if [ "$1" = "build" ]; then
     mkdir -p tools/ab /tmp/p2p_asan
     python -c "from pix2pose_amd import build; build.build()"     # regenerates csrc/_build_id.cpp
     OBJS=""
-    for s in igemm igemm_halo igemm_halo8 igemm_halo_s2 igemm_stream resblock heads conv1 misc_kernels model pipeline resize_aa pnp comm; do
-        if [ "$MODE" = "ubsan" ]; then SAN="-Xarch_host -fsanitize=undefined -Xarch_host -D_GLIBCXX_ASSERTIONS"; else SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined"; fi
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC $SAN \
-            -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined -c pix2pose_amd/csrc/$s.hip -o /tmp/p2p_asan/$s.o &
-        OBJS="$OBJS /tmp/p2p_asan/$s.o"
-    done
-    wait
-    g++ -O1 -fPIC -c pix2pose_amd/csrc/_build_id.cpp -o /tmp/p2p_asan/_build_id.o
+    SRCS=$(python -c "from pix2pose_amd import build; print(' '.join(s[:-4] for s in build.SOURCES))")      # every source of the library
+    if [ "$MODE" = "ubsan" ]; then SAN="-Xarch_host -fsanitize=undefined -Xarch_host -D_GLIBCXX_ASSERTIONS"; else SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined"; fi
     if [ "$MODE" = "ubsan" ]; then LSAN="-fsanitize=undefined"; else LSAN="-fsanitize=address -fsanitize=undefined"; fi
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $LSAN -shared-libsan -o $OUT $OBJS /tmp/p2p_asan/_build_id.o -ldl
-    echo "built $OUT"
+    g++ -O1 -fPIC -c pix2pose_amd/csrc/_build_id.cpp -o /tmp/p2p_asan/_build_id.o
+    # twice: the shipped configuration, and the development twin (-DP2P_DEV_SWITCHES) the route-equivalence tests load through
+    # build.dev_switches() (P2P_DEV_LIB names the instrumented twin for them)
+    for variant in "" dev; do
+        OBJS=""; n=0
+        for s in $SRCS; do
+            /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC $SAN ${variant:+-DP2P_DEV_SWITCHES} \
+                -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined -c pix2pose_amd/csrc/$s.hip -o /tmp/p2p_asan/$s$variant.o &
+            OBJS="$OBJS /tmp/p2p_asan/$s$variant.o"
+            n=$((n + 1)); if [ $((n % 4)) -eq 0 ]; then wait; fi
+        done
+        wait
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $LSAN -shared-libsan -o ${OUT%.so}${variant:+_dev}.so $OBJS /tmp/p2p_asan/_build_id.o -ldl
+        echo "built ${OUT%.so}${variant:+_dev}.so"
+    done
     exit 0
 fi
 shift || true
@@ -36,5 +43,5 @@ fi
 # python itself is not instrumented: preload the runtime; leaks are not checked (the interpreter and HIP keep process-lifetime
 # allocations); the library is named through P2P_LIB (the binding then skips its build-id check)
 LD_PRELOAD=$RT ASAN_OPTIONS=${ASAN_OPTIONS:-detect_leaks=0:halt_on_error=1:abort_on_error=0:protect_shadow_gap=0} UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-    P2P_LIB=$PWD/$OUT python -m pytest tests -m gpu -q -x -p no:cacheprovider \
-    --deselect tests/test_bench_multirank_gpu.py --deselect tests/test_halo_gpu.py --deselect tests/test_fullsize_gpu.py::test_configs3_share_30_objects_256_detections "$@"
+    P2P_LIB=$PWD/$OUT P2P_DEV_LIB=$PWD/${OUT%.so}_dev.so python -m pytest tests -m gpu -q -x -p no:cacheprovider \
+    --deselect tests/test_bench_multirank_gpu.py "$@"
