@@ -37,6 +37,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
+#ifdef P2P_W3_STAMPS      // A/B builds: 100 MHz time stamps of the phases of a workgroup's tiles (tools/w3_stamps.py)
+__device__ unsigned long long g_w3_stamps[8 * 16 * 16];
+// slots 0..11: end of the K loop of wave 0..11; 12: tile start (after the top barrier), 13: K loop start, 14: after the end-of-K barrier (wave 0)
+#define W3_STAMP(k) do { if (lane == 0 && (blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 8 && n_tile_seen < 16) g_w3_stamps[((blockIdx.x >> 5) * 16 + n_tile_seen) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define W3_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -157,7 +165,13 @@ __global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino
     float amax = 0.f;
     char* const wimg = smem + wv * WIMG;             // this wave's image in buffer 0
 
+#ifdef P2P_W3_STAMPS
+    int n_tile_seen = -1;
+#endif
     for (int tl = tl0; tl < ntiles; tl += gridDim.x) {
+#ifdef P2P_W3_STAMPS
+    ++n_tile_seen;
+#endif
     int rest = tl / G4;
     // the phase rotates with the sweep: a workgroup's tiles would otherwise all be of one phase (gridDim.x is a multiple of G4), and the
     // phases with py = 1 are 1.5x the work of the others
@@ -246,6 +260,7 @@ __global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino
     const char* img0 = wimg + lk * WPLANE + (li >> 2) * 64 + (li & 3) * 16;
 
     lds_barrier();                                   // (persistent loop) the previous tile's exchange images have been read
+    if (wv == 0) W3_STAMP(12);
 
     auto body = [&](auto nky_c) {
         constexpr int NKY = decltype(nky_c)::value;
@@ -257,6 +272,7 @@ __global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino
                                                                               (unsigned)((S * NKY + 1) * 4096), 0x00020000);
         const unsigned uoff = (unsigned)lane * 16u;
         f16x8 u[2][4];                               // (half 0 hi, lo, half 1 hi, lo) of the even / odd K-steps
+        f16x8 vhp[2];                                // the next K-step's hi fragments
         auto uload = [&](int set, int kb) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) u[set][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + f * 1024, kb * 4096, 0));
@@ -265,12 +281,12 @@ __global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino
         vload_all(0, true);
         uload(0, 0);
         vstore_all(0);
+        if (wv == 0) W3_STAMP(13);
         // two slices per iteration: buffer and weight register set of every K-step are compile-time
         for (int s2 = 0; s2 < S; s2 += 2) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int s = s2 + half;
-                vload_all(s + 1, s + 1 < S);                             // lands during this slice's matrix work
 #pragma unroll
                 for (int ky = 0; ky < NKY; ++ky) {
                     const int kk = half * NKY + ky;
@@ -278,23 +294,37 @@ __global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino
                     if (s2 == 0)
 #endif
                     uload((kk + 1) & 1, s * NKY + ky + 1);               // (the panel's padding covers the K-step past the stream's end)
+                    // the next slice's V pieces AFTER the next K-step's U fragments: vmcnt counts in issue order, so the wait for those
+                    // fragments (one K-step from now) would otherwise wait for the V pieces too -- they have until the K-step after that
+                    if (ky == 0) vload_all(s + 1, s + 1 < S);
                     __builtin_amdgcn_sched_barrier(0);
                     const char* img = img0 + half * BUF + ky * 64;
+                    // hi fragments one K-step ahead inside a slice: a K-step starts with the four (U lo x V hi) products while its lo
+                    // fragments are still on their way from LDS (12 MFMAs per K-step do not hide an LDS round trip in front of them)
                     f16x8 vh[2], vl[2];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        vh[i] = *reinterpret_cast<const f16x8*>(img + i * 512);
+                        vh[i] = ky == 0 ? *reinterpret_cast<const f16x8*>(img + i * 512) : vhp[i];
                         vl[i] = *reinterpret_cast<const f16x8*>(img + i * 512 + 2 * WPLANE);
                     }
+                    if (ky + 1 < NKY) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) vhp[i] = *reinterpret_cast<const f16x8*>(img + 64 + i * 512);
+                    }
                     const f16x8* uc = u[kk & 1];
+                    // (every accumulator still takes its three products in the order lo x hi, hi x lo, hi x hi: same bits)
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c + 1], vh[i], acc[i][c], 0, 0, 0);
-                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vl[i], acc[i][c], 0, 0, 0);
-                            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vh[i], acc[i][c], 0, 0, 0);
-                        }
+                        for (int i = 0; i < 2; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c + 1], vh[i], acc[i][c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vl[i], acc[i][c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uc[2 * c], vh[i], acc[i][c], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 vstore_all(half ^ 1);                                    // (a slice past the last one: zeros nobody reads)
@@ -303,7 +333,9 @@ __global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino
     };
     if (py) body(std::integral_constant<int, 3>{});
     else body(std::integral_constant<int, 2>{});
+    W3_STAMP(wv);
     lds_barrier();                                   // every wave is done with its image: the exchange images may overwrite them
+    if (wv == 0) W3_STAMP(14);
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA with U as the A operand: row = channel (r & 3) + 8 (r >> 2) + 4 lk of the 32-channel
     //      half, column li = pair.  Pass i: every wave puts m-tile i of its unit into exchange image mh, then thread (pair = tid >> 4,
@@ -389,6 +421,13 @@ __global__ __launch_bounds__(NU * 384, 2 / NU) void wino3_gemm_kernel(const Wino
 }
 
 }  // namespace
+
+#ifdef P2P_W3_STAMPS
+extern "C" __attribute__((visibility("default"))) int p2p_dbg_w3_stamps(unsigned long long* host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w3_stamps), sizeof(g_w3_stamps));
+}
+#endif
 
 bool wino3_supported(int H, int W, int Cin, int Cout)
 {

@@ -128,13 +128,16 @@ template <int MODE>
 __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
 {
     constexpr int SROW = 320;                       // LDS bytes of one sample of a plane: 10 rows x 2 tiles x 16 B
-    constexpr int WPLANE = 4 * SROW;                // one plane of a wave's image (four samples)
+    constexpr int WPLANE = 4 * SROW + 128;          // one plane of a wave's image (four samples); + 128 B: the two k halves of a fragment read
+                                                    // (lanes 0..31 / 32..63, planes lk = 0 / 1) start 32 banks apart (1280 B apart they collided:
+                                                    // bank-conflict cycles 35 % of the LDS-active cycles, profiles/r06_sq_counters.txt)
     constexpr int WIMG = 4 * WPLANE;
-    constexpr int BUF = 12 * WIMG;
+    constexpr int BUF = WIMG;                       // a wave's two buffers sit next to each other (every LDS offset stays a 16-bit immediate)
+    constexpr int LDS_BYTES = 24 * WIMG;
     constexpr int XLD = 68;                         // exchange image: [position 6][pair 32][64 channels + 4] floats
     constexpr int XBUF = 6 * 32 * XLD * 4;
-    static_assert(2 * XBUF <= 2 * BUF, "two exchange images fit the two slice buffers");
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    static_assert(2 * XBUF <= LDS_BYTES, "two exchange images fit the slice buffers");
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
     }
     const int pair = tid >> 4, cq = tid & 15;       // epilogue role (threads 0..511)
     float amax = 0.f;
-    char* const wimg = smem + wv * WIMG;             // this wave's image in buffer 0
+    char* const wimg = smem + wv * 2 * WIMG;         // this wave's image in buffer 0
 
     for (int tl = tl0; tl < ntiles; tl += gridDim.x) {
     const int unit = tl / G4;
@@ -239,11 +242,11 @@ __global__ __launch_bounds__(768) void wino3o_gemm_kernel(const Wino3oParams p)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int s = s2 + half;
-                vload_all(s + 1, s + 1 < sq1);
 #pragma unroll
                 for (int ky = 0; ky < NKY; ++ky) {
                     const int kk = half * NKY + ky;
                     uload((kk + 1) & 1, kb0 + (s - sq0) * NKY + ky + 1);
+                    if (ky == 0) vload_all(s + 1, s + 1 < sq1);          // after the U fragments: vmcnt counts in issue order (wino3.hip)
                     __builtin_amdgcn_sched_barrier(0);
                     const char* img = img0 + half * BUF + (RO + ky) * 32;
                     f16x8 vh[2], vl[2];
