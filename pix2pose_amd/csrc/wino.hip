@@ -243,13 +243,6 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
         for (int f = 0; f < 4; ++f) u[set][f] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_u, uoff + f * 1024, kb * 4096, 0));
     };
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
     // V fragment of m-tile i, tap ky, half hl: plane (j, hl, lk), image row base_i + ky + (li >> 2), tile li & 3
     const char* img0 = smem + (j * 4 + lk) * PLANE + (li >> 2) * 64 + (li & 3) * 16;
@@ -268,12 +261,33 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
             *reinterpret_cast<f32x4*>(smem + bf * BUF + (j * 4 + pl) * PLANE + row * 64 + t * 16) = z;
         }
     }
-    // prologue: slice 0 -> buffer 0; the first two groups of slice 1 on their way
+    // prologue: slice 0 -> buffer 0; the first two groups of slice 1 on their way.  All ten pieces of slice 0 are loaded in ONE round trip
+    // (the accumulators are not live yet: the registers are there) -- through the two staging sets it took three, with every wave of the CU
+    // waiting in lockstep behind the tile's top barrier.
+#ifndef P2P_WINO_SERIAL_PROLOGUE
+    {
+        f32x4 pv[5][2];
+#pragma unroll
+        for (int g = 0; g < 5; ++g) { vload1(pv[g][0], 0, 2 * g, true); vload1(pv[g][1], 0, 2 * g + 1, true); }
+        uload(0, 0);
+#pragma unroll
+        for (int g = 0; g < 5; ++g) { vstore1(pv[g][0], 0, 2 * g); vstore1(pv[g][1], 0, 2 * g + 1); }
+    }
+#else
 #pragma unroll
     for (int g = 0; g < 5; ++g) { vload(g & 1, 0, g, true); vstore(g & 1, 0, g); }
     uload(0, 0);
+#endif
     vload(0, 1, 0, true);                            // S is even (Cin % 32 == 0)
     vload(1, 1, 1, true);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
     // Two slices (10 K-steps) per iteration: buffer, weight register set and staging register set of every K-step are compile-time.
     // K-step (s, ky): write group ky of slice s + 1 (loaded two K-steps ago), issue the load of the group two K-steps ahead.
