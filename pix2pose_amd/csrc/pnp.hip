@@ -391,6 +391,129 @@ __device__ __forceinline__ void gather_rows8(const double (&A)[36], double (&u8)
         }
 }
 
+// ---------------------------------------------------------------- 12x12 SVD on a TEAM of lane quads (the latency form)
+// A handful of problems (one detection at a time: the reference's own call shape) leaves the chip idle while a lone wave walks the 66
+// pair visits of a sweep one after the other.  The pairs (i, j) of one anti-diagonal i + j = t share no row and have their inputs once
+// the diagonals before are done, so a sweep is 21 steps of up to six INDEPENDENT rotations: a team of 32 lanes (eight quads, six of
+// them with a pair) walks the diagonals, quad g of the team taking pair (max(0, t - 11) + g, t - i).  The matrix lives in LDS (row
+// image, 12 x 12 doubles + the 12 squared norms per team); a quad reads its two rows, rotates them exactly as jacobi12_quad does (lane
+// q = columns 3q .. 3q + 2, the three sums as one chain of additions in OpenCV's order) and writes them back.  Every rotation sees the
+// values the sequential order would hand it => the same bits as jacobi12_quad / jacobi_svd_t<12, 12, false>.  The code of a step is
+// one loop body with run-time row indices (a few KB) where the register form is 66 unrolled bodies per sweep.
+constexpr int TEAM_LANES = 32;
+constexpr int TEAM_DOUBLES = 160;          // 144 matrix + 12 norms + padding
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sm: this team's TEAM_DOUBLES of LDS, the matrix already stored (sm[i * 12 + k], symmetric) and visible.  tl = lane within the team.
+// live = false: the team only keeps the wave company.  On exit u8 = rows 8..11 of the left singular vectors (all twelve columns) on
+// every lane of the team.  Returns false when a singular value is (numerically) zero (see jacobi12_quad).
+__device__ __forceinline__ bool jacobi12_team(double* __restrict__ sm, const int tl, const bool live, double (&u8)[48])
+{
+    const double eps = kDblEps * 10;
+    constexpr int max_iter = 30;
+    const int g = tl >> 2, q = tl & 3;
+    double* sW = sm + 144;
+    // squared norms of rows g and g + 6
+    if (g < 6) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int i = g + 6 * h;
+            double x[3];
+#pragma unroll
+            for (int e = 0; e < 3; e++) { const double t = sm[i * 12 + 3 * q + e]; x[e] = t * t; }
+            const double w = chain12(x);
+            if (q == 0) sW[i] = w;
+        }
+    }
+    wave_lds_sync();
+    bool team_live = live;
+#pragma unroll 1
+    for (int iter = 0; iter < max_iter; iter++) {
+        if (__builtin_amdgcn_ballot_w64(team_live) == 0) break;
+        bool changed = false;
+#pragma unroll 1
+        for (int t = 1; t <= 21; t++) {
+            const int i = (t > 11 ? t - 11 : 0) + g, j = t - i;
+            const bool valid = team_live & (i < j);
+            if (valid) {
+                double a = sW[i], b = sW[j];
+                double ri[3], rj[3], x[3], y[3];
+#pragma unroll
+                for (int e = 0; e < 3; e++) { ri[e] = sm[i * 12 + 3 * q + e]; rj[e] = sm[j * 12 + 3 * q + e]; x[e] = ri[e] * rj[e]; }
+                const double p = chain12(x);
+                if (!jacobi_skip(p, a, b, eps)) {
+                    double c, s;
+                    jacobi_cs(p, a, b, c, s);
+#pragma unroll
+                    for (int e = 0; e < 3; e++) {
+                        const double t0 = c * ri[e] + s * rj[e];
+                        const double t1 = -s * ri[e] + c * rj[e];
+                        sm[i * 12 + 3 * q + e] = t0; sm[j * 12 + 3 * q + e] = t1;
+                        x[e] = t0 * t0; y[e] = t1 * t1;
+                    }
+                    chain12x2(x, y, a, b);
+                    if (q == 0) { sW[i] = a; sW[j] = b; }
+                    changed = true;
+                }
+            }
+            wave_lds_sync();
+        }
+        // OpenCV leaves after a sweep without a rotation: the team's quads decide together
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(changed);
+        const int team_shift = (int)(threadIdx.x & 63 & ~(TEAM_LANES - 1));
+        if (((any >> team_shift) & 0xffffffffULL) == 0) team_live = false;
+    }
+    if (g < 6) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int i = g + 6 * h;
+            double x[3];
+#pragma unroll
+            for (int e = 0; e < 3; e++) { const double t = sm[i * 12 + 3 * q + e]; x[e] = t * t; }
+            const double w = sqrt_cr(chain12(x));
+            if (q == 0) sW[i] = w;
+        }
+    }
+    wave_lds_sync();
+    // selection sort, descending, on the singular values with the row index riding along (jacobi_svd_t swaps the rows themselves)
+    double W[12];
+    int idx[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { W[i] = sW[i]; idx[i] = i; }
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < 12; k++)
+            if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k = i + 1; k < 12; k++)
+            if (j == k) {
+                const double t = W[i]; W[i] = W[k]; W[k] = t;
+                const int ti = idx[i]; idx[i] = idx[k]; idx[k] = ti;
+            }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+        if (W[i] <= kDblMin) ok = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double sd = W[8 + r];
+        const double s = sd > kDblMin ? 1 / sd : 0.;
+        const double* row = sm + idx[8 + r] * 12;
+#pragma unroll
+        for (int k = 0; k < 12; k++) u8[r * 12 + k] = row[k] * s;
+    }
+    return ok;
+}
+
 // x = V diag(1/w) U^T b, singular values below sum(w)*2*eps dropped (OpenCV SVD back-substitution)
 template <int M, int N>
 __device__ __forceinline__ void svd_backsubst_t(const double (&w)[N], const double (&ut)[N * M], const double (&vt)[N * N],
@@ -757,11 +880,14 @@ __device__ void orientation(const double* abt, const double* pc0, const double* 
 
 // ---------------------------------------------------------------- 5-point EPnP, one lane, sequential
 // pws[15] (object, mm), us[10] (pixels).  Sequential summation order = OpenCV's.
-// QUAD: lanes (4h .. 4h + 3) run this together on the same inputs; the 12x12 SVD is shared between them (jacobi12_quad), everything
-// else is computed by all four (same inputs, same bits).  q = lane & 3.
-template <bool QUAD>
-__device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout, const int q)
+// MODE 1 (quad): lanes (4h .. 4h + 3) run this together on the same inputs; the 12x12 SVD is shared between them (jacobi12_quad),
+// everything else is computed by all four (same inputs, same bits).  q = lane & 3.  MODE 2 (team): the 32 lanes of a team run it together,
+// the SVD walks the anti-diagonals of a sweep on six of their quads (jacobi12_team; sm = the team's LDS, tl = lane in the team).
+template <int MODE>
+__device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout, const int q,
+                      double* __restrict__ sm = nullptr, const int tl = 0, const bool live = true)
 {
+    constexpr bool QUAD = MODE != 0;
     const int n = 5;
     double cws[4][3], c0[3] = {0, 0, 0}, ptp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     #pragma unroll
@@ -823,9 +949,20 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
                 #pragma unroll
                 for (int e = 0; e < 3; e++) A[p * 3 + e] += m2[p] * m2q[e];
         }
-        double w12[12];
-        solved = jacobi12_quad(A, w12);
-        if (solved) gather_rows8(A, u8);
+        if (MODE == 2) {
+            if (tl < 4) {
+                #pragma unroll
+                for (int p = 0; p < 12; p++)
+                    #pragma unroll
+                    for (int e = 0; e < 3; e++) sm[p * 12 + 3 * q + e] = A[p * 3 + e];
+            }
+            wave_lds_sync();
+            solved = jacobi12_team(sm, tl, live, u8);
+        } else {
+            double w12[12];
+            solved = jacobi12_quad(A, w12);
+            if (solved) gather_rows8(A, u8);
+        }
     }
     if (!solved) {          // single-lane solve (not QUAD, or a zero singular value: OpenCV's random fill-in lives in jacobi_svd_t)
         double mtm[144];
@@ -1070,24 +1207,28 @@ constexpr int HYP_ROUND0 = 16, HYP_ROUND1 = 64;
 // one of whose SIMDs is held by a 512-register wave, so single-wave workgroups -- which the dispatcher spreads over the chip --
 // took a whole CU each away from the generator kernels of the next batch (192 of 256 CUs for the first round of a 256-detection
 // batch: the ResNet front running under it was 2.7x slower); packed four to a CU they take a quarter as many.
+// MODE 2 (launches of a handful of problems): workgroups of ONE wave, two hypotheses per wave, each on a team of 32 lanes (jacobi12_team).
+template <int MODE>
 __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(const PnpProblem* __restrict__ probs, double* __restrict__ hyp,
                                                             const PnpFit* __restrict__ fits, int n_problems, int iterations, int min_points,
                                                             int h_begin, int h_stop, int ppb, int* __restrict__ act, int round, int wpp)
 {
     __shared__ int s_idx_wg[4][MAX_ITERS][5];    // per wave; ppb == 4: rows 16 sub + it (it < 16); ppb == 1: row it
+    __shared__ double s_team[MODE == 2 ? 4 * (64 / TEAM_LANES) * TEAM_DOUBLES : 1];
     int (*s_idx)[5] = s_idx_wg[threadIdx.x >> 6];
     const int tid = threadIdx.x & 63;
     const int lanes = 64 / ppb;                  // lanes per problem: FOUR per hypothesis (lane quads share the 12x12 SVD, jacobi12_quad)
+    const int hpp = MODE == 2 ? lanes / TEAM_LANES : lanes >> 2;      // hypotheses per pass of a problem's lanes
     const int sub = tid / lanes, lane_in = tid - sub * lanes;
     // Round 0 takes the problems in order (and clears the lists of the later rounds); rounds 1 and 2 take theirs from the list the
     // scoring pass of the round before appended to (act: [count1, count2, list1[n], list2[n]]), so that the few problems still
     // running are packed four to a workgroup: the waves of the other workgroups leave at once.
     // wpp waves share a problem's hypothesis range, 16 hypotheses each (the later rounds: 48 and 36 hypotheses -- walked by one wave
     // they were three passes of 0.5 ms on the critical path of exactly the detections that are slow already)
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int prob = (wave_g / wpp) * ppb + sub;
-    h_begin += (wave_g % wpp) * (lanes >> 2);
-    h_stop = min(h_stop, h_begin + (wpp > 1 ? lanes >> 2 : MAX_ITERS));
+    h_begin += (wave_g % wpp) * hpp;
+    h_stop = min(h_stop, h_begin + (wpp > 1 ? hpp : MAX_ITERS));
     if (round == 0) {
         if (blockIdx.x == 0 && threadIdx.x < 2) act[threadIdx.x] = 0;
         if (prob < n_problems) {                 // round 0 is one wave per problem: it clears the problem's inlier counters (pnp_count_kernel adds to them)
@@ -1135,8 +1276,8 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
 
     // ---- 2. hypotheses: one lane QUAD each; a wave's lane group walks its range in passes of lanes / 4
     const int q4 = lane_in & 3;
-    for (int h0 = h_begin; h0 < h_end; h0 += lanes >> 2) {
-    const int hi = h0 + (lane_in >> 2);
+    for (int h0 = h_begin; h0 < h_end; h0 += hpp) {
+    const int hi = h0 + (MODE == 2 ? lane_in / TEAM_LANES : lane_in >> 2);
     if (active && hi < h_end) {
         const float* PX = pb.pts;
         const float* PY = pb.pts + (size_t)pb.cap;
@@ -1156,10 +1297,13 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
             us[2 * i + 1] = yn * pb.K[4] + pb.K[5];
         }
         double R[9], t[3], rvec[3];
-        epnp5<true>(cam, pws, us, R, t, q4);
+        if (MODE == 2)
+            epnp5<2>(cam, pws, us, R, t, q4, s_team + ((threadIdx.x >> 6) * (64 / TEAM_LANES) + (tid / TEAM_LANES)) * TEAM_DOUBLES, tid & (TEAM_LANES - 1));
+        else
+            epnp5<1>(cam, pws, us, R, t, q4);
         rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
         rodrigues_v2r(rvec, R);
-        if (q4 == 0) {
+        if (MODE == 2 ? (tid & (TEAM_LANES - 1)) == 0 : q4 == 0) {
             double* h = hyp + ((size_t)prob * MAX_ITERS + hi) * 12;
             for (int k = 0; k < 9; k++) h[k] = R[k];
             for (int k = 0; k < 3; k++) h[9 + k] = t[k];
@@ -1481,11 +1625,16 @@ __device__ __forceinline__ double mtm_entry(const double (&g)[56], const Cam& ca
 // run one after the other on one lane; the kernel is a pure latency chain (the tail of a blocking call and of a single detection
 // waits for it): 0.62 -> 0.54 ms for the 768 problems of a 256-detection batch, 0.45 -> 0.39 ms for the three of one detection
 // (the 12x12 SVD dominates).
+// TEAM (launches of a handful of problems): a team of 32 lanes per problem -- the SVD on six of its quads (jacobi12_team), the beta
+// cases on quads 0..2 -- in workgroups of one wave.
+template <bool TEAM>
 __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
 {
-    const int li = blockIdx.x * 256 + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
+    __shared__ double s_team[TEAM ? 4 * (64 / TEAM_LANES) * TEAM_DOUBLES : 1];
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
     const int q4 = li & 3, qi = li >> 2;                // a lane QUAD per (problem, beta case): the quad shares the 12x12 SVD
-    const int pi = qi / 3, c = qi - pi * 3;
+    const int tl = li & (TEAM_LANES - 1);
+    const int pi = TEAM ? li / TEAM_LANES : qi / 3, c = TEAM ? min(tl >> 2, 2) : qi - pi * 3;
     if (pi >= n_problems) return;
     PnpFit& fit = fits[pi];
     if (fit.state != 0) return;
@@ -1510,8 +1659,20 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
                 const double v0 = mtm_entry(g, cam, p, e), v1 = mtm_entry(g, cam, p, 3 + e), v2 = mtm_entry(g, cam, p, 6 + e), v3 = mtm_entry(g, cam, p, 9 + e);
                 A[p * 3 + e] = q4 == 0 ? v0 : q4 == 1 ? v1 : q4 == 2 ? v2 : v3;
             }
-        solved = jacobi12_quad(A, w12);
-        if (solved) gather_rows8(A, u8);
+        if (TEAM) {
+            double* sm = s_team + (threadIdx.x / TEAM_LANES) * TEAM_DOUBLES;
+            if (tl < 4) {
+#pragma unroll
+                for (int p = 0; p < 12; p++)
+#pragma unroll
+                    for (int e = 0; e < 3; e++) sm[p * 12 + 3 * q4 + e] = A[p * 3 + e];
+            }
+            wave_lds_sync();
+            solved = jacobi12_team(sm, tl, true, u8);
+        } else {
+            solved = jacobi12_quad(A, w12);
+            if (solved) gather_rows8(A, u8);
+        }
     }
     if (!solved) {          // a zero singular value: the single-lane routine has OpenCV's random fill-in
         double mtm[144], w12[12];
@@ -1552,7 +1713,7 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
         }
         double R[3][3], t[3];
         orientation(abt, pc0, cws[0], R, t);
-        if (q4 == 0) {
+        if (TEAM ? (tl < 12 && q4 == 0) : q4 == 0) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {
 #pragma unroll
@@ -1659,15 +1820,23 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
     static const int eager_max = dev_env("P2P_PNP_EAGER_MAX") ? atoi(dev_env("P2P_PNP_EAGER_MAX")) : 48;      // development builds: 0 = rounds of 16 / 48 / 36 always
     static const int eager_stop = dev_env("P2P_PNP_EAGER_STOP") ? atoi(dev_env("P2P_PNP_EAGER_STOP")) : 48;   // development builds: 32 / 48 / 64
     const bool eager = n_problems <= eager_max;
+    // the same handful of problems: every 12x12 SVD on a team of 32 lanes (jacobi12_team) -- same bits, a third of the dependent steps
+    static const bool team_ok = !(dev_env("P2P_PNP_TEAM") && atoi(dev_env("P2P_PNP_TEAM")) == 0);      // development builds: 0 = the quad form always
+    const bool team = eager && team_ok;
     const int stops[3] = {eager ? eager_stop : pnp::HYP_ROUND0, eager ? (eager_stop < pnp::HYP_ROUND1 ? pnp::HYP_ROUND1 : pnp::MAX_ITERS) : pnp::HYP_ROUND1, pnp::MAX_ITERS};
     int h_begin = 0;
     for (int r = 0; r < 3; ++r) {
         const int ppb = 1;          // a wave per problem: 16 hypotheses x 4 lanes
-        const int wpp = (std::min(stops[r], iterations) - h_begin + pnp::HYP_ROUND0 - 1) / pnp::HYP_ROUND0;      // waves per problem: 16 hypotheses each
+        const int per_wave = team ? 64 / pnp::TEAM_LANES : pnp::HYP_ROUND0;
+        const int wpp = (std::min(stops[r], iterations) - h_begin + per_wave - 1) / per_wave;      // waves per problem: 16 hypotheses each (team form: 2)
         {
             ProfScope ps(12, s);
-            hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel, dim3((n_problems * wpp + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
-                               min_points, h_begin, stops[r], ppb, act, r, wpp);
+            if (team)
+                hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel<2>, dim3(n_problems * wpp), dim3(64), 0, s, probs, workspace, fits, n_problems, iterations,
+                                   min_points, h_begin, stops[r], ppb, act, r, wpp);
+            else
+                hipLaunchKernelGGL(pnp::pnp_hypotheses_kernel<1>, dim3((n_problems * wpp + 3) / 4), dim3(256), 0, s, probs, workspace, fits, n_problems, iterations,
+                                   min_points, h_begin, stops[r], ppb, act, r, wpp);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // counts of the round's hypotheses: work items (problem, chunk of 8 hypotheses, slice of the points) walked by a bounded grid.
@@ -1694,7 +1863,10 @@ hipError_t launch_pnp_ransac(const PnpProblem* probs, PnpResult* results, int n_
         if (iterations <= h_begin) break;
     }
     ProfScope ps(15, s);
-    hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel, dim3((12 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
+    if (team)
+        hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel<true>, dim3((n_problems + 1) / 2), dim3(64), 0, s, probs, fits, n_problems);
+    else
+        hipLaunchKernelGGL(pnp::pnp_fit_solve_kernel<false>, dim3((12 * n_problems + 255) / 256), dim3(256), 0, s, probs, fits, n_problems);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(pnp::pnp_fit_select_kernel, dim3(n_problems), dim3(256), 0, s, probs, workspace, fits, results, reproj_err);
     return hipGetLastError();
