@@ -89,6 +89,7 @@ __device__ __forceinline__ double sqrt_cr(double x)
 __device__ __forceinline__ bool jacobi_skip(const double p, const double a, const double b, const double eps)
 {
     const double ab = a * b, pp = p * p, lim = (eps * eps) * ab;
+    if ((p == 0.0) & (ab >= 0.0)) return true;          // 0 <= eps * sqrt(ab) whatever ab is (zero-padded rows land here)
     const bool in_range = (pp > 1e-280) & (pp < 1e280) & (ab > 1e-250) & (ab < 1e280);
     if (in_range & (pp > lim * 1.000001)) return false;
     if (in_range & (pp < lim * 0.999999)) return true;
@@ -135,8 +136,11 @@ struct Rng {
 // serial dependency chain; with scratch arrays every element access was a memory round trip and one
 // 5-point EPnP took ~3 ms.  Operation order is unchanged (sequential sums), so results are bit for
 // bit those of the rolled loops.
+// n_live < N: rows n_live .. N - 1 are zero padding (a narrower system run in the code of the wider one, betas_approx_any).  A zero row never
+// rotates (p = 0 is "already orthogonal"), sorts behind every live row and is dropped by the back-substitution; it only has to be kept out
+// of OpenCV's fill-in of zero singular values.  The live rows see the operations of jacobi_svd_t<M, n_live> in the same order.
 template <int M, int N, bool WITH_V>
-__device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N], double* Vt)
+__device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N], double* Vt, const int n_live = N)
 {
     const double eps = kDblEps * 10;
     constexpr int max_iter = M > 30 ? M : 30;
@@ -220,7 +224,7 @@ __device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N]
     for (int i = 0; i < N; i++) {
         double sd = W[i];
 #pragma unroll 1
-        for (int ii = 0; ii < 100 && sd <= kDblMin; ii++) {
+        for (int ii = 0; ii < 100 && sd <= kDblMin && i < n_live; ii++) {
             const double val0 = 1. / M;
 #pragma unroll
             for (int k = 0; k < M; k++) At[i * M + k] = (rng.next() & 256) != 0 ? val0 : -val0;
@@ -402,6 +406,7 @@ __device__ __forceinline__ void gather_rows8(const double (&A)[36], double (&u8)
 // one loop body with run-time row indices (a few KB) where the register form is 66 unrolled bodies per sweep.
 constexpr int TEAM_LANES = 32;
 constexpr int TEAM_DOUBLES = 160;          // 144 matrix + 12 norms + padding
+typedef __attribute__((address_space(3))) double lds_double;      // the team's matrix is handed down as an LDS pointer: ds_read / ds_write, not flat accesses
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -412,12 +417,12 @@ __device__ __forceinline__ void wave_lds_sync()
 // sm: this team's TEAM_DOUBLES of LDS, the matrix already stored (sm[i * 12 + k], symmetric) and visible.  tl = lane within the team.
 // live = false: the team only keeps the wave company.  On exit u8 = rows 8..11 of the left singular vectors (all twelve columns) on
 // every lane of the team.  Returns false when a singular value is (numerically) zero (see jacobi12_quad).
-__device__ __forceinline__ bool jacobi12_team(double* __restrict__ sm, const int tl, const bool live, double (&u8)[48])
+__device__ __forceinline__ bool jacobi12_team(lds_double* sm, const int tl, const bool live, double (&u8)[48])
 {
     const double eps = kDblEps * 10;
     constexpr int max_iter = 30;
     const int g = tl >> 2, q = tl & 3;
-    double* sW = sm + 144;
+    lds_double* sW = sm + 144;
     // squared norms of rows g and g + 6
     if (g < 6) {
 #pragma unroll
@@ -431,15 +436,24 @@ __device__ __forceinline__ bool jacobi12_team(double* __restrict__ sm, const int
         }
     }
     wave_lds_sync();
+    // Sweeps overlap: pair (i, j) of sweep s has its inputs at step 12 s + i + j (the last visits of its rows: (i, j - 1) or (i - 1, i) one or two
+    // steps before, (i - 1, j) one step before, for i = 0 the rows' last visits of sweep s - 1 at 12 s + j - 1), so while sweep s - 1 walks its
+    // diagonals 13 .. 21, sweep s walks 1 .. 9 -- never more than six pairs in one step.  OpenCV leaves after a sweep without a rotation; the
+    // diagonals of the next sweep taken by then found the matrix that sweep had found: they rotated nothing either.
     bool team_live = live;
+    bool chg_lo = false, chg_hi = false;            // "changed" of the older / the newer sweep in flight
+    const int team_shift = (int)(threadIdx.x & 63 & ~(TEAM_LANES - 1));
 #pragma unroll 1
-    for (int iter = 0; iter < max_iter; iter++) {
+    for (int s_hi = 0; s_hi <= max_iter; s_hi++) {
         if (__builtin_amdgcn_ballot_w64(team_live) == 0) break;
-        bool changed = false;
 #pragma unroll 1
-        for (int t = 1; t <= 21; t++) {
-            const int i = (t > 11 ? t - 11 : 0) + g, j = t - i;
-            const bool valid = team_live & (i < j);
+        for (int t_hi = 1; t_hi <= 12; t_hi++) {
+            const int t_lo = t_hi + 12;
+            const int n_lo = (s_hi >= 1 && t_lo <= 21) ? ((t_lo - 1) >> 1) - (t_lo - 11) + 1 : 0;
+            const bool lo = g < n_lo;
+            const int t = lo ? t_lo : t_hi;
+            const int i = (t > 11 ? t - 11 : 0) + (lo ? g : g - n_lo), j = t - i;
+            const bool valid = team_live & (i < j) & (lo | (s_hi < max_iter));
             if (valid) {
                 double a = sW[i], b = sW[j];
                 double ri[3], rj[3], x[3], y[3];
@@ -458,15 +472,16 @@ __device__ __forceinline__ bool jacobi12_team(double* __restrict__ sm, const int
                     }
                     chain12x2(x, y, a, b);
                     if (q == 0) { sW[i] = a; sW[j] = b; }
-                    changed = true;
+                    if (lo) chg_lo = true; else chg_hi = true;
                 }
             }
             wave_lds_sync();
+            if (t_hi == 9 && s_hi >= 1) {           // sweep s_hi - 1 has walked its last diagonal: the team's quads decide together
+                const unsigned long long any = __builtin_amdgcn_ballot_w64(chg_lo);
+                if (((any >> team_shift) & 0xffffffffULL) == 0) team_live = false;
+            }
         }
-        // OpenCV leaves after a sweep without a rotation: the team's quads decide together
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(changed);
-        const int team_shift = (int)(threadIdx.x & 63 & ~(TEAM_LANES - 1));
-        if (((any >> team_shift) & 0xffffffffULL) == 0) team_live = false;
+        chg_lo = chg_hi; chg_hi = false;
     }
     if (g < 6) {
 #pragma unroll
@@ -507,7 +522,7 @@ __device__ __forceinline__ bool jacobi12_team(double* __restrict__ sm, const int
     for (int r = 0; r < 4; r++) {
         const double sd = W[8 + r];
         const double s = sd > kDblMin ? 1 / sd : 0.;
-        const double* row = sm + idx[8 + r] * 12;
+        const lds_double* row = sm + idx[8 + r] * 12;
 #pragma unroll
         for (int k = 0; k < 12; k++) u8[r * 12 + k] = row[k] * s;
     }
@@ -541,14 +556,14 @@ __device__ __forceinline__ void svd_backsubst_t(const double (&w)[N], const doub
 
 // least squares A x = b (A row-major 6 x N, N <= 5) through the SVD
 template <int N>
-__device__ __forceinline__ void solve_svd6(const double* A, const double* b, double* x)
+__device__ __forceinline__ void solve_svd6(const double* A, const double* b, double* x, const int n_live = N)
 {
     double w[N], ut[N * 6], vt[N * N];
 #pragma unroll
     for (int i = 0; i < N; i++)
 #pragma unroll
         for (int k = 0; k < 6; k++) ut[i * 6 + k] = A[k * N + i];
-    jacobi_svd_t<6, N, true>(ut, w, vt);
+    jacobi_svd_t<6, N, true>(ut, w, vt, n_live);
     svd_backsubst_t<6, N>(w, ut, vt, b, x);
 }
 
@@ -762,6 +777,35 @@ __device__ void betas_approx_3(const double* l, const double* rho, double* betas
     betas[3] = 0.0;
 }
 
+// The three starting points in ONE instruction stream, for lanes that hold different cases side by side (the quad / team forms: walked one
+// after the other the three routines above were a third of a solve).  Case c's system is written into the 6 x 5 frame of case 3 -- its own
+// columns first, zero columns behind them -- and solved by the same code; the live columns go through exactly the operations of
+// solve_svd6<4> / <3> / <5> (see jacobi_svd_t), so the betas are those of betas_approx_c bit for bit.
+__device__ void betas_approx_any(const double* l, const double* rho, const int c, double* betas)
+{
+    double l5[30], b5[5];
+    #pragma unroll
+    for (int i = 0; i < 6; i++) {
+        l5[5 * i] = l[10 * i];
+        l5[5 * i + 1] = l[10 * i + 1];
+        l5[5 * i + 2] = c == 1 ? l[10 * i + 3] : l[10 * i + 2];
+        l5[5 * i + 3] = c == 1 ? l[10 * i + 6] : c == 3 ? l[10 * i + 3] : 0.0;
+        l5[5 * i + 4] = c == 3 ? l[10 * i + 4] : 0.0;
+    }
+    solve_svd6<5>(l5, rho, b5, c == 1 ? 4 : c == 2 ? 3 : 5);
+    const bool neg = b5[0] < 0;
+    const double b0 = sqrt_cr(neg ? -b5[0] : b5[0]);
+    if (c == 1) {
+        betas[0] = b0;
+        betas[1] = (neg ? -b5[1] : b5[1]) / b0; betas[2] = (neg ? -b5[2] : b5[2]) / b0; betas[3] = (neg ? -b5[3] : b5[3]) / b0;
+    } else {
+        betas[0] = b5[1] < 0 ? -b0 : b0;
+        betas[1] = (neg ? b5[2] < 0 : b5[2] > 0) ? sqrt_cr(neg ? -b5[2] : b5[2]) : 0.0;
+        betas[2] = c == 3 ? b5[3] / betas[0] : 0.0;
+        betas[3] = 0.0;
+    }
+}
+
 // Householder least squares for the 6x4 Gauss-Newton system (A destroyed)
 __device__ void qr_solve(double* A, double* b, double* X)
 {
@@ -885,7 +929,7 @@ __device__ void orientation(const double* abt, const double* pc0, const double* 
 // the SVD walks the anti-diagonals of a sweep on six of their quads (jacobi12_team; sm = the team's LDS, tl = lane in the team).
 template <int MODE>
 __device__ void epnp5(const Cam& cam, const double* pws, const double* us, double* Rout, double* tout, const int q,
-                      double* __restrict__ sm = nullptr, const int tl = 0, const bool live = true)
+                      lds_double* sm = nullptr, const int tl = 0, const bool live = true)
 {
     constexpr bool QUAD = MODE != 0;
     const int n = 5;
@@ -907,7 +951,7 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
             for (int b = 0; b < 3; b++) ptp[a * 3 + b] += d[a] * d[b];
     }
 #ifdef P2P_PNP_TIMING
-    long long tk[8]; int nk = 0;
+    long long tk[12]; int nk = 0;
     tk[nk++] = clock64();
 #endif
     control_points(c0, ptp, n, cws);
@@ -1004,6 +1048,9 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
     // one beta case: Gauss-Newton from the case's starting point, camera-frame control points, absolute orientation, mean reprojection error
     auto finish_case = [&](double* betas, double (&R)[3][3], double (&t)[3]) -> double {
         gauss_newton(l, rho, betas);
+#ifdef P2P_PNP_TIMING
+        tk[nk++] = clock64();
+#endif
         double ccs[4][3], pcs[15];
         compute_ccs(betas, ut, ccs);
         #pragma unroll
@@ -1032,6 +1079,9 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
                 abt[3 * j + 2] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + 2] - pw0[2]);
             }
         orientation(abt, pc0, pw0, R, t);
+#ifdef P2P_PNP_TIMING
+        tk[nk++] = clock64();
+#endif
         double sum2 = 0.0;
         #pragma unroll
         for (int i = 0; i < n; i++) {
@@ -1050,12 +1100,13 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
         // and now runs ONCE for the three: two of the three tails (a third of the solve) are gone.
         const int c = q < 2 ? q + 1 : 3;
         double betas[4], R[3][3], t[3];
-        if (c == 1) betas_approx_1(l, rho, betas);
-        else if (c == 2) betas_approx_2(l, rho, betas);
-        else betas_approx_3(l, rho, betas);
+        betas_approx_any(l, rho, c, betas);
+#ifdef P2P_PNP_TIMING
+        tk[nk++] = clock64();
+#endif
         const double err = finish_case(betas, R, t);
 #ifdef P2P_PNP_TIMING
-        tk[nk++] = clock64(); tk[nk++] = tk[nk - 1]; tk[nk++] = tk[nk - 1];
+        tk[nk++] = clock64();
 #endif
         // OpenCV's rule, in its order: keep case 1; take case 2 if its error is smaller; then case 3 if smaller than the best so far
         const double e1 = quad_bcast<0>(err), e2 = quad_bcast<1>(err), e3 = quad_bcast<2>(err);
@@ -1097,8 +1148,13 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
         }
     }
 #ifdef P2P_PNP_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("epnp5 cycles: setup %lld  mtm+svd12 %lld  case1 %lld  case2 %lld  case3 %lld\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (QUAD)
+            printf("epnp5 cycles: setup %lld  mtm+svd12 %lld  L+rho+betas_approx x3 %lld  gauss_newton %lld  ccs+orientation %lld  error %lld\n", tk[1] - tk[0], tk[2] - tk[1],
+                   tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
+        else
+            printf("epnp5 cycles: setup %lld  mtm+svd12 %lld  rest %lld\n", tk[1] - tk[0], tk[2] - tk[1], tk[nk - 1] - tk[2]);
+    }
 #endif
 }
 
@@ -1298,7 +1354,7 @@ __global__ __launch_bounds__(256, P2P_PNP_HYP_WAVES) void pnp_hypotheses_kernel(
         }
         double R[9], t[3], rvec[3];
         if (MODE == 2)
-            epnp5<2>(cam, pws, us, R, t, q4, s_team + ((threadIdx.x >> 6) * (64 / TEAM_LANES) + (tid / TEAM_LANES)) * TEAM_DOUBLES, tid & (TEAM_LANES - 1));
+            epnp5<2>(cam, pws, us, R, t, q4, (lds_double*)(s_team + ((threadIdx.x >> 6) * (64 / TEAM_LANES) + (tid / TEAM_LANES)) * TEAM_DOUBLES), tid & (TEAM_LANES - 1));
         else
             epnp5<1>(cam, pws, us, R, t, q4);
         rodrigues_r2v(R, rvec);          // the model handed to RANSAC is (rvec, tvec)
@@ -1660,7 +1716,7 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
                 A[p * 3 + e] = q4 == 0 ? v0 : q4 == 1 ? v1 : q4 == 2 ? v2 : v3;
             }
         if (TEAM) {
-            double* sm = s_team + (threadIdx.x / TEAM_LANES) * TEAM_DOUBLES;
+            lds_double* sm = (lds_double*)(s_team + (threadIdx.x / TEAM_LANES) * TEAM_DOUBLES);
             if (tl < 4) {
 #pragma unroll
                 for (int p = 0; p < 12; p++)
@@ -1690,9 +1746,7 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
     compute_rho(cws, rho);
     {
         double betas[4];
-        if (c == 0) betas_approx_1(l, rho, betas);
-        else if (c == 1) betas_approx_2(l, rho, betas);
-        else betas_approx_3(l, rho, betas);
+        betas_approx_any(l, rho, c + 1, betas);
         gauss_newton(l, rho, betas);
         double ccs[4][3];
         compute_ccs(betas, ut, ccs);
