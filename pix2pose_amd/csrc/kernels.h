@@ -286,6 +286,7 @@ struct StreamMulti {
     StreamPhase ph[4];
 };
 bool igemm_stream_supported(const IgemmParams& p);
+int igemm_stream_waves(const IgemmParams& p, int tm);      // waves of a streaming launch with 32 tm x 32 tiles (before any K split)
 void stream_phase_of(const IgemmParams& p, const StreamOrder& o, StreamPhase* ph);
 hipError_t launch_igemm_stream(const IgemmParams& p, const StreamMulti& mp, hipStream_t s);
 

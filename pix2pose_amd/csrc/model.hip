@@ -988,11 +988,48 @@ static int launch_prepared(Ctx& X, const PreparedConv* pc, int n)
     return P2P_OK;
 }
 
+static bool small_split_route() { static const bool on = dev_env("P2P_NO_SMALL_SPLIT") == nullptr; return on; }     // development builds: A/B against the single chain
+
 static int run_conv(Ctx& X, const ConvLayer& L, const ConvCall& c)
 {
     PreparedConv pc;
     int rc = prepare_conv(X, L, c, pc);
     if (rc) return rc;
+    return launch_prepared(X, &pc, 1);
+}
+
+// The long-K layers of a pass over a few inputs (one detection at a time: conv4 walks 400 K-steps on 16 waves, deconv1 300 on 64 -- a
+// quarter of such a pass while the chip idles): under "auto" -- the mode whose form already depends on the pass size -- the streaming launch
+// splits K over enough waves to occupy the chip (raw partial sums into the Winograd workspace, which such a pass does not use for this layer)
+// and splitk_reduce_kernel applies the epilogue.  The partial sums are added in a fixed order: the bits depend on the pass size (as the
+// Winograd forms' do), not on the run.  "off" / "always" keep the single chain (size-independent bits).
+static int run_conv_small(Ctx& X, const ConvLayer& L, const ConvCall& c)
+{
+    PreparedConv pc;
+    int rc = prepare_conv(X, L, c, pc);
+    if (rc) return rc;
+    const IgemmParams& p = pc.p;
+    if (pc.stream && X.wino_mode == P2P_WINOGRAD_AUTO && small_split_route() && c.ksplit == 1 && !c.residual && c.mode == EPI_NORMAL && c.os == 1 &&
+        c.out_coff == 0 && c.out_cstride == L.Cout && c.Hout == c.Hg && c.Wout == c.Wg && p.n_groups <= 1) {
+        const int tiles = igemm_stream_waves(p, 1);
+        // (measured per pass size, tools/time_small.py with the development switches below: a launch of more waves than these is bound by what
+        // its waves stream from L2 -- every wave loads its own operands -- and a split adds nothing: deconv2 at one input 55 us either way)
+        static const int max_s1 = dev_env("P2P_SMALL_SPLIT_S1") ? atoi(dev_env("P2P_SMALL_SPLIT_S1")) : 128;      // development builds: largest launch (waves) that still splits
+        static const int max_s2 = dev_env("P2P_SMALL_SPLIT_S2") ? atoi(dev_env("P2P_SMALL_SPLIT_S2")) : 256;     // stride-2 gathers stream at half the rate per wave
+        int S = tiles <= (c.in_stride == 2 ? max_s2 : max_s1) ? std::min(std::min(16, 768 / std::max(1, tiles)), p.ksteps / 12) : 1;
+        while (S >= 2 && (size_t)S * p.M * L.Cout > (size_t)X.max_batch * 64 * 64 * 128 * 2) --S;      // the "wv" workspace (kBuffers)
+        if (S >= 2) {
+            ConvCall c2 = c;
+            c2.ksplit = S; c2.partial = X.cur->act["wv"];
+            PreparedConv pc2;
+            if ((rc = prepare_conv(X, L, c2, pc2))) return rc;
+            if (pc2.stream) {
+                if ((rc = launch_prepared(X, &pc2, 1))) return rc;
+                HIP_TRY(launch_splitk_reduce(c2.partial, S, p.M, L.Cout, L.scale, L.shift, c.act, LEAKY, c.out, L.prec == PREC_F16X3 ? X.range_cur : nullptr, X.cur->stream));
+                return P2P_OK;
+            }
+        }
+    }
     return launch_prepared(X, &pc, 1);
 }
 
@@ -1005,7 +1042,7 @@ static int conv_layer(Ctx& X, const ConvLayer& L, const float* in, int N, int H,
     c.N = N; c.Hin = H; c.Win = W; c.Hg = H / stride; c.Wg = W / stride; c.in_stride = stride;
     c.out = out; c.Hout = c.Hg; c.Wout = c.Wg; c.out_cstride = L.Cout;
     c.act = act; c.residual = residual; c.res_cstride = L.Cout;
-    return run_conv(X, L, c);
+    return L.ntaps == 25 ? run_conv_small(X, L, c) : run_conv(X, L, c);
 }
 
 // The 5x5 stride-1 layers of split-f16 models in Winograd form (wino.hip: 2.5x fewer MFMA products).  Measured per generator pass
@@ -1090,7 +1127,7 @@ static int concat_conv(Ctx& X, const ConvLayer& L, const float* a, int Ca, const
     c.N = N; c.Hin = H; c.Win = H; c.Hg = H; c.Wg = H;
     c.out = out; c.Hout = H; c.Wout = H; c.out_cstride = L.Cout;
     c.act = ACT_LEAKY;
-    return run_conv(X, L, c);
+    return run_conv_small(X, L, c);
 }
 
 // Conv2DTranspose 5x5/2 + BN + LeakyReLU as four phase convolutions
