@@ -199,6 +199,8 @@ struct WinoParams {
     unsigned* range_acc;   // operand-range guard: the transform reports the TRANSFORMED operand, the GEMM epilogue what it stores
     int n_groups;          // mixed-object batches: samples [grp[g].sample0, grp[g + 1].sample0) use group g's panel
     WinoGroup grp[IGEMM_MAX_GROUPS + 1];
+    int ksplit;            // 1, or the channel slices cut into ksplit ranges (launches under one workgroup per CU): raw sums after the -- linear --
+    float* partial;        //   inverse transform go to `partial` [ksplit][N * H * W][Cout], then launch_splitk_reduce (scale / shift / activation)
 };
 bool wino_supported(int H, int W, int Cin0, int Cin1, int Cout);
 size_t wino_v_bytes(int N, int H, int W, int Cin);

@@ -761,6 +761,7 @@ static int pack_block_ss(Model& M)
 // ------------------------------------------------------------------------------------------
 // activation workspace
 // ------------------------------------------------------------------------------------------
+constexpr size_t WINO_PARTIAL_FLOATS = (size_t)256 * 16 * 32 * 64;      // 256 (tile, K range) pairs x the 16 x 32 pixels x 64 channels of a tile
 static const struct { const char* name; size_t per_sample; } kBuffers[] = {
     // shared
     {"f4", 8 * 8 * 512}, {"enc", 256}, {"dd", 8 * 8 * 256}, {"u1", 16 * 16 * 256}, {"c1", 16 * 16 * 256},
@@ -787,6 +788,11 @@ int Ctx::ensure_lane(int i)
         float* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, b.per_sample * (size_t)max_batch * sizeof(float)));
         ln.act[b.name] = d;
+    }
+    {   // raw partial sums of a split-K Winograd launch (try_wino): launches under one workgroup per CU only, so the size does not grow with max_batch
+        float* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, WINO_PARTIAL_FLOATS * sizeof(float)));
+        ln.act["wp"] = d;
     }
     return P2P_OK;
 }
@@ -1047,11 +1053,12 @@ static int conv_layer(Ctx& X, const ConvLayer& L, const float* in, int N, int H,
 
 // The 5x5 stride-1 layers of split-f16 models in Winograd form (wino.hip: 2.5x fewer MFMA products).  Measured per generator pass
 // (profiles/r06_wino_small_batches.txt): faster than the direct kernels from 3 inputs up (703 vs 772 us; 8: 841 vs 971; 64: 2100 vs 2613;
-// 256: 5490 vs 7740), 5 % slower at ONE input (651 vs 622 us: three launches of 4-16 workgroups walking their whole K range) -- so "auto"
-// keeps the direct kernels for one-input passes only.  Unlike the other route pairs of this file the two forms do NOT compute the same
+// 256: 5490 vs 7740), 5 % slower at ONE input (651 vs 622 us: three launches of 4-16 workgroups walking their whole K range) -- until such
+// launches split K over ranges of channel slices (try_wino: one input 0.510 -> 0.462 ms against the direct kernels with THEIR split, two
+// inputs 0.607 -> 0.492, three 0.650 -> 0.539): "auto" now takes the Winograd form at every size.  Unlike the other route pairs of this file the two forms do NOT compute the same
 // bits: both sit within the generator's error bar of the oracle (tests/test_wino_gpu.py), 3e-5 apart -- so the choice is the caller's
 // (p2p_ctx_set_winograd: off / auto / always), not a development switch.
-constexpr int WINO_MIN_INPUTS = 2;
+constexpr int WINO_MIN_INPUTS = 1;
 
 static int timed_launch(Ctx& X, int slot, double flops, double bytes, const std::function<hipError_t()>& launch)
 {
@@ -1068,6 +1075,8 @@ static int timed_launch(Ctx& X, int slot, double flops, double bytes, const std:
     HIP_TRY(launch());
     return P2P_OK;
 }
+
+static bool wino_split_route() { static const bool on = dev_env("P2P_NO_WINO_SPLIT") == nullptr; return on; }     // development builds: A/B against the single chain
 
 // 0 = not for this route (the caller falls through to the direct kernels), 1 = done, < 0 = error
 static int try_wino(Ctx& X, const ConvLayer& L, const float* a, int Ca, const float* b, int Cb, int cb_stride, int cb_off, int N, int H, float* out)
@@ -1102,14 +1111,25 @@ static int try_wino(Ctx& X, const ConvLayer& L, const float* a, int Ca, const fl
         p.grp[ng] = {nullptr, nullptr, nullptr, G.start[ng], unit0};
         p.n_groups = ng;
     }
-    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < WINO_MIN_INPUTS) return 0;
+    static const int wino_min = dev_env("P2P_WINO_MIN") ? atoi(dev_env("P2P_WINO_MIN")) : WINO_MIN_INPUTS;
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < wino_min) return 0;
+    // Launches under half a workgroup per CU (a pass over a few inputs; deconv1 up to 64): under "auto" the channel slices are cut into ranges,
+    // one workgroup each, and the raw sums meet in splitk_reduce_kernel (the inverse transform is linear).  Like every choice "auto" makes
+    // the split depends on the pass size only; "always" keeps one chain (size-independent bits).
+    if (X.wino_mode == P2P_WINOGRAD_AUTO && p.n_groups <= 1 && wino_split_route()) {
+        const int tiles = wino_gemm_grid(p), S = p.Cin / 16;
+        for (int k : {6, 4, 3, 2})
+            if (tiles * k <= 256 && S % (2 * k) == 0 && (size_t)k * px * L.Cout <= WINO_PARTIAL_FLOATS) { p.ksplit = k; p.partial = X.cur->act["wp"]; break; }
+    }
     hipStream_t st = X.cur->stream;
     const double in_el = (double)px * p.Cin, out_el = (double)px * L.Cout;
     int rc = timed_launch(X, 11, 0.0, 4.0 * in_el + 8.0 * in_el, [&]() { return launch_wino_input(p, st); });
     if (rc) return rc;
     // algorithmic work of the LAYER (the direct form's MACs, like every other slot); compulsory bytes: V once, the panel once, the output
     rc = timed_launch(X, 10, 2.0 * out_el * 25.0 * p.Cin, 8.0 * in_el + (double)L.wino_bytes + 4.0 * out_el, [&]() { return launch_wino_gemm(p, st); });
-    return rc ? rc : 1;
+    if (rc) return rc;
+    if (p.ksplit > 1) HIP_TRY(launch_splitk_reduce(p.partial, p.ksplit, (int)px, L.Cout, L.wino_scale, L.shift, ACT_LEAKY, LEAKY, out, X.range_cur, st));
+    return 1;
 }
 
 // 5x5 stride-1 'SAME' conv over the concatenation [a (Ca ch) || b[..., :Cb] (pixel stride cb_stride)]

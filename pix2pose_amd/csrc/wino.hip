@@ -138,7 +138,9 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
     const int RB = DUAL ? 1 : p.H >> 5;
     const int NT = p.Cout >> 6;
     const int units = DUAL ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) >> 1) : p.N;
-    const int ntiles = units * PC * RB * NT;
+    const int KS = p.ksplit > 1 ? p.ksplit : 1;       // split K: tile = (unit, patch, channel tile, range of S / KS channel slices)
+    const int Sl = S / KS;                            // (even: launch_wino_gemm)
+    const int ntiles = units * PC * RB * NT * KS;
     const unsigned slice_bytes = 32u * (unsigned)p.H * 64u;
     const size_t unit_block = (size_t)S * slice_bytes;           // bytes of one (sample, patch column)
 
@@ -155,8 +157,10 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
     float amax = 0.f;
 
     for (int tl = tl0; tl < ntiles; tl += gridDim.x) {
-    const int ntile = tl % NT;
-    int rest = tl / NT;
+    const int ks = tl % KS;
+    const int s_begin = ks * Sl;
+    const int ntile = (tl / KS) % NT;
+    int rest = tl / (KS * NT);
     const int rb = rest % RB; rest /= RB;
     const int pc = rest % PC;
     const int unit = rest / PC;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
 #ifdef P2P_ABL_WV
         on = false;
 #endif
-        unsigned so = (unsigned)slice * slice_bytes + (unsigned)(j * 4) * plane_bytes;
+        unsigned so = (unsigned)(s_begin + slice) * slice_bytes + (unsigned)(j * 4) * plane_bytes;
         unsigned vo;
         if (DUAL) {
             if (q >= 8) return;
@@ -234,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
 
     // ---- U: this wave's stream (channel tile, position j): K-step kb = 4 fragments of 1 KB, contiguous.  The panel carries one K-step
     //      of padding behind its last stream, so the load one K-step ahead needs no condition.
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(gu) + ((size_t)(ntile * 8 + j) * S * 5) * 4096), 0,
-                                                                          (unsigned)((S * 5 + 1) * 4096), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(gu) + ((size_t)(ntile * 8 + j) * S * 5 + (size_t)s_begin * 5) * 4096), 0,
+                                                                          (unsigned)((Sl * 5 + 1) * 4096), 0x00020000);
     const unsigned uoff = (unsigned)lane * 16u;
     f16x8 u[2][4];                                   // (tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo) of the even / odd K-steps
     auto uload = [&](int set, int kb) {
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
 
     // Two slices (10 K-steps) per iteration: buffer, weight register set and staging register set of every K-step are compile-time.
     // K-step (s, ky): write group ky of slice s + 1 (loaded two K-steps ago), issue the load of the group two K-steps ahead.
-    for (int s2 = 0; s2 < S; s2 += 2) {
+    for (int s2 = 0; s2 < Sl; s2 += 2) {
 #pragma unroll
         for (int kk = 0; kk < 10; ++kk) {
             const int half = kk / 5, ky = kk % 5;
@@ -302,8 +306,8 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
             if (s2 == 0) uload((kk + 1) & 1, s * 5 + ky + 1);
 #endif
             vstore(kk & 1, half ^ 1, ky);                        // (a slice past the last one: zeros nobody reads)
-            if (ky < 3) vload(kk & 1, s + 1, ky + 2, half == 0 || s + 1 < S);
-            else vload(kk & 1, s + 2, ky - 3, s + 2 < S);
+            if (ky < 3) vload(kk & 1, s + 1, ky + 2, half == 0 || s + 1 < Sl);
+            else vload(kk & 1, s + 2, ky - 3, s + 2 < Sl);
             __builtin_amdgcn_sched_barrier(0);                   // the loads above stay AHEAD of this K-step's matrix work (the scheduler would sink them to their uses)
             const char* img = img0 + half * BUF;
             f16x8 vh[4], vl[4];
@@ -379,6 +383,12 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoParams p)
                 yv[2][e] = __builtin_fmaf(0.25f, s56, __builtin_fmaf(4.f, s34, s12));
                 yv[3][e] = __builtin_fmaf(0.125f, d56, __builtin_fmaf(8.f, d34, d12)) + m[7][e];
             }
+            if (KS > 1) {           // raw sums of this K range; scale / shift / activation belong to the reduction
+                float* po = p.partial + ((size_t)ks * p.N * p.H * p.W + pix) * p.Cout + col;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(po + (size_t)k * p.Cout) = yv[k];
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f32x4 v = yv[k];
@@ -418,7 +428,7 @@ int wino_gemm_grid(const WinoParams& p)
 {
     const bool dual = p.H == 16;
     const int units = dual ? (p.n_groups > 1 ? p.grp[p.n_groups].unit0 : (p.N + 1) / 2) : p.N * (p.H / 32);
-    return units * (p.W / 16) * (p.Cout / 64);
+    return units * (p.W / 16) * (p.Cout / 64) * (p.ksplit > 1 ? p.ksplit : 1);
 }
 
 hipError_t launch_wino_input(const WinoParams& p, hipStream_t s)
@@ -438,6 +448,7 @@ hipError_t launch_wino_gemm(const WinoParams& p, hipStream_t s)
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if (p.ksplit > 1 && ((p.Cin >> 4) % (2 * p.ksplit) || !p.partial || p.n_groups > 1)) return hipErrorInvalidValue;      // even slice ranges; one object
     const int tiles = wino_gemm_grid(p);
     const int grid = tiles < n_cu ? tiles : n_cu;
     if (p.H == 16) hipLaunchKernelGGL((wino_gemm_kernel<true>), dim3(grid), dim3(512), 0, s, p);

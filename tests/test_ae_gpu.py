@@ -37,7 +37,7 @@ def test_predict_matches_oracle(backbone, precision):
 @pytest.mark.parametrize("winograd", ["off", "always"])
 def test_predict_batch_invariance_and_chunking(winograd):
     """The same crop gives bit-identical output alone, inside a batch, and across workspace chunks -- with the form of the 5x5 decoder layers
-    pinned (the default "auto" runs a ONE-input pass on the direct kernels and every larger one in Winograd form: p2p_ctx_set_winograd)."""
+    pinned (the default "auto" picks form and K split by the pass size: p2p_ctx_set_winograd)."""
     from pix2pose_amd.runtime import Context, Generator
     w = W.synthetic_weights("resnet50", 2)
     ctx = Context(0, max_batch=4, winograd=winograd)
