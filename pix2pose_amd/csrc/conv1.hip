@@ -271,10 +271,14 @@ hipError_t launch_conv1_f16x3(const float* x, int N, int KH, int Cout, const Con
     if ((size_t)N * C1_HIN * C1_HIN * 12 >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     // a handful of images (one detection at a time): one 2-row tile per workgroup so that the layer covers the chip
     // (an output pixel is computed the same way whichever workgroup owns its row)
-    const int tpw = N * (C1_HOUT / (C1_ROWS_OUT * C1_TILES_PER_WG)) >= 64 ? C1_TILES_PER_WG : (N >= 4 ? 2 : 1);
+    // 16 .. 127 images: 16 rows per workgroup would leave the layer on 64 .. 508 workgroups of four waves (a quarter to a whole wave of
+    // one workgroup per CU): 4- and 8-row workgroups instead (the pooled form computes one tile more than it stores: 3/2 and 5/4 of the
+    // products, on a layer bound by its stores)
+    static const int tpw_mid = dev_env("P2P_CONV1_TPW") ? atoi(dev_env("P2P_CONV1_TPW")) : 0;      // development builds: tiles per workgroup for 16 .. 127 images
+    const int tpw = N >= 128 ? C1_TILES_PER_WG : N >= 16 ? (tpw_mid ? tpw_mid : N >= 64 ? 4 : 2) : (N >= 4 ? 2 : 1);
     const int wgs = N * (C1_HOUT / (C1_ROWS_OUT * tpw));
     static const bool no_fuse = dev_env("P2P_NO_POOL_FUSE") != nullptr;      // development switch (A/B)
-    if (KH == 7 && pool_out && tpw == C1_TILES_PER_WG && !no_fuse) {
+    if (KH == 7 && pool_out && N >= 16 && !no_fuse) {
         hipLaunchKernelGGL((conv1_f16x3_kernel<7, 3, 64, true>), dim3(wgs), dim3(256), 0, s, x, N, G, act, alpha, out, tpw, pool_out, range_acc);
         return hipGetLastError();
     }
