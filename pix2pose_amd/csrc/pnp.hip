@@ -26,6 +26,9 @@
 #ifndef P2P_PNP_HYP_WAVES
 #define P2P_PNP_HYP_WAVES 1
 #endif
+#ifndef P2P_PNP_SOLVE_WAVES
+#define P2P_PNP_SOLVE_WAVES 1
+#endif
 #ifndef P2P_PNP_FIT_WAVES
 #define P2P_PNP_FIT_WAVES 2
 #endif
@@ -253,6 +256,104 @@ __device__ __forceinline__ void jacobi_svd_t(double (&At)[N * M], double (&W)[N]
         }
         const double s = sd > kDblMin ? 1 / sd : 0.;
 #pragma unroll
+        for (int k = 0; k < M; k++) At[i * M + k] *= s;
+    }
+}
+
+// The same routine for M = N = 12 without V, ROLLED: run-time indices, the matrix in the lane's scratch memory.  Only the fall-back of the
+// quad / team forms runs it (a numerically zero singular value: OpenCV's random fill-in), i.e. practically never -- but unrolled in place its
+// 288 matrix registers were what sized the register file of the kernels that contain it.  Same operations in the same order: same bits.
+__device__ __noinline__ void jacobi_svd12_rolled(double* __restrict__ At, double* __restrict__ W)
+{
+    constexpr int M = 12, N = 12;
+    const double eps = kDblEps * 10;
+    constexpr int max_iter = 30;
+#pragma unroll 1
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll 1
+        for (int k = 0; k < M; k++) { const double t = At[i * M + k]; sd += t * t; }
+        W[i] = sd;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+#pragma unroll 1
+        for (int i = 0; i < N - 1; i++)
+#pragma unroll 1
+            for (int j = i + 1; j < N; j++) {
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll 1
+                for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
+                if (jacobi_skip(p, a, b, eps)) continue;
+                double c, s;
+                jacobi_cs(p, a, b, c, s);
+                a = b = 0;
+#pragma unroll 1
+                for (int k = 0; k < M; k++) {
+                    const double t0 = c * At[i * M + k] + s * At[j * M + k];
+                    const double t1 = -s * At[i * M + k] + c * At[j * M + k];
+                    At[i * M + k] = t0; At[j * M + k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+            }
+        if (!changed) break;
+    }
+#pragma unroll 1
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll 1
+        for (int k = 0; k < M; k++) { const double t = At[i * M + k]; sd += t * t; }
+        W[i] = sqrt_cr(sd);
+    }
+#pragma unroll 1
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+#pragma unroll 1
+        for (int k = i + 1; k < N; k++)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+#pragma unroll 1
+            for (int e = 0; e < M; e++) { t = At[i * M + e]; At[i * M + e] = At[j * M + e]; At[j * M + e] = t; }
+        }
+    }
+    Rng rng(0x12345678ULL);
+#pragma unroll 1
+    for (int i = 0; i < N; i++) {
+        double sd = W[i];
+#pragma unroll 1
+        for (int ii = 0; ii < 100 && sd <= kDblMin; ii++) {
+            const double val0 = 1. / M;
+#pragma unroll 1
+            for (int k = 0; k < M; k++) At[i * M + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+#pragma unroll 1
+            for (int it = 0; it < 2; it++)
+#pragma unroll 1
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+#pragma unroll 1
+                    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[j * M + k];
+                    double asum = 0;
+#pragma unroll 1
+                    for (int k = 0; k < M; k++) {
+                        const double t = At[i * M + k] - sd * At[j * M + k];
+                        At[i * M + k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll 1
+                    for (int k = 0; k < M; k++) At[i * M + k] *= asum;
+                }
+            sd = 0;
+#pragma unroll 1
+            for (int k = 0; k < M; k++) { const double t = At[i * M + k]; sd += t * t; }
+            sd = sqrt_cr(sd);
+        }
+        const double s = sd > kDblMin ? 1 / sd : 0.;
+#pragma unroll 1
         for (int k = 0; k < M; k++) At[i * M + k] *= s;
     }
 }
@@ -1032,7 +1133,8 @@ __device__ void epnp5(const Cam& cam, const double* pws, const double* us, doubl
                 for (int q = 0; q < 12; q++) mtm[p * 12 + q] += m2[p] * m2[q];
         }
         double w12[12];
-        jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
+        if (QUAD) jacobi_svd12_rolled(mtm, w12);
+        else jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
         #pragma unroll
         for (int k = 0; k < 48; k++) u8[k] = mtm[96 + k];
     }
@@ -1684,7 +1786,7 @@ __device__ __forceinline__ double mtm_entry(const double (&g)[56], const Cam& ca
 // TEAM (launches of a handful of problems): a team of 32 lanes per problem -- the SVD on six of its quads (jacobi12_team), the beta
 // cases on quads 0..2 -- in workgroups of one wave.
 template <bool TEAM>
-__global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
+__global__ __launch_bounds__(256, P2P_PNP_SOLVE_WAVES) void pnp_fit_solve_kernel(const PnpProblem* __restrict__ probs, PnpFit* __restrict__ fits, int n_problems)
 {
     __shared__ double s_team[TEAM ? 4 * (64 / TEAM_LANES) * TEAM_DOUBLES : 1];
     const int li = blockIdx.x * blockDim.x + threadIdx.x;      // four waves per workgroup = one CU, see pnp_hypotheses_kernel
@@ -1736,7 +1838,7 @@ __global__ __launch_bounds__(256, 1) void pnp_fit_solve_kernel(const PnpProblem*
         for (int p = 0; p < 12; p++)
 #pragma unroll
             for (int k = 0; k < 12; k++) mtm[p * 12 + k] = mtm_entry(g, cam, p, k);
-        jacobi_svd_t<12, 12, false>(mtm, w12, nullptr);
+        jacobi_svd12_rolled(mtm, w12);
 #pragma unroll
         for (int k = 0; k < 48; k++) u8[k] = mtm[96 + k];
     }
