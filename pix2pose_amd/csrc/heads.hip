@@ -287,8 +287,9 @@ bool heads_halo_supported(const IgemmParams& p)
 hipError_t launch_heads_halo(const IgemmParams& p, hipStream_t s)
 {
     // few samples: one 4-row step per workgroup (16 workgroups per sample instead of 4); an output pixel's chain of MFMAs over
-    // (slice, tap) is the same either way
-    const bool small = p.N * (p.Hg / (HEADS_TH * HEADS_TILES_BIG)) < 64;
+    // (slice, tap) is the same either way.  Measured per pass (tools/time_small.py): 16 inputs -20 us, 32 inputs -18 us, 64 inputs +-0 or worse
+    static const int small_below = dev_env("P2P_HEADS_SMALL_BELOW") ? atoi(dev_env("P2P_HEADS_SMALL_BELOW")) : 130;      // development builds: workgroups of the 16-row form below which the 4-row form runs
+    const bool small = p.N * (p.Hg / (HEADS_TH * HEADS_TILES_BIG)) < small_below;
     const int n_wgs = p.N * (p.Hg / (HEADS_TH * (small ? 1 : HEADS_TILES_BIG)));
     const int per_xcd = (n_wgs + 7) / 8;
     static const bool two_ahead = dev_env("P2P_HEADS_TWO_AHEAD") != nullptr && atoi(dev_env("P2P_HEADS_TWO_AHEAD")) != 0;      // development switch (A/B; same bits)

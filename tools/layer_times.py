@@ -97,6 +97,16 @@ def main(path, batch=256):
             out.append((nm + " gemm", mmac))
             KF[nm + " gemm"] = KF.get(nm, 0)
             i += 2
+            if i < len(ks) and "splitk_reduce" in ks[i][0]:                                          # launches under half a workgroup per CU: K split over ranges of channel slices
+                out.append((nm + " reduce", 0))
+                KF[nm + " reduce"] = {"deconv1": 3 * 66, "deconv2": 3 * 262, "deconv3": 3 * 524}.get(nm, 0)      # (two or more) partial tensors read, the output written
+                i += 1
+            continue
+        if nm == "conv4" and i + 1 < len(ks) and "igemm_stream" in ks[i][0] and "splitk_reduce" in ks[i + 1][0]:      # a few inputs: conv4 on the streaming kernel, K split
+            out.append((nm, mmac))
+            out.append(("conv4 reduce", 0))
+            KF["conv4 reduce"] = 5 * 33
+            i += 2
             continue
         out.append((nm, mmac))
         i += 1
