@@ -133,8 +133,8 @@ P2P_API int p2p_ctx_range_event(p2p_ctx* ctx, float* max_abs);
  * layers (1.67x fewer) -- form different products than the direct convolutions, so the forms do not give the same bits: all are held to the
  * same bar against the oracle (network output within 1e-4; measured 4e-5 with every layer in Winograd form, 2.6e-5 direct;
  * tests/test_wino_gpu.py), 6e-5 apart at most.
- *   P2P_WINOGRAD_AUTO (default)  the fastest form at every pass size: F(4,5) for the stride-1 layers at every size, F(4,3) for up2 / up3 from 8
- *                                and for conv4 / up1 from 16 inputs; launches that would occupy a fraction of the chip split K over more
+ *   P2P_WINOGRAD_AUTO (default)  the fastest form at every pass size: F(4,5) for the stride-1 layers at every size, F(4,3) for up2 / up3 from 5
+ *                                and for conv4 / up1 from 9 inputs; launches that would occupy a fraction of the chip split K over more
  *                                workgroups and add the partial sums in a separate step, in a fixed order (a pass over a few inputs: conv4
  *                                on the direct kernel, the stride-1 layers over ranges of channel slices, deconv1 up to 64 inputs; conv4 in
  *                                F(4,3) form over its four parity planes while under one workgroup per CU).  A sample's bits then depend on

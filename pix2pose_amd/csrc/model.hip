@@ -1153,15 +1153,19 @@ static int concat_conv(Ctx& X, const ConvLayer& L, const float* a, int Ca, const
 // Conv2DTranspose 5x5/2 + BN + LeakyReLU as four phase convolutions
 // The transposed convolutions of split-f16 models on 16x16 / 32x32 input grids in Winograd F(4,3) form (wino3.hip), same switch as the
 // stride-1 layers (p2p_ctx_set_winograd).  0 = not for this route, 1 = done, < 0 = error.
-constexpr int WINO3_MIN_INPUTS = 8;       // up2 / up3 (measured: 8 inputs 806 vs 834 us per pass, 4 inputs 737 vs 731)
-constexpr int WINO3O_MIN_INPUTS = 16;     // up1 / conv4, eight samples per workgroup (measured with all four layers: 16 inputs 972 vs 1194 us, 8 inputs 840 vs 834)
+// (thresholds re-measured after the K splits of the small launches, tools/time_small.py with P2P_WINO3_MIN / P2P_WINO3O_MIN: per pass at
+// 5 / 6 inputs 660 / 669 us against 678 / 685 with up2 / up3 direct; at 9 / 12 / 15 inputs 764 / 802 / 856 us against 833 / 875 / 939 with
+// conv4 / up1 direct, at 8 inputs 782 against 760)
+constexpr int WINO3_MIN_INPUTS = 5;       // up2 / up3
+constexpr int WINO3O_MIN_INPUTS = 9;      // up1 / conv4, eight samples per workgroup
 static bool wino3_route() { static const bool on = dev_env("P2P_NO_WINO3") == nullptr; return on; }     // development builds: A/B against the direct phases
 
 // The 8x8-grid layers (wino3o.hip): mode 0 = the transposed convolution up1, mode 1 = the stride-2 convolution conv4.
 static int try_wino3o(Ctx& X, const ConvLayer& L, int mode, const float* in, int N, int C, float* out)
 {
     if (!L.wino_u || L.prec != PREC_F16X3 || X.wino_mode == P2P_WINOGRAD_OFF || !specialised_kernels() || !wino3_route() || !wino3o_supported(mode, C, L.Cout)) return 0;
-    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < WINO3O_MIN_INPUTS) return 0;
+    static const int wino3o_min = dev_env("P2P_WINO3O_MIN") ? atoi(dev_env("P2P_WINO3O_MIN")) : WINO3O_MIN_INPUTS;
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < wino3o_min) return 0;
     const size_t b0 = (size_t)N * (mode ? 256 : 64) * C * sizeof(float);
     if (b0 >= 0xFFFFFFF0ull || L.wino_bytes >= 0xFFFFFFF0ull) return 0;
     Wino3oParams p;
@@ -1215,7 +1219,8 @@ static int try_wino3(Ctx& X, const ConvLayer& L, const float* in, int N, int H, 
 {
     if (H == 8) return try_wino3o(X, L, 0, in, N, C, out);
     if (!L.wino_u || L.prec != PREC_F16X3 || X.wino_mode == P2P_WINOGRAD_OFF || !specialised_kernels() || !wino3_route() || !wino3_supported(H, H, C, L.Cout)) return 0;
-    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < WINO3_MIN_INPUTS) return 0;
+    static const int wino3_min = dev_env("P2P_WINO3_MIN") ? atoi(dev_env("P2P_WINO3_MIN")) : WINO3_MIN_INPUTS;
+    if (X.wino_mode != P2P_WINOGRAD_ALWAYS && N < wino3_min) return 0;
     const size_t px = (size_t)N * H * H;
     const size_t b0 = px * C * sizeof(float);
     if (b0 >= 0xFFFFFFF0ull || L.wino_bytes >= 0xFFFFFFF0ull) return 0;
