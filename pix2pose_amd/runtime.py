@@ -24,7 +24,7 @@ class Context:
 
     def set_winograd(self, mode: str):
         """Form of the 5x5 layers (deconv1-3, up1-3, conv4) in split-f16 passes (p2p_ctx_set_winograd): "auto" (default) = the fastest form at
-        every pass size (Winograd F(4,5) / F(4,3) from 2 / 8 / 16 inputs up, direct below) -- a sample's bits depend on the pass SIZE;
+        every pass size (Winograd F(4,5) at every size, F(4,3) from 5 / 9 inputs up, K splits for launches that would fill a fraction of the chip) -- a sample's bits depend on the pass SIZE;
         "off" / "always" = one form at every size."""
         _lib.check(_lib.lib().p2p_ctx_set_winograd(self._h, self.WINOGRAD[mode]), "p2p_ctx_set_winograd")
 
