@@ -42,7 +42,7 @@ timeout 300 tools/probe_kernel.sh resblock 256 > /dev/null 2>&1
 [ -d tools/ab/prev ] && timeout 600 tools/ab_round.sh run 3 > gpurun_out/ab_round.log 2>&1      # the A/B worktree travels only when .gpurunignore lets it
 [ -d tools/ab/prev ] && timeout 300 tools/general_ab.sh > /dev/null 2>&1
 timeout 200 tools/batch_layers.sh 64 > /dev/null 2>&1
-(python tools/soak_est_pose.py 60 2 7000; python tools/soak_est_pose.py 40 1 7100; python tools/soak_est_pose.py 25 0 7200) 2>/dev/null | grep -E "^soak|MISMATCH" > gpurun_out/soak.txt
+(python tools/soak_est_pose.py 60 2 7000; python tools/soak_est_pose.py 40 1 7100; python tools/soak_est_pose.py 25 0 7200; python tools/soak_est_pose.py 8 0 7300 40; python tools/soak_est_pose.py 60 0 7400 1) 2>/dev/null | grep -E "^soak|MISMATCH" > gpurun_out/soak.txt
 cat gpurun_out/gpu_tests.log; tail -c 300 gpurun_out/bench_final.json
 ' 2>&1 | tail -8
 python tools/rocprof_summary.py gpurun_out/prof_final/bench_results.db > profiles/${R}_bench_kernel_stats.txt

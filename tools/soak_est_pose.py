@@ -1,5 +1,6 @@
 """Soak: the HIP est_pose pipeline against the oracle on many random detections (development aid; the committed tests hold fixed scenes).
-    python tools/soak_est_pose.py [n_scenes] [resize generation 0|1|2] [seed0]
+    python tools/soak_est_pose.py [n_scenes] [resize generation 0|1|2] [seed0] [detections per scene: 8 = 24 PnP problems per call (the team form of the
+    EPnP solvers, K splits of the small generator launches); 40 = 120 problems (the quad form, batched kernels)]
 Every detection: status, returned box, valid mask, uint8 image identical; pose within 1e-6 mm / 1e-4 deg.
 Generation 2 (scikit-image 0.15 / 0.16) filters the BOOL keep mask: a detection whose filters use a crop side where libm's exp (the library,
 numpy <= 1.18) and this interpreter's numpy exp build different Gaussian weights may legitimately differ -- counted apart."""
@@ -19,8 +20,9 @@ from pix2pose_amd.runtime import Context, Generator, ObjectSpec, est_pose_batch
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 aa = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 9000
+n_per = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 TH_O, TH_I = [0.2, 0.3, 0.35], 0.2
-ctx = Context(0, max_batch=64)
+ctx = Context(0, max_batch=max(64, 3 * n_per))
 spec = ObjectSpec(Generator(W.synthetic_weights("paper", 1), "paper", ctx), S.OBJ_PARAM, TH_O, TH_I)
 n_det = n_bad = n_ok = n_sens = n_sens_bad = 0
 t0 = time.time()
@@ -49,7 +51,7 @@ BAD = exp_sensitive_sides() if aa == 2 else set()
 for k in range(n_scenes):
     rs = np.random.RandomState(seed0 + k)
     lo = int(rs.randint(24, 200))
-    sc = S.make_scene(8, seed=seed0 + k, bbox_side=(lo, lo + int(rs.randint(1, 200))), outlier_frac=float(rs.uniform(0.1, 0.5)))
+    sc = S.make_scene(n_per, seed=seed0 + k, bbox_side=(lo, lo + int(rs.randint(1, 200))), outlier_frac=float(rs.uniform(0.1, 0.5)))
     j1, j2 = torch.from_numpy(sc["inject1"]).cuda(), torch.from_numpy(sc["inject2"]).cuda()
     torch.cuda.synchronize()
     poses, ex = est_pose_batch(ctx, [spec], list(sc["images"]), sc["dets"], inject1=j1.data_ptr(), inject2=j2.data_ptr(), inject_slots=3,
@@ -87,6 +89,6 @@ for k in range(n_scenes):
         elif why:
             n_bad += 1
             print("MISMATCH scene seed %d det %d bbox %s: %s" % (seed0 + k, i, list(bbox), why))
-print("soak: %d detections (%d with a pose), resize generation %d, %d mismatches; %d detections on exp-sensitive crop sides, %d of them differ; %.0f s"
-      % (n_det, n_ok, aa, n_bad, n_sens, n_sens_bad, time.time() - t0))
+print("soak: %d detections (%d with a pose, %d per call), resize generation %d, %d mismatches; %d detections on exp-sensitive crop sides, %d of them differ; %.0f s"
+      % (n_det, n_ok, n_per, aa, n_bad, n_sens, n_sens_bad, time.time() - t0))
 sys.exit(1 if n_bad else 0)
