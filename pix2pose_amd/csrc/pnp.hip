@@ -9,13 +9,14 @@
 // (uint64)-1 on every call and each iteration draws five distinct indices, so all minimal sets are
 // known up front.  The work is five kernels (launch_pnp_ransac):
 //   1. pnp_hypotheses_kernel: a lane replays the multiply-with-carry generator, lane quads solve the 5-point EPnP
-//      hypotheses in fp64 -- lazily, in rounds [0, 16), [16, 64), [64, 100): RANSAC's adaptive bound rarely asks for more,
+//      hypotheses in fp64 -- lazily, in rounds [0, 16), [16, 64), [64, 100): RANSAC's adaptive bound rarely asks for more
+//      (launches of a handful of problems: teams of 32 lanes per hypothesis, rounds [0, 48), [48, 100) -- jacobi12_team),
 //   2. pnp_count_kernel: inlier counts of the round's hypotheses (integers: independent workgroups over slices of the points),
 //   3. pnp_score_kernel: OpenCV's "best so far" rule and adaptive iteration bound replayed over the counts in OpenCV's order
 //      (it stops where OpenCV stops and picks the hypothesis OpenCV picks; a problem that needs the next round parks its
 //      state), then the refit's reductions over the inlier set (the 2n x 12 system is never formed: M^T M has only four
 //      distinct weighted Gram sums of the barycentric coordinates),
-//   4. pnp_fit_solve_kernel: the 12x12 SVD and the same beta / Gauss-Newton / absolute-orientation steps,
+//   4. pnp_fit_solve_kernel: the 12x12 SVD and the same beta / Gauss-Newton / absolute-orientation steps (quad / team forms likewise),
 //   5. pnp_fit_select_kernel: the candidate with the smallest mean reprojection error, Rodrigues round trip.
 // All arithmetic that decides an inlier uses OpenCV's types (float32 point storage, float32
 // projected points and squared distance) with FMA contraction disabled.
