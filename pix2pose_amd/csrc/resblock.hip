@@ -67,7 +67,25 @@ constexpr bool RB_WDIR = false;
 #else
 constexpr bool RB_WDIR = true;
 #endif
-template <int F1, int PY, int HPX, int DA, int DB, int KA, bool PRIV, int ABL = 0, int CIN = 4 * F1, int STRIDE = 1, bool PROJ = false, bool WDIR = RB_WDIR>
+// DBUF: phase A stages K-step s + 1 into the OTHER of two staging buffers before the MFMAs of K-step s: the split + LDS stores of the loader run
+// under the matrix pipe and a K-step ends in ONE barrier (single-buffered: MFMAs | barrier | stores | barrier).  Same K order: same bits.
+#ifndef P2P_RB_DA64
+#define P2P_RB_DA64 2         // stages of global loads in flight in phase A of the F1 = 64 identity blocks (4 with the explicit schedule: 112 bytes of scratch per lane)
+#endif
+#ifndef P2P_RB_DA3A
+#define P2P_RB_DA3A 2         // the same for the projection block res3a (4: 40 bytes of scratch per lane)
+#endif
+#ifdef P2P_RB_NO_PIPE
+constexpr bool RB_PIPE = false;
+#else
+constexpr bool RB_PIPE = true;                  // phases B / C: the next K-step's fragment reads in front of this K-step's MFMAs (explicit schedule)
+#endif
+#ifdef P2P_RB_NO_DBUF
+constexpr bool RB_DBUF = false;
+#else
+constexpr bool RB_DBUF = true;
+#endif
+template <int F1, int PY, int HPX, int DA, int DB, int KA, bool PRIV, int ABL = 0, int CIN = 4 * F1, int STRIDE = 1, bool PROJ = false, bool WDIR = RB_WDIR, bool DBUF = RB_DBUF, bool PIPE = RB_PIPE>
 __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p)
 {
     constexpr int C = 4 * F1;                     // output channels
@@ -93,7 +111,9 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     constexpr int CLD = 128 + 4;
     constexpr int CS_BYTES = TMC * 32 * CLD * 4;
     constexpr int XC_BYTES = NPIX * REC;          // PROJ: a 32-channel slice of the block input at the patch's own pixels, staged per K-step
-    constexpr int ZERO_OFF = cmax(cmax(KA * (XS_BYTES + WA_BYTES), T_BYTES + WB_BYTES),
+    constexpr int NBUF = DBUF ? 2 : KA;            // staging buffers of phase A
+    static_assert(!DBUF || (KA == 1 && DA % 2 == 0), "double buffering: one K-step per stage, buffer parity = ring slot parity");
+    constexpr int ZERO_OFF = cmax(cmax(NBUF * (XS_BYTES + WA_BYTES), T_BYTES + WB_BYTES),
                                   T2_BYTES + cmax(PROJ ? 128 * WREC + XC_BYTES : WC_BYTES, CS_BYTES));
     constexpr int SS_OFF = ZERO_OFF + 128, SS_FLOATS = 4 * F1 + 2 * C;      // the folded BatchNorm vectors: read by every epilogue, kept in LDS
     constexpr int SMEM = SS_OFF + SS_FLOATS * 4;
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     static_assert(SS_FLOATS % 4 == 0, "float4 copies");
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (kept in an SGPR: it selects tiles and the fragment stream's offset -- as a vector value every load of phase B became a waterfall loop)
     const int li = lane & 31, lk = lane >> 5;
 
     // XCD-aware tile order (block b runs on XCD b % 8): contiguous runs of patches per XCD
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
     const int ntA = wave % WNA, mt0A = (wave / WNA) * 3;
     {
         char* Xs = smem;                           // [KA][MA * 32 records]
-        char* Was = smem + KA * XS_BYTES;          // [KA][F1 rows]
+        char* Was = smem + NBUF * XS_BYTES;        // [KA | 2][F1 rows]
         unsigned x_off[MA];
         int x_dst[MA];
 #pragma unroll
@@ -183,18 +203,19 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
                 for (int j = 0; j < F1 / 32; ++j) qw[k2][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wa, wa_off[j], s * 128, 0));
             }
         };
-        auto lstore = [&](const auto& qx, const auto& qw) {
+        auto lstore = [&](const auto& qx, const auto& qw, int buf = 0) {
 #pragma unroll
             for (int k2 = 0; k2 < KA; ++k2) {
+                const int b = DBUF ? buf : k2;
 #pragma unroll
                 for (int j = 0; j < MA; ++j) {
                     uint2 hi, lo;
                     split4(qx[k2][j], hi, lo);
-                    *reinterpret_cast<uint2*>(Xs + k2 * XS_BYTES + x_dst[j]) = hi;
-                    *reinterpret_cast<uint2*>(Xs + k2 * XS_BYTES + x_dst[j] + 64) = lo;
+                    *reinterpret_cast<uint2*>(Xs + b * XS_BYTES + x_dst[j]) = hi;
+                    *reinterpret_cast<uint2*>(Xs + b * XS_BYTES + x_dst[j] + 64) = lo;
                 }
 #pragma unroll
-                for (int j = 0; j < F1 / 32; ++j) *reinterpret_cast<f32x4*>(Was + k2 * WA_BYTES + w_dst + 32 * j * WREC) = qw[k2][j];
+                for (int j = 0; j < F1 / 32; ++j) *reinterpret_cast<f32x4*>(Was + b * WA_BYTES + w_dst + 32 * j * WREC) = qw[k2][j];
             }
         };
 #pragma unroll
@@ -213,24 +234,53 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             for (int d = 0; d < DA; ++d) {
                 const int stg = g0 + d;                                       // the staged stage; its ring slot d is free again
                 if (stg + DA < NSTG) gload(stg + DA, rx[d], rw[d]);
+                if constexpr (PIPE && KA == 1 && ABL == 0) {
+                    // explicit schedule: all sixteen fragment reads of the K-step in front of its eighteen MFMAs (the scheduler sinks each read to its
+                    // first use: read, wait, MFMA ...); the loader's split + stores of the next stage are left to interleave with the MFMAs
+                    const int b = DBUF ? (d & 1) : 0;
+                    f16x8 wf[2][2], xf[2][3][2];
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        wf[kb][0] = *reinterpret_cast<const f16x8*>(Wf + b * WA_BYTES + w_sw[kb][0]);
+                        wf[kb][1] = *reinterpret_cast<const f16x8*>(Wf + b * WA_BYTES + w_sw[kb][1]);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            xf[kb][i][0] = *reinterpret_cast<const f16x8*>(Xf + b * XS_BYTES + i * 32 * REC + kb * 32);
+                            xf[kb][i][1] = *reinterpret_cast<const f16x8*>(Xf + b * XS_BYTES + i * 32 * REC + kb * 32 + 64);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (DBUF && stg + 1 < NSTG) lstore(rx[(d + 1) % DA], rw[(d + 1) % DA], (d + 1) & 1);      // (its buffer was last read before the previous barrier)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kb][0], xf[kb][i][1], accA[i], 0, 0, 0);
+                            accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kb][1], xf[kb][i][0], accA[i], 0, 0, 0);
+                            accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kb][0], xf[kb][i][0], accA[i], 0, 0, 0);
+                        }
+                } else {
+                if (DBUF && stg + 1 < NSTG) lstore(rx[(d + 1) % DA], rw[(d + 1) % DA], (d + 1) & 1);
 #pragma unroll
                 for (int k2 = 0; k2 < KA; ++k2)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
-                        const f16x8 wh = *reinterpret_cast<const f16x8*>(Wf + k2 * WA_BYTES + w_sw[kb][0]);
-                        const f16x8 wl = *reinterpret_cast<const f16x8*>(Wf + k2 * WA_BYTES + w_sw[kb][1]);
+                        const int b = DBUF ? (d & 1) : k2;
+                        const f16x8 wh = *reinterpret_cast<const f16x8*>(Wf + b * WA_BYTES + w_sw[kb][0]);
+                        const f16x8 wl = *reinterpret_cast<const f16x8*>(Wf + b * WA_BYTES + w_sw[kb][1]);
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
-                            const f16x8 xh = *reinterpret_cast<const f16x8*>(Xf + k2 * XS_BYTES + i * 32 * REC + kb * 32);
-                            const f16x8 xl = *reinterpret_cast<const f16x8*>(Xf + k2 * XS_BYTES + i * 32 * REC + kb * 32 + 64);
+                            const f16x8 xh = *reinterpret_cast<const f16x8*>(Xf + b * XS_BYTES + i * 32 * REC + kb * 32);
+                            const f16x8 xl = *reinterpret_cast<const f16x8*>(Xf + b * XS_BYTES + i * 32 * REC + kb * 32 + 64);
                             if (ABL & 32) { accA[i][0] += (float)wh[0] + (float)wl[0] + (float)xh[0] + (float)xl[0]; continue; }
                             accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accA[i], 0, 0, 0);      // (al bh, ah bl, ah bh) with a = activation, b = weight,
                             accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accA[i], 0, 0, 0);      // operand roles swapped: D[channel][pixel]
                             accA[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accA[i], 0, 0, 0);
                         }
                     }
+                }
                 __syncthreads();
-                if (stg + 1 < NSTG) {
+                if (!DBUF && stg + 1 < NSTG) {
                     lstore(rx[(d + 1) % DA], rw[(d + 1) % DA]);
                     __syncthreads();
                 }
@@ -335,6 +385,64 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) w_sw[kb][hf] = ((kb * 2 + lk + 4 * hf) ^ ((li >> 1) & 7)) << 4;
+        // X fragment offsets of K-step ks (both m-tiles)
+        auto xoff = [&](int ks, int (&xo)[2]) {
+            const int chunk = ks / 9, tap = ks - chunk * 9;
+            const int ky = tap / 3, kx = tap - ky * 3;                        // tap t = kh * 3 + kw at (kh - 1, kw - 1)   (pack_conv)
+            const int shift = chunk * TSLICE + ky * PITCH + (kx - 1 + HX0) * REC;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xo[i] = xbase + shift + (mt0B + i) * 2 * PITCH;
+                if (HPX == 16) {
+                    const int col = (li & 15) + kx - 1;
+                    if ((unsigned)col > 15u) xo[i] = ZERO_OFF + lk * 16;
+                }
+            }
+        };
+        if constexpr (WDIR && PIPE) {
+            // software pipeline: the eight X fragments of K-step ks + 1 and the weight fragments of K-step ks + DB are requested BEFORE the twelve
+            // MFMAs of K-step ks (left to itself the scheduler sinks every fragment read to its first use: read, wait, one to three MFMAs, read ...)
+            f16x8 xc[2][2][2], xn[2][2][2];               // [k half][m-tile][hi | lo]
+            auto xread = [&](int ks, f16x8 (&q)[2][2][2]) {
+                int xo[2];
+                xoff(ks, xo);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        q[kb][i][0] = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32);
+                        q[kb][i][1] = *reinterpret_cast<const f16x8*>(smem + xo[i] + kb * 32 + 64);
+                    }
+            };
+            xread(0, xc);
+            for (int k0 = 0; k0 < TOTAL; k0 += DB) {
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const int ks = k0 + d;
+                    f16x8 wq[4];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) wq[f] = rwf[d][f];
+                    if (ks + DB < TOTAL) wfload(ks + DB, rwf[d]);
+                    if (ks + 1 < TOTAL) xread(ks + 1, xn);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[2 * kb], xc[kb][i][1], accB[i], 0, 0, 0);
+                            accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[2 * kb + 1], xc[kb][i][0], accB[i], 0, 0, 0);
+                            accB[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[2 * kb], xc[kb][i][0], accB[i], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) xc[kb][i][h] = xn[kb][i][h];
+                }
+            }
+        } else
         for (int k0 = 0; k0 < TOTAL; k0 += DB) {
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
@@ -346,17 +454,9 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
                     for (int f = 0; f < 4; ++f) wq[f] = rwf[d][f];
                     if (ks + DB < TOTAL) wfload(ks + DB, rwf[d]);
                 } else if (ks + DB < TOTAL) wbload(ks + DB, rwb[d]);
-                const int ky = tap / 3, kx = tap - ky * 3;                    // tap t = kh * 3 + kw at (kh - 1, kw - 1)   (pack_conv)
-                const int shift = chunk * TSLICE + ky * PITCH + (kx - 1 + HX0) * REC;
+                (void)chunk; (void)tap;
                 int xo[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    xo[i] = xbase + shift + (mt0B + i) * 2 * PITCH;
-                    if (HPX == 16) {
-                        const int col = (li & 15) + kx - 1;
-                        if ((unsigned)col > 15u) xo[i] = ZERO_OFF + lk * 16;
-                    }
-                }
+                xoff(ks, xo);
                 f16x8 wh[2], wl[2], xh[2][2], xl[2][2];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
@@ -608,6 +708,38 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
             for (int st = 0; st < NST; ++st) {
                 const bool more = st + 1 < NST || q + 1 < NCH;
                 if (more) wcload(st + 1 < NST ? q : q + 1, st + 1 < NST ? st + 1 : 0);
+                if constexpr (PIPE && ABL == 0) {
+                    // the stage's four (K-step, k half) sub-steps as a software pipeline: the fragments of sub-step u + 1 are requested before the MFMAs of u
+                    f16x8 fa[2][TMC][2], fb[2][TNC][2];       // [buffer][tile][hi | lo]
+                    auto fread = [&](int u, f16x8 (&qa)[TMC][2], f16x8 (&qb)[TNC][2]) {
+                        const int k2 = u >> 1, kb = u & 1;
+#pragma unroll
+                        for (int i = 0; i < TMC; ++i) {
+                            qa[i][0] = *reinterpret_cast<const f16x8*>(Af + (2 * st + k2) * T2SLICE + i * 32 * REC + kb * 32);
+                            qa[i][1] = *reinterpret_cast<const f16x8*>(Af + (2 * st + k2) * T2SLICE + i * 32 * REC + kb * 32 + 64);
+                        }
+#pragma unroll
+                        for (int j = 0; j < TNC; ++j) {
+                            qb[j][0] = *reinterpret_cast<const f16x8*>(Bf + k2 * 128 * WREC + j * 32 * WREC + w_sw[kb][0]);
+                            qb[j][1] = *reinterpret_cast<const f16x8*>(Bf + k2 * 128 * WREC + j * 32 * WREC + w_sw[kb][1]);
+                        }
+                    };
+                    fread(0, fa[0], fb[0]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u + 1 < 4) fread(u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < TMC; ++i)
+#pragma unroll
+                            for (int j = 0; j < TNC; ++j) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u & 1][i][1], fb[u & 1][j][0], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u & 1][i][0], fb[u & 1][j][1], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u & 1][i][0], fb[u & 1][j][0], acc[i][j], 0, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -702,7 +834,7 @@ hipError_t launch_resproj(const ResBlockParams& p, int F1, hipStream_t s)
     if (!resblock_supported(F1, p.H, p.W)) return hipErrorInvalidValue;
     const int grid = resblock_grid(F1, p.N, p.H, p.W);
     if (F1 == 64) hipLaunchKernelGGL((resblock_kernel<64, 8, 18, 2, 3, 1, false, 0, 64, 1, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((resblock_kernel<128, 4, 16, 4, 4, 1, false, 0, 256, 2, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((resblock_kernel<128, 4, 16, P2P_RB_DA3A, 4, 1, false, 0, 256, 2, true>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -715,7 +847,7 @@ hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s)
     // B / A.  The shipped library holds the default form only.
 #define P2P_RB_LAUNCH(KA_, DA_, PRIV_, ABL_)                                                                                              \
     do {                                                                                                                                  \
-        if (F1 == 64) hipLaunchKernelGGL((resblock_kernel<64, 8, 18, DA_, 3, KA_, PRIV_, ABL_>), dim3(grid), dim3(256), 0, s, p);      \
+        if (F1 == 64) hipLaunchKernelGGL((resblock_kernel<64, 8, 18, (DA_ == 4 ? P2P_RB_DA64 : DA_), 3, KA_, PRIV_, ABL_>), dim3(grid), dim3(256), 0, s, p);      \
         else hipLaunchKernelGGL((resblock_kernel<128, 4, 16, DA_, 4, KA_, PRIV_, ABL_>), dim3(grid), dim3(256), 0, s, p);              \
     } while (0)
 #ifdef P2P_DEV_SWITCHES
@@ -734,9 +866,7 @@ hipError_t launch_resblock(const ResBlockParams& p, int F1, hipStream_t s)
     default: break;
     }
     switch (variant) {
-    case 2: P2P_RB_LAUNCH(2, 2, false, 0); return hipGetLastError();
     case 5: P2P_RB_LAUNCH(1, 4, true, 0); return hipGetLastError();
-    case 6: P2P_RB_LAUNCH(2, 2, true, 0); return hipGetLastError();
     default: break;
     }
 #endif
