@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
 #pragma unroll
                 for (int j = 0; j < MA; ++j)
                     qx[k2][j] = (ABL & 4) ? f32x4{1.f, 2.f, 3.f, 4.f}
-                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[j] == OOB ? OOB : x_off[j] + (unsigned)s * 128u, 0, 0));
+                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, x_off[j], s * 128, 0));      // (the range check takes the vector offset alone: OOB stays out of range, the slice travels in the scalar offset)
 #pragma unroll
                 for (int j = 0; j < F1 / 32; ++j) qw[k2][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wa, wa_off[j], s * 128, 0));
             }
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void resblock_kernel(const ResBlockParams p
         f32x4 rxc[XP];
         auto xcload = [&](int sx) {
 #pragma unroll
-            for (int j = 0; j < XP; ++j) rxc[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xc_off[j] + (unsigned)sx * 128u, 0, 0));
+            for (int j = 0; j < XP; ++j) rxc[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xc_off[j], sx * 128, 0));
         };
         auto xcstore = [&]() {
 #pragma unroll
